@@ -1,0 +1,234 @@
+/*
+ * timeviper_hip.h — C ABI of libtimeviper_hip.so (gfx950 / MI355X).
+ *
+ * This is the drop-in boundary of the TimeViper long-video forward hot path.
+ * The reference (xiaomi-research/timeviper) is pure Python; its accelerated
+ * operators are calls into un-vendored wheels (mamba_ssm 2.2.5, causal_conv1d
+ * 1.5.2, flash_attn 2.8.0.post2, timm).  Each entry point below replaces one of
+ * those call sites.  A maintainer binds them with ctypes;
+ * `timeviper_amd/kernels.py` is exactly that binding, exposing the reference's
+ * Python operator names.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc / torch storage) unless the
+ *     name ends in `_host`;
+ *   - innermost dimension is contiguous, outer strides are given in ELEMENTS;
+ *   - `dtype` is a tv_dtype; fp32 statistics/accumulation inside every kernel;
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued, never
+ *     synchronised; no allocation happens inside any entry point (workspaces
+ *     are caller-provided, sizes from the *_workspace_bytes query);
+ *   - return value: 0 = TV_OK, negative = tv_status error (nothing launched).
+ */
+#ifndef TIMEVIPER_HIP_H
+#define TIMEVIPER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { TV_F32 = 0, TV_BF16 = 1, TV_F16 = 2 } tv_dtype;
+
+typedef enum {
+  TV_OK = 0,
+  TV_ERR_BAD_ARG = -1,      /* null pointer / non-positive size            */
+  TV_ERR_UNSUPPORTED = -2,  /* shape or dtype outside the compiled kernels */
+  TV_ERR_WORKSPACE = -3,    /* workspace too small                         */
+  TV_ERR_LAUNCH = -4        /* hipGetLastError() != hipSuccess             */
+} tv_status;
+
+/* ABI version; bumped whenever a signature changes. */
+int tv_abi_version(void);
+/* Human readable string of the last error on this thread (never NULL). */
+const char* tv_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * S2  causal depthwise conv1d (+bias, +SiLU), channels-last.
+ * Replaces causal_conv1d_fn(x=(B,C,L) view of (B,L,C), weight=(C,K), bias,
+ * activation="silu")        reference: modeling_nano.py:619-624 (CPU twin :705)
+ *   y[b,t,c] = act(bias[c] + sum_{j<K} w[c,j] * xpad[b, t-(K-1)+j, c])
+ * xpad rows t<0 come from `halo` ((B,K-1,C) contiguous, the K-1 rows that
+ * precede this shard) or are zero when halo==NULL.
+ * x,y: (B,L,C) with row strides in elements; weight (C,K) and bias (C) in
+ * `dtype` too (what nn.Conv1d holds after .to(dtype)); bias may be NULL.
+ * K in [2,4].  C % (16/sizeof(elem)) == 0.
+ * --------------------------------------------------------------------- */
+int tv_causal_conv1d_fwd(const void* x, const void* weight, const void* bias,
+                         const void* halo, void* y, int batch, int seqlen,
+                         int channels, int kernel, int64_t x_stride_b,
+                         int64_t x_stride_l, int64_t y_stride_b,
+                         int64_t y_stride_l, int dtype, int silu, void* stream);
+
+/* Single-token decode step, replaces causal_conv1d_update (:495-501).
+ * conv_state (B,C,K) contiguous, updated in place (shift left, append x).   */
+int tv_causal_conv1d_update(const void* x, void* conv_state, const void* weight,
+                            const void* bias, void* y, int batch, int channels,
+                            int kernel, int dtype, int silu, void* stream);
+
+/* ------------------------------------------------------------------------
+ * L1  RMSNorm, optionally fused with the preceding residual add.
+ * Replaces NemotronHRMSNorm.forward (modeling_nano.py:897-903) and the
+ * `residual + hidden_states` of NemotronHBlock.forward (:966).
+ *   s      = x (+ delta)            rounded to `dtype`  -> sum_out (if !NULL)
+ *   y[r,:] = w * s * rsqrt(mean(s^2) + eps)             (fp32 math)
+ * delta / sum_out may be NULL.  weight is `wdtype` (TV_F32 or == dtype).
+ * --------------------------------------------------------------------- */
+int tv_rmsnorm_fwd(const void* x, const void* delta, const void* weight,
+                   void* sum_out, void* y, int64_t rows, int dim,
+                   int64_t x_stride, int64_t delta_stride, int64_t sum_stride,
+                   int64_t y_stride, float eps, int dtype, int wdtype,
+                   void* stream);
+
+/* ------------------------------------------------------------------------
+ * S4  gated, grouped RMSNorm.  Replaces mamba_ssm rmsnorm_fn(x, weight,
+ * bias=None, z=gate, eps, group_size, norm_before_gate=False)
+ *                                        reference: modeling_nano.py:371-380
+ *   u = x * silu(z);  y = w * u * rsqrt(mean_group(u^2) + eps)
+ * z may be NULL (plain grouped RMSNorm).  dim % group_size == 0.
+ * --------------------------------------------------------------------- */
+int tv_rmsnorm_gated_fwd(const void* x, const void* z, const void* weight,
+                         void* y, int64_t rows, int dim, int group_size,
+                         int64_t x_stride, int64_t z_stride, int64_t y_stride,
+                         float eps, int dtype, int wdtype, void* stream);
+
+/* ------------------------------------------------------------------------
+ * S3  Mamba-2 SSD selective scan (prefill).  Replaces
+ * mamba_chunk_scan_combined(x, dt, A, B, C, chunk_size, D, z=None,
+ *     seq_idx=None, return_final_states=True, dt_bias, dt_softplus=True,
+ *     [dt_limit], [initial_states])
+ *                 reference: modeling_nano.py:639-653 (CPU twin :775-851)
+ *   dt_t  = clamp(softplus(dt_raw + dt_bias_h), dt_min, dt_max)
+ *   S_t   = exp(dt_t A_h) S_{t-1} + dt_t x_t (outer) B_t ;  S_{-1} = init
+ *   y_t   = S_t . C_t + D_h x_t ;   final = S_{L-1}
+ * x (B,L,H,P), dt (B,L,H), Bm/Cm (B,L,G,N), y (B,L,H,P) in `dtype` with
+ * per-tensor (batch,row) strides; A, D, dt_bias (H) fp32; init_state /
+ * final_state (B,H,P,N) fp32 contiguous (either may be NULL); D, dt_bias may
+ * be NULL.  group_map: 0 = head h reads group h / (H/G) (GPU reference and
+ * checkpoints), 1 = h % G (quirk of the reference's CPU torch_forward,
+ * :781-782).  The chunk size is an implementation detail (results are
+ * chunk-invariant up to rounding) and is not part of the ABI.
+ * total_decay (B,H) fp32, optional: sum_t dt_t*A_h over the sequence, the
+ * per-head log-decay a sequence-sharded caller needs to chain shard states.
+ * --------------------------------------------------------------------- */
+size_t tv_ssd_scan_workspace_bytes(int batch, int seqlen, int nheads,
+                                   int headdim, int ngroups, int dstate,
+                                   int dtype);
+int tv_ssd_scan_fwd(const void* x, const void* dt, const void* A,
+                    const void* Bm, const void* Cm, const void* D,
+                    const void* dt_bias, const void* init_state, void* y,
+                    void* final_state, void* total_decay, int batch,
+                    int seqlen, int nheads, int headdim, int ngroups,
+                    int dstate, int64_t x_stride_b, int64_t x_stride_l,
+                    int64_t dt_stride_b, int64_t dt_stride_l,
+                    int64_t b_stride_b, int64_t b_stride_l, int64_t c_stride_b,
+                    int64_t c_stride_l, int64_t y_stride_b, int64_t y_stride_l,
+                    int dtype, int dt_softplus, float dt_min, float dt_max,
+                    int group_map, void* workspace, size_t workspace_bytes,
+                    void* stream);
+
+/* Force a particular implementation (testing/benchmarking):
+ * 0 = auto, 1 = generic fp32 recurrence kernel, 2 = MFMA chunk-march kernel. */
+void tv_ssd_scan_set_impl(int impl);
+
+/* Single-token decode step, replaces selective_state_update (:528-539) with
+ * the head-broadcast arguments the reference passes (A,D,dt_bias per head). */
+int tv_selective_state_update(void* state, const void* x, const void* dt,
+                              const void* A, const void* Bm, const void* Cm,
+                              const void* D, const void* dt_bias, void* y,
+                              int batch, int nheads, int headdim, int ngroups,
+                              int dstate, int dtype, int dt_softplus,
+                              void* stream);
+
+/* ------------------------------------------------------------------------
+ * A1 / T3 / ViT  fused softmax attention forward (flash-style, no S x S
+ * matrix).  Replaces _flash_attention_forward (modeling_nano.py:1198-1209),
+ * F.scaled_dot_product_attention (:1300, cross_attention.py:310) and
+ * flash_attn_varlen_qkvpacked_func (flash_attention_class.py:59-66).
+ * q (B,Lq,Hq,D), k/v (B,Lk,Hkv,D), o (B,Lq,Hq,D); strides per tensor for
+ * (batch,row,head) in elements, D contiguous.  GQA: q head h uses kv head
+ * h / (Hq/Hkv).  causal!=0: bottom-right aligned (query i sees keys
+ * j <= i + Lk - Lq).  lse (B,Hq,Lq) fp32 optional (natural-log sum-exp of
+ * the scaled scores), used to merge partial results across sequence shards.
+ * D in {64,72,80,88,96,128}; dtype bf16/f16.
+ * --------------------------------------------------------------------- */
+int tv_flash_attn_fwd(const void* q, const void* k, const void* v, void* o,
+                      void* lse, int batch, int seqlen_q, int seqlen_k,
+                      int nheads_q, int nheads_kv, int headdim,
+                      int64_t q_stride_b, int64_t q_stride_l,
+                      int64_t q_stride_h, int64_t k_stride_b,
+                      int64_t k_stride_l, int64_t k_stride_h,
+                      int64_t v_stride_b, int64_t v_stride_l,
+                      int64_t v_stride_h, int64_t o_stride_b,
+                      int64_t o_stride_l, int64_t o_stride_h,
+                      float softmax_scale, int causal, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------
+ * T2  pdrop "attn" ranking.  Replaces modeling_nano.py:1822-1857,:1914-1939
+ * without the (L,L) mask: one query row (the last prompt token) against all
+ * keys <= that row, fp32 softmax per head, mean over heads, vision span only.
+ *   scores[j] = mean_h softmax_k(q_h . K_{g(h),k} * scale)[vis_start + j]
+ * q (Hq,D), k (L,Hkv,D) row/head strides; keys 0..n_keys-1 take part in the
+ * softmax (n_keys = query_row+1); scores (n_vis) fp32.
+ * workspace: tv_attn_rank_workspace_bytes.
+ * --------------------------------------------------------------------- */
+size_t tv_attn_rank_workspace_bytes(int n_keys, int nheads_q);
+int tv_attn_rank_scores(const void* q, const void* k, void* scores,
+                        int n_keys, int nheads_q, int nheads_kv, int headdim,
+                        int64_t k_stride_l, int64_t k_stride_h,
+                        int vis_start, int n_vis, float scale, int dtype,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
+ * T1  row gather (token keep / drop).  Replaces features[i][top_rank_index,:]
+ * and the concat of modeling_nano.py:1982-1989.
+ *   dst[r,:] = src[index[r],:]      index int64, values in [0, src_rows)
+ * --------------------------------------------------------------------- */
+int tv_gather_rows(const void* src, const int64_t* index, void* dst,
+                   int64_t n_rows, int dim, int64_t src_stride,
+                   int64_t dst_stride, int dtype, void* stream);
+
+/* uniform keep indices, reference :1946-1953: torch.linspace(0, n-1, keep,
+ * dtype=long) with CPU (double-step, symmetric halves) semantics; out int64
+ * (keep) on the device.  Bit-exact with the CPU reference for any n<2^31.  */
+int tv_uniform_keep_indices(int64_t* out, int64_t n_tokens, int64_t keep,
+                            int64_t offset, void* stream);
+
+/* complement of a sorted keep list inside [start, start+n): the dropped
+ * vision tokens (reference :1966-1970, torch.isin + ~mask).  out_dropped
+ * has n - n_keep entries, ascending.                                        */
+int tv_dropped_indices(const int64_t* keep_sorted, int64_t n_keep,
+                       int64_t start, int64_t n, int64_t* out_dropped,
+                       void* stream);
+
+/* ------------------------------------------------------------------------
+ * V1/V2  ViT patch embedding as an im2col-free MFMA GEMM.  Replaces
+ * timm PatchEmbed Conv2d(k=s=patch) (base_vision.py:146-170) and
+ * InternVideo2 PatchEmbed Conv3d(k=s=(1,p,p)) (vit_scale_clean.py:445-461).
+ *   out[f, py*gw+px, :] = W . patch(f,py,px) + bias (+ pos[py*gw+px,:])
+ * pixels (F,Cin,H,W) contiguous `dtype`; weight (Dout, Cin*p*p) `dtype`
+ * (the Conv weight flattened); bias (Dout) / pos (gh*gw, Dout) optional;
+ * out (F, gh*gw, Dout).
+ * --------------------------------------------------------------------- */
+int tv_patch_embed_fwd(const void* pixels, const void* weight, const void* bias,
+                       const void* pos, void* out, int frames, int cin,
+                       int height, int width, int patch, int dout, int dtype,
+                       void* stream);
+/* Same GEMM with an explicit frame layout: the pixel offset of (frame f,
+ * channel c) is (f / frames_per_group) * group_stride + (f % frames_per_group)
+ * * frame_stride + c * chan_stride (elements).  Conv3d input (B,C,T,H,W) with
+ * k=s=(1,p,p): frames_per_group=T, group_stride=C*T*H*W, frame_stride=H*W,
+ * chan_stride=T*H*W; output token order (b, t, py, px) as the reference's
+ * flatten(3).permute(0,2,3,1) (vit_scale_clean.py:455-460).               */
+int tv_patch_embed_strided_fwd(const void* pixels, const void* weight,
+                               const void* bias, const void* pos, void* out,
+                               int frames, int cin, int height, int width,
+                               int patch, int dout, int frames_per_group,
+                               int64_t group_stride, int64_t frame_stride,
+                               int64_t chan_stride, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TIMEVIPER_HIP_H */

@@ -1,0 +1,218 @@
+// L1 / S4: RMSNorm (+fused residual add) and gated grouped RMSNorm. HBM-bound:
+// every element is read once with 16-byte accesses, kept in registers across
+// the reduction, and written once.
+// Reference semantics: NemotronHRMSNorm.forward modeling_nano.py:897-903,
+// NemotronHBlock residual add :966, MambaRMSNormGated :371-380 (mamba_ssm
+// rmsnorm_fn with norm_before_gate=False).
+#include "common.hpp"
+
+namespace {
+
+constexpr int NORM_THREADS = 256;
+constexpr int NORM_MAXV = 4;  // 16-byte vectors cached per thread
+
+template <typename T>
+__device__ __forceinline__ float wload(const void* w, int wf32, int i) {
+  return wf32 ? ((const float*)w)[i] : to_f32(((const T*)w)[i]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(NORM_THREADS) void rmsnorm_kernel(
+    const T* __restrict__ x, const T* __restrict__ delta, const void* __restrict__ w,
+    T* __restrict__ sum_out, T* __restrict__ y, int D, int64_t xs, int64_t ds, int64_t ss,
+    int64_t ys, float eps, int wf32) {
+  constexpr int V = Vec16<T>::N;
+  typedef typename Vec16<T>::type vec_t;
+  __shared__ float red[NORM_THREADS / 64];
+  const int64_t row = blockIdx.x;
+  const int nv = D / V;
+  const T* xr = x + row * xs;
+  const T* dr = delta ? delta + row * ds : nullptr;
+  float vals[NORM_MAXV][V];
+  float ssq = 0.f;
+#pragma unroll
+  for (int k = 0; k < NORM_MAXV; ++k) {
+    const int iv = threadIdx.x + k * NORM_THREADS;
+    if (iv < nv) {
+      vec_t v = *(const vec_t*)(xr + (int64_t)iv * V);
+      if (dr) {
+        vec_t d = *(const vec_t*)(dr + (int64_t)iv * V);
+        vec_t sv;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          // the reference adds in the activation dtype: round, then normalise
+          sv[i] = from_f32<T>(to_f32(v[i]) + to_f32(d[i]));
+          vals[k][i] = to_f32(sv[i]);
+        }
+        if (sum_out) *(vec_t*)(sum_out + row * ss + (int64_t)iv * V) = sv;
+      } else {
+#pragma unroll
+        for (int i = 0; i < V; ++i) vals[k][i] = to_f32(v[i]);
+        if (sum_out) *(vec_t*)(sum_out + row * ss + (int64_t)iv * V) = v;
+      }
+#pragma unroll
+      for (int i = 0; i < V; ++i) ssq = fmaf(vals[k][i], vals[k][i], ssq);
+    }
+  }
+  ssq = wave_sum(ssq);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ssq;
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int i = 0; i < NORM_THREADS / 64; ++i) tot += red[i];
+  const float rstd = rsqrtf(tot / (float)D + eps);
+#pragma unroll
+  for (int k = 0; k < NORM_MAXV; ++k) {
+    const int iv = threadIdx.x + k * NORM_THREADS;
+    if (iv < nv) {
+      vec_t o;
+#pragma unroll
+      for (int i = 0; i < V; ++i)
+        o[i] = from_f32<T>(wload<T>(w, wf32, iv * V + i) * (vals[k][i] * rstd));
+      *(vec_t*)(y + row * ys + (int64_t)iv * V) = o;
+    }
+  }
+}
+
+// one wave per (row, group)
+template <typename T>
+__global__ __launch_bounds__(NORM_THREADS) void rmsnorm_gated_kernel(
+    const T* __restrict__ x, const T* __restrict__ z, const void* __restrict__ w,
+    T* __restrict__ y, int64_t rows, int D, int gsz, int64_t xs, int64_t zs, int64_t ys,
+    float eps, int wf32) {
+  constexpr int V = Vec16<T>::N;
+  typedef typename Vec16<T>::type vec_t;
+  const int ngroups = D / gsz;
+  const int64_t wid = (int64_t)blockIdx.x * (NORM_THREADS / 64) + (threadIdx.x >> 6);
+  if (wid >= rows * ngroups) return;
+  const int64_t row = wid / ngroups;
+  const int g = (int)(wid % ngroups);
+  const int lane = threadIdx.x & 63;
+  const int nv = gsz / V;
+  const T* xr = x + row * xs + (int64_t)g * gsz;
+  const T* zr = z ? z + row * zs + (int64_t)g * gsz : nullptr;
+  float vals[NORM_MAXV][V];
+  float ssq = 0.f;
+#pragma unroll
+  for (int k = 0; k < NORM_MAXV; ++k) {
+    const int iv = lane + k * 64;
+    if (iv < nv) {
+      vec_t v = *(const vec_t*)(xr + (int64_t)iv * V);
+      if (zr) {
+        vec_t zv = *(const vec_t*)(zr + (int64_t)iv * V);
+#pragma unroll
+        for (int i = 0; i < V; ++i) vals[k][i] = to_f32(v[i]) * silu_f(to_f32(zv[i]));
+      } else {
+#pragma unroll
+        for (int i = 0; i < V; ++i) vals[k][i] = to_f32(v[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < V; ++i) ssq = fmaf(vals[k][i], vals[k][i], ssq);
+    }
+  }
+  ssq = wave_sum(ssq);
+  const float rstd = rsqrtf(ssq / (float)gsz + eps);
+  T* yr = y + row * ys + (int64_t)g * gsz;
+#pragma unroll
+  for (int k = 0; k < NORM_MAXV; ++k) {
+    const int iv = lane + k * 64;
+    if (iv < nv) {
+      vec_t o;
+#pragma unroll
+      for (int i = 0; i < V; ++i)
+        o[i] = from_f32<T>(wload<T>(w, wf32, g * gsz + iv * V + i) * (vals[k][i] * rstd));
+      *(vec_t*)(yr + (int64_t)iv * V) = o;
+    }
+  }
+}
+
+template <typename T>
+int launch_rms(const void* x, const void* delta, const void* w, void* sum_out, void* y,
+               int64_t rows, int D, int64_t xs, int64_t ds, int64_t ss, int64_t ys, float eps,
+               int wf32, hipStream_t s) {
+  constexpr int V = Vec16<T>::N;
+  if (D % V || D / V > NORM_THREADS * NORM_MAXV)
+    TV_UNSUPPORTED("rmsnorm: dim %d not a multiple of %d or larger than %d", D, V,
+                   V * NORM_THREADS * NORM_MAXV);
+  rmsnorm_kernel<T><<<dim3((unsigned)rows), NORM_THREADS, 0, s>>>(
+      (const T*)x, (const T*)delta, w, (T*)sum_out, (T*)y, D, xs, ds, ss, ys, eps, wf32);
+  TV_LAUNCH_CHECK();
+}
+
+template <typename T>
+int launch_gated(const void* x, const void* z, const void* w, void* y, int64_t rows, int D,
+                 int gsz, int64_t xs, int64_t zs, int64_t ys, float eps, int wf32,
+                 hipStream_t s) {
+  constexpr int V = Vec16<T>::N;
+  if (gsz % V || gsz / V > 64 * NORM_MAXV)
+    TV_UNSUPPORTED("rmsnorm_gated: group_size %d not a multiple of %d or larger than %d", gsz,
+                   V, V * 64 * NORM_MAXV);
+  const int64_t nwaves = rows * (D / gsz);
+  const int64_t nblk = (nwaves + NORM_THREADS / 64 - 1) / (NORM_THREADS / 64);
+  rmsnorm_gated_kernel<T><<<dim3((unsigned)nblk), NORM_THREADS, 0, s>>>(
+      (const T*)x, (const T*)z, w, (T*)y, rows, D, gsz, xs, zs, ys, eps, wf32);
+  TV_LAUNCH_CHECK();
+}
+
+bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int tv_rmsnorm_fwd(const void* x, const void* delta, const void* weight,
+                              void* sum_out, void* y, int64_t rows, int dim, int64_t x_stride,
+                              int64_t delta_stride, int64_t sum_stride, int64_t y_stride,
+                              float eps, int dtype, int wdtype, void* stream) {
+  TV_CHECK_ARG(x && weight && y, "rmsnorm: null pointer");
+  TV_CHECK_ARG(rows >= 0 && dim > 0, "rmsnorm: bad sizes");
+  if (rows == 0) return TV_OK;
+  if (wdtype != TV_F32 && wdtype != dtype) TV_UNSUPPORTED("rmsnorm: wdtype must be f32 or dtype");
+  const int vec = dtype == TV_F32 ? 4 : 8;
+  if (!aligned16(x) || !aligned16(y) || (delta && !aligned16(delta)) ||
+      (sum_out && !aligned16(sum_out)) || x_stride % vec || y_stride % vec ||
+      (delta && delta_stride % vec) || (sum_out && sum_stride % vec))
+    TV_UNSUPPORTED("rmsnorm: pointers/strides must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const int wf32 = wdtype == TV_F32;
+  switch (dtype) {
+    case TV_F32:
+      return launch_rms<float>(x, delta, weight, sum_out, y, rows, dim, x_stride, delta_stride,
+                               sum_stride, y_stride, eps, 1, s);
+    case TV_BF16:
+      return launch_rms<bf16_t>(x, delta, weight, sum_out, y, rows, dim, x_stride, delta_stride,
+                                sum_stride, y_stride, eps, wf32, s);
+    case TV_F16:
+      return launch_rms<f16_t>(x, delta, weight, sum_out, y, rows, dim, x_stride, delta_stride,
+                               sum_stride, y_stride, eps, wf32, s);
+  }
+  TV_UNSUPPORTED("rmsnorm: dtype %d", dtype);
+}
+
+extern "C" int tv_rmsnorm_gated_fwd(const void* x, const void* z, const void* weight, void* y,
+                                    int64_t rows, int dim, int group_size, int64_t x_stride,
+                                    int64_t z_stride, int64_t y_stride, float eps, int dtype,
+                                    int wdtype, void* stream) {
+  TV_CHECK_ARG(x && weight && y, "rmsnorm_gated: null pointer");
+  TV_CHECK_ARG(rows >= 0 && dim > 0 && group_size > 0 && dim % group_size == 0,
+               "rmsnorm_gated: bad sizes (dim %d, group %d)", dim, group_size);
+  if (rows == 0) return TV_OK;
+  if (wdtype != TV_F32 && wdtype != dtype)
+    TV_UNSUPPORTED("rmsnorm_gated: wdtype must be f32 or dtype");
+  const int vec = dtype == TV_F32 ? 4 : 8;
+  if (!aligned16(x) || !aligned16(y) || (z && !aligned16(z)) || x_stride % vec ||
+      y_stride % vec || (z && z_stride % vec))
+    TV_UNSUPPORTED("rmsnorm_gated: pointers/strides must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const int wf32 = wdtype == TV_F32;
+  switch (dtype) {
+    case TV_F32:
+      return launch_gated<float>(x, z, weight, y, rows, dim, group_size, x_stride, z_stride,
+                                 y_stride, eps, 1, s);
+    case TV_BF16:
+      return launch_gated<bf16_t>(x, z, weight, y, rows, dim, group_size, x_stride, z_stride,
+                                  y_stride, eps, wf32, s);
+    case TV_F16:
+      return launch_gated<f16_t>(x, z, weight, y, rows, dim, group_size, x_stride, z_stride,
+                                 y_stride, eps, wf32, s);
+  }
+  TV_UNSUPPORTED("rmsnorm_gated: dtype %d", dtype);
+}

@@ -1,0 +1,192 @@
+// V1/V2: ViT patch embedding (Conv2d / Conv3d with kernel == stride == patch) as an
+// im2col-free MFMA GEMM:  out[m, n] = sum_k W[n, k] * patch(m)[k] + bias[n] + pos[m % P, n]
+// with m = (frame, py, px), k = (c, dy, dx).  Patch pixels are gathered straight
+// from the NCHW frame into an LDS tile whose (c,dy) rows are padded from `patch`
+// to 16 columns, so every MFMA k-step of 16 is one image row of one patch; the
+// weight tile gets the same padding on the fly.  The product is formed as
+// W . patches^T (32x32x16 MFMA) so the patch index sits on the lane and each lane
+// stores 4 consecutive output channels.
+// Reference: timm PatchEmbed via TimmViTBackbone (base_vision.py:146-170,:274-278);
+// InternVideo2 PatchEmbed Conv3d k=s=(1,14,14) (vit_scale_clean.py:445-461).
+#include "common.hpp"
+
+namespace {
+
+constexpr int PE_TM = 128, PE_TN = 128;
+constexpr int PE_RPS = 6;                 // (c,dy) rows per K step
+constexpr int PE_KS = PE_RPS * 16;        // 96
+constexpr int PE_STR = PE_KS + 8;         // LDS row stride (elements)
+constexpr int PE_THREADS = 256;
+
+struct PeArgs {
+  const void *pix, *w, *bias, *pos;
+  void* out;
+  int64_t M;                // frames * gh * gw
+  int cin, H, W, p, gh, gw, dout;
+  int fpg;                  // frames per group (T for Conv3d layout, else 1)
+  int64_t group_stride, frame_stride, chan_stride;
+};
+
+template <typename T> struct PeMma;
+template <> struct PeMma<bf16_t> {
+  typedef bf16x8 v8; typedef bf16x4 v4;
+  static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct PeMma<f16_t> {
+  typedef f16x8 v8; typedef f16x4 v4;
+  static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+template <typename T>
+__global__ __launch_bounds__(PE_THREADS) void patch_embed_kernel(PeArgs a) {
+  typedef typename PeMma<T>::v8 v8;
+  typedef typename PeMma<T>::v4 v4;
+  __shared__ __attribute__((aligned(16))) T sP[PE_TM * PE_STR];  // patches  [m][k]
+  __shared__ __attribute__((aligned(16))) T sW[PE_TN * PE_STR];  // weights  [n][k]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 31, hh = lane >> 5;
+  const int wm = wave & 1, wn = wave >> 1;       // 2x2 waves, 64x64 each
+  const int64_t m0 = (int64_t)blockIdx.x * PE_TM;
+  const int n0 = blockIdx.y * PE_TN;
+  const int npatch = a.gh * a.gw;
+  const int rows_total = a.cin * a.p;            // (c,dy) rows
+  const int kw = a.cin * a.p * a.p;              // weight row length
+
+  f32x16 acc[2][2];  // [nt][mt]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const T* pix = (const T*)a.pix;
+  const T* wgt = (const T*)a.w;
+
+  for (int row0 = 0; row0 < rows_total; row0 += PE_RPS) {
+    __syncthreads();
+    // stage patches: (m, row) pairs, `p` elements each, padded to 16
+    for (int i = tid; i < PE_TM * PE_RPS; i += PE_THREADS) {
+      const int ml = i % PE_TM, rl = i / PE_TM;
+      const int64_t m = m0 + ml;
+      const int row = row0 + rl;
+      T* dst = sP + ml * PE_STR + rl * 16;
+      if (m < a.M && row < rows_total) {
+        const int64_t f = m / npatch;
+        const int pi = (int)(m % npatch);
+        const int py = pi / a.gw, px = pi % a.gw;
+        const int c = row / a.p, dy = row % a.p;
+        const T* src = pix + (f / a.fpg) * a.group_stride + (f % a.fpg) * a.frame_stride +
+                       (int64_t)c * a.chan_stride + (int64_t)(py * a.p + dy) * a.W + px * a.p;
+        for (int dx = 0; dx < 16; ++dx) dst[dx] = dx < a.p ? src[dx] : from_f32<T>(0.f);
+      } else {
+        for (int dx = 0; dx < 16; ++dx) dst[dx] = from_f32<T>(0.f);
+      }
+    }
+    for (int i = tid; i < PE_TN * PE_RPS; i += PE_THREADS) {
+      const int nl = i % PE_TN, rl = i / PE_TN;
+      const int n = n0 + nl;
+      const int row = row0 + rl;
+      T* dst = sW + nl * PE_STR + rl * 16;
+      if (n < a.dout && row < rows_total) {
+        const T* src = wgt + (int64_t)n * kw + (int64_t)row * a.p;
+        for (int dx = 0; dx < 16; ++dx) dst[dx] = dx < a.p ? src[dx] : from_f32<T>(0.f);
+      } else {
+        for (int dx = 0; dx < 16; ++dx) dst[dx] = from_f32<T>(0.f);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < PE_RPS; ++ks) {
+      v8 wf[2], pf[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        wf[t] = *(const v8*)(sW + (wn * 64 + t * 32 + r) * PE_STR + ks * 16 + hh * 8);
+        pf[t] = *(const v8*)(sP + (wm * 64 + t * 32 + r) * PE_STR + ks * 16 + hh * 8);
+      }
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+          acc[nt][mt] = PeMma<T>::mfma(wf[nt], pf[mt], acc[nt][mt]);
+    }
+  }
+
+  // epilogue: lane owns patch m (column), 4 consecutive channels per register group
+  const T* bias = (const T*)a.bias;
+  const T* pos = (const T*)a.pos;
+  T* out = (T*)a.out;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int64_t m = m0 + wm * 64 + mt * 32 + r;
+    if (m >= a.M) continue;
+    const int pi = (int)(m % npatch);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wn * 64 + nt * 32 + 8 * g + 4 * hh;
+        if (n + 3 < a.dout) {
+          v4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float v = acc[nt][mt][4 * g + j];
+            if (bias) v += to_f32(bias[n + j]);
+            if (pos) v += to_f32(pos[(int64_t)pi * a.dout + n + j]);
+            o[j] = from_f32<T>(v);
+          }
+          *(v4*)(out + m * a.dout + n) = o;
+        } else {
+          for (int j = 0; j < 4 && n + j < a.dout; ++j) {
+            float v = acc[nt][mt][4 * g + j];
+            if (bias) v += to_f32(bias[n + j]);
+            if (pos) v += to_f32(pos[(int64_t)pi * a.dout + n + j]);
+            out[m * a.dout + n + j] = from_f32<T>(v);
+          }
+        }
+      }
+  }
+}
+
+}  // namespace
+
+// extended entry used by the Conv3d (B,C,T,H,W) layout; tv_patch_embed_fwd wraps it
+extern "C" int tv_patch_embed_strided_fwd(const void* pixels, const void* weight,
+                                          const void* bias, const void* pos, void* out,
+                                          int frames, int cin, int height, int width, int patch,
+                                          int dout, int frames_per_group, int64_t group_stride,
+                                          int64_t frame_stride, int64_t chan_stride, int dtype,
+                                          void* stream) {
+  TV_CHECK_ARG(pixels && weight && out, "patch_embed: null pointer");
+  TV_CHECK_ARG(frames >= 0 && cin > 0 && height > 0 && width > 0 && patch > 0 && dout > 0 &&
+                   frames_per_group > 0,
+               "patch_embed: bad sizes");
+  if (patch > 16) TV_UNSUPPORTED("patch_embed: patch %d > 16", patch);
+  if (dtype != TV_BF16 && dtype != TV_F16) TV_UNSUPPORTED("patch_embed: dtype must be bf16/f16");
+  if (dout % 4 || ((uintptr_t)out & 7)) TV_UNSUPPORTED("patch_embed: dout must be a multiple of 4");
+  if (frames == 0) return TV_OK;
+  PeArgs a;
+  a.pix = pixels; a.w = weight; a.bias = bias; a.pos = pos; a.out = out;
+  a.cin = cin; a.H = height; a.W = width; a.p = patch;
+  a.gh = height / patch; a.gw = width / patch; a.dout = dout;
+  a.M = (int64_t)frames * a.gh * a.gw;
+  a.fpg = frames_per_group; a.group_stride = group_stride; a.frame_stride = frame_stride;
+  a.chan_stride = chan_stride;
+  dim3 grid((unsigned)((a.M + PE_TM - 1) / PE_TM), (dout + PE_TN - 1) / PE_TN);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TV_BF16) patch_embed_kernel<bf16_t><<<grid, PE_THREADS, 0, st>>>(a);
+  else patch_embed_kernel<f16_t><<<grid, PE_THREADS, 0, st>>>(a);
+  TV_LAUNCH_CHECK();
+}
+
+extern "C" int tv_patch_embed_fwd(const void* pixels, const void* weight, const void* bias,
+                                  const void* pos, void* out, int frames, int cin, int height,
+                                  int width, int patch, int dout, int dtype, void* stream) {
+  return tv_patch_embed_strided_fwd(pixels, weight, bias, pos, out, frames, cin, height, width,
+                                    patch, dout, 1, (int64_t)cin * height * width, 0,
+                                    (int64_t)height * width, dtype, stream);
+}

@@ -1,0 +1,221 @@
+// S3 (generic path): Mamba-2 selective scan as the exact fp32 token recurrence
+//   S_t = exp(dt_t A_h) S_{t-1} + dt_t x_t (x) B_t ;  y_t = S_t . C_t + D_h x_t
+// for any dtype / head_dim / d_state (BASELINE config 1: fp32, N=16).  One
+// workgroup owns (batch, head, 16 columns of P); a thread owns one column and
+// every 16th state index n, keeps its state slice in registers for the whole
+// sequence, and the 16 n-lanes of a column reduce y with DPP shuffles.  Token
+// tiles are staged through LDS with coalesced loads.  The bf16 Nano-shape fast
+// path is the MFMA chunk-march kernel in ssd_march.hip.
+// Reference semantics: modeling_nano.py:639-653, CPU twin :775-851.
+#include "common.hpp"
+
+namespace {
+
+constexpr int GS_TT = 32;    // tokens staged per tile
+constexpr int GS_PB = 16;    // P columns per workgroup
+constexpr int GS_NL = 16;    // n-lanes per column
+constexpr int GS_THREADS = GS_PB * GS_NL;
+
+struct SsdArgs {
+  const void *x, *dt, *Bm, *Cm;
+  const float *A, *D, *dt_bias, *init;
+  void* y;
+  float *final_state, *total_decay;
+  int L, H, P, G, N;
+  int64_t xsb, xsl, dsb, dsl, bsb, bsl, csb, csl, ysb, ysl;
+  int softplus, group_map;
+  float dt_min, dt_max;
+};
+
+template <typename T, int NPT>
+__global__ __launch_bounds__(GS_THREADS) void ssd_generic_kernel(SsdArgs a) {
+  extern __shared__ float smem[];
+  const int N = a.N;
+  float* sB = smem;                    // [TT][N]
+  float* sC = sB + GS_TT * N;          // [TT][N]
+  float* sX = sC + GS_TT * N;          // [TT][PB]
+  float* sY = sX + GS_TT * GS_PB;      // [TT][PB]
+  float* sDt = sY + GS_TT * GS_PB;     // [TT]
+  float* sDa = sDt + GS_TT;            // [TT]
+
+  const int pb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x;
+  const int pl = tid / GS_NL, nl = tid % GS_NL;
+  const int p = pb * GS_PB + pl;
+  const int g = a.group_map ? (h % a.G) : (h / (a.H / a.G));
+  const float Ah = a.A[h];
+  const float Dh = a.D ? a.D[h] : 0.f;
+  const float bias = a.dt_bias ? a.dt_bias[h] : 0.f;
+
+  const T* xb = (const T*)a.x + (int64_t)b * a.xsb + (int64_t)h * a.P;
+  const T* dtb = (const T*)a.dt + (int64_t)b * a.dsb + h;
+  const T* Bb = (const T*)a.Bm + (int64_t)b * a.bsb + (int64_t)g * N;
+  const T* Cb = (const T*)a.Cm + (int64_t)b * a.csb + (int64_t)g * N;
+  T* yb = (T*)a.y + (int64_t)b * a.ysb + (int64_t)h * a.P;
+
+  float s[NPT];
+#pragma unroll
+  for (int j = 0; j < NPT; ++j) {
+    const int n = nl + GS_NL * j;
+    s[j] = (a.init && p < a.P && n < N)
+               ? a.init[(((int64_t)b * a.H + h) * a.P + p) * N + n] : 0.f;
+  }
+  float decay_sum = 0.f;
+
+  for (int t0 = 0; t0 < a.L; t0 += GS_TT) {
+    const int tt = min(GS_TT, a.L - t0);
+    __syncthreads();
+    for (int i = tid; i < tt * N; i += GS_THREADS) {
+      const int t = i / N, n = i % N;
+      sB[i] = to_f32(Bb[(int64_t)(t0 + t) * a.bsl + n]);
+      sC[i] = to_f32(Cb[(int64_t)(t0 + t) * a.csl + n]);
+    }
+    for (int i = tid; i < tt * GS_PB; i += GS_THREADS) {
+      const int t = i / GS_PB, c = pb * GS_PB + i % GS_PB;
+      sX[i] = c < a.P ? to_f32(xb[(int64_t)(t0 + t) * a.xsl + c]) : 0.f;
+    }
+    if (tid < tt) {
+      float d = to_f32(dtb[(int64_t)(t0 + tid) * a.dsl]) + bias;
+      if (a.softplus) d = softplus_f(d);
+      d = fminf(fmaxf(d, a.dt_min), a.dt_max);
+      sDt[tid] = d;
+      sDa[tid] = d * Ah;
+    }
+    __syncthreads();
+    for (int t = 0; t < tt; ++t) {
+      const float dtv = sDt[t];
+      const float da = sDa[t];
+      const float dec = expf(da);
+      const float xr = sX[t * GS_PB + pl];
+      const float xv = dtv * xr;
+      float acc = 0.f;
+#pragma unroll
+      for (int j = 0; j < NPT; ++j) {
+        const int n = nl + GS_NL * j;
+        if (n < N) {
+          s[j] = fmaf(dec, s[j], xv * sB[t * N + n]);
+          acc = fmaf(s[j], sC[t * N + n], acc);
+        }
+      }
+      acc += __shfl_xor(acc, 8, 64);
+      acc += __shfl_xor(acc, 4, 64);
+      acc += __shfl_xor(acc, 2, 64);
+      acc += __shfl_xor(acc, 1, 64);
+      if (nl == 0) sY[t * GS_PB + pl] = fmaf(Dh, xr, acc);
+      decay_sum += da;
+    }
+    __syncthreads();
+    for (int i = tid; i < tt * GS_PB; i += GS_THREADS) {
+      const int t = i / GS_PB, c = pb * GS_PB + i % GS_PB;
+      if (c < a.P) yb[(int64_t)(t0 + t) * a.ysl + c] = from_f32<T>(sY[i]);
+    }
+  }
+  if (a.final_state && p < a.P) {
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+      const int n = nl + GS_NL * j;
+      if (n < N) a.final_state[(((int64_t)b * a.H + h) * a.P + p) * N + n] = s[j];
+    }
+  }
+  if (a.total_decay && pb == 0 && tid == 0) a.total_decay[(int64_t)b * a.H + h] = decay_sum;
+}
+
+template <typename T>
+int launch_generic(const SsdArgs& a, int B, hipStream_t st) {
+  const int npt = (a.N + GS_NL - 1) / GS_NL;
+  dim3 grid((a.P + GS_PB - 1) / GS_PB, a.H, B);
+  const size_t lds = (size_t)(2 * GS_TT * a.N + 2 * GS_TT * GS_PB + 2 * GS_TT) * sizeof(float);
+#define TV_GS_CASE(NP)                                                                \
+  if (npt <= NP) {                                                                    \
+    ssd_generic_kernel<T, NP><<<grid, GS_THREADS, lds, st>>>(a);                      \
+    TV_LAUNCH_CHECK();                                                                \
+  }
+  TV_GS_CASE(1)
+  TV_GS_CASE(2)
+  TV_GS_CASE(4)
+  TV_GS_CASE(8)
+  TV_GS_CASE(16)
+#undef TV_GS_CASE
+  TV_UNSUPPORTED("ssd_scan: d_state %d > 256", a.N);
+}
+
+// ---------------------------------------------------------------- decode
+template <typename T>
+__global__ void state_update_kernel(float* __restrict__ state, const T* __restrict__ x,
+                                    const T* __restrict__ dt, const float* __restrict__ A,
+                                    const T* __restrict__ Bm, const T* __restrict__ Cm,
+                                    const float* __restrict__ D, const float* __restrict__ dt_bias,
+                                    T* __restrict__ y, int H, int P, int G, int N, int softplus) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int h = blockIdx.y, b = blockIdx.z;
+  if (p >= P) return;
+  const int g = h / (H / G);
+  float d = to_f32(dt[(int64_t)b * H + h]) + (dt_bias ? dt_bias[h] : 0.f);
+  if (softplus) d = softplus_f(d);
+  const float dec = expf(d * A[h]);
+  const float xr = to_f32(x[((int64_t)b * H + h) * P + p]);
+  const float xv = d * xr;
+  float* s = state + (((int64_t)b * H + h) * P + p) * N;
+  const T* Br = Bm + ((int64_t)b * G + g) * N;
+  const T* Cr = Cm + ((int64_t)b * G + g) * N;
+  float acc = 0.f;
+  for (int n = 0; n < N; ++n) {
+    const float v = fmaf(dec, s[n], xv * to_f32(Br[n]));
+    s[n] = v;
+    acc = fmaf(v, to_f32(Cr[n]), acc);
+  }
+  y[((int64_t)b * H + h) * P + p] = from_f32<T>(fmaf(D ? D[h] : 0.f, xr, acc));
+}
+
+}  // namespace
+
+// called from ssd_scan.hip (dispatcher)
+int tv_ssd_generic_launch(const void* x, const void* dt, const void* A, const void* Bm,
+                          const void* Cm, const void* D, const void* dt_bias,
+                          const void* init_state, void* y, void* final_state, void* total_decay,
+                          int batch, int seqlen, int nheads, int headdim, int ngroups, int dstate,
+                          int64_t xsb, int64_t xsl, int64_t dsb, int64_t dsl, int64_t bsb,
+                          int64_t bsl, int64_t csb, int64_t csl, int64_t ysb, int64_t ysl,
+                          int dtype, int dt_softplus, float dt_min, float dt_max, int group_map,
+                          hipStream_t st) {
+  SsdArgs a;
+  a.x = x; a.dt = dt; a.Bm = Bm; a.Cm = Cm;
+  a.A = (const float*)A; a.D = (const float*)D; a.dt_bias = (const float*)dt_bias;
+  a.init = (const float*)init_state; a.y = y; a.final_state = (float*)final_state;
+  a.total_decay = (float*)total_decay;
+  a.L = seqlen; a.H = nheads; a.P = headdim; a.G = ngroups; a.N = dstate;
+  a.xsb = xsb; a.xsl = xsl; a.dsb = dsb; a.dsl = dsl; a.bsb = bsb; a.bsl = bsl;
+  a.csb = csb; a.csl = csl; a.ysb = ysb; a.ysl = ysl;
+  a.softplus = dt_softplus; a.group_map = group_map; a.dt_min = dt_min; a.dt_max = dt_max;
+  switch (dtype) {
+    case TV_F32: return launch_generic<float>(a, batch, st);
+    case TV_BF16: return launch_generic<bf16_t>(a, batch, st);
+    case TV_F16: return launch_generic<f16_t>(a, batch, st);
+  }
+  TV_UNSUPPORTED("ssd_scan: dtype %d", dtype);
+}
+
+extern "C" int tv_selective_state_update(void* state, const void* x, const void* dt,
+                                         const void* A, const void* Bm, const void* Cm,
+                                         const void* D, const void* dt_bias, void* y, int batch,
+                                         int nheads, int headdim, int ngroups, int dstate,
+                                         int dtype, int dt_softplus, void* stream) {
+  TV_CHECK_ARG(state && x && dt && A && Bm && Cm && y, "selective_state_update: null pointer");
+  TV_CHECK_ARG(batch > 0 && nheads > 0 && headdim > 0 && ngroups > 0 && dstate > 0 &&
+                   nheads % ngroups == 0,
+               "selective_state_update: bad sizes");
+  dim3 grid((headdim + 63) / 64, nheads, batch);
+  hipStream_t s = (hipStream_t)stream;
+#define TV_SU(T)                                                                              \
+  state_update_kernel<T><<<grid, 64, 0, s>>>((float*)state, (const T*)x, (const T*)dt,        \
+      (const float*)A, (const T*)Bm, (const T*)Cm, (const float*)D, (const float*)dt_bias,    \
+      (T*)y, nheads, headdim, ngroups, dstate, dt_softplus)
+  switch (dtype) {
+    case TV_F32: TV_SU(float); break;
+    case TV_BF16: TV_SU(bf16_t); break;
+    case TV_F16: TV_SU(f16_t); break;
+    default: TV_UNSUPPORTED("selective_state_update: dtype %d", dtype);
+  }
+#undef TV_SU
+  TV_LAUNCH_CHECK();
+}

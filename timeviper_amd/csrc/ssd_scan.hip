@@ -1,0 +1,84 @@
+// S3 dispatcher: tv_ssd_scan_fwd picks the MFMA chunk-march kernel (bf16/f16,
+// d_state 128, MFMA-tileable head_dim) or the generic fp32 recurrence kernel.
+#include "common.hpp"
+
+int tv_ssd_generic_launch(const void* x, const void* dt, const void* A, const void* Bm,
+                          const void* Cm, const void* D, const void* dt_bias,
+                          const void* init_state, void* y, void* final_state, void* total_decay,
+                          int batch, int seqlen, int nheads, int headdim, int ngroups, int dstate,
+                          int64_t xsb, int64_t xsl, int64_t dsb, int64_t dsl, int64_t bsb,
+                          int64_t bsl, int64_t csb, int64_t csl, int64_t ysb, int64_t ysl,
+                          int dtype, int dt_softplus, float dt_min, float dt_max, int group_map,
+                          hipStream_t st);
+
+// ssd_march.hip
+bool tv_ssd_march_supported(int seqlen, int nheads, int headdim, int ngroups, int dstate,
+                            int dtype, int64_t xsl, int64_t bsl, int64_t csl, int64_t ysl,
+                            const void* x, const void* Bm, const void* Cm, const void* y);
+size_t tv_ssd_march_workspace_bytes(int batch, int seqlen, int nheads, int headdim, int ngroups,
+                                    int dstate);
+int tv_ssd_march_launch(const void* x, const void* dt, const void* A, const void* Bm,
+                        const void* Cm, const void* D, const void* dt_bias,
+                        const void* init_state, void* y, void* final_state, void* total_decay,
+                        int batch, int seqlen, int nheads, int headdim, int ngroups, int dstate,
+                        int64_t xsb, int64_t xsl, int64_t dsb, int64_t dsl, int64_t bsb,
+                        int64_t bsl, int64_t csb, int64_t csl, int64_t ysb, int64_t ysl,
+                        int dtype, int dt_softplus, float dt_min, float dt_max, int group_map,
+                        void* workspace, size_t workspace_bytes, hipStream_t st);
+
+static int g_ssd_impl = 0;
+
+extern "C" void tv_ssd_scan_set_impl(int impl) { g_ssd_impl = impl; }
+
+extern "C" size_t tv_ssd_scan_workspace_bytes(int batch, int seqlen, int nheads, int headdim,
+                                              int ngroups, int dstate, int dtype) {
+  if (dtype == TV_F32) return 0;
+  return tv_ssd_march_workspace_bytes(batch, seqlen, nheads, headdim, ngroups, dstate);
+}
+
+extern "C" int tv_ssd_scan_fwd(const void* x, const void* dt, const void* A, const void* Bm,
+                               const void* Cm, const void* D, const void* dt_bias,
+                               const void* init_state, void* y, void* final_state,
+                               void* total_decay, int batch, int seqlen, int nheads, int headdim,
+                               int ngroups, int dstate, int64_t x_stride_b, int64_t x_stride_l,
+                               int64_t dt_stride_b, int64_t dt_stride_l, int64_t b_stride_b,
+                               int64_t b_stride_l, int64_t c_stride_b, int64_t c_stride_l,
+                               int64_t y_stride_b, int64_t y_stride_l, int dtype, int dt_softplus,
+                               float dt_min, float dt_max, int group_map, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+  TV_CHECK_ARG(x && dt && A && Bm && Cm && y, "ssd_scan: null pointer");
+  TV_CHECK_ARG(batch > 0 && seqlen >= 0 && nheads > 0 && headdim > 0 && ngroups > 0 &&
+                   dstate > 0 && nheads % ngroups == 0,
+               "ssd_scan: bad sizes (B %d L %d H %d P %d G %d N %d)", batch, seqlen, nheads,
+               headdim, ngroups, dstate);
+  TV_CHECK_ARG(dtype == TV_F32 || dtype == TV_BF16 || dtype == TV_F16, "ssd_scan: dtype %d", dtype);
+  hipStream_t st = (hipStream_t)stream;
+  if (seqlen == 0) {
+    // empty sequence: the state passes through unchanged
+    if (final_state) {
+      const size_t bytes = (size_t)batch * nheads * headdim * dstate * sizeof(float);
+      if (init_state) (void)hipMemcpyAsync(final_state, init_state, bytes, hipMemcpyDeviceToDevice, st);
+      else (void)hipMemsetAsync(final_state, 0, bytes, st);
+    }
+    if (total_decay) (void)hipMemsetAsync(total_decay, 0, (size_t)batch * nheads * sizeof(float), st);
+    return TV_OK;
+  }
+  bool march = g_ssd_impl != 1 &&
+               tv_ssd_march_supported(seqlen, nheads, headdim, ngroups, dstate, dtype, x_stride_l,
+                                      b_stride_l, c_stride_l, y_stride_l, x, Bm, Cm, y);
+  if (g_ssd_impl == 2 && !march)
+    TV_UNSUPPORTED("ssd_scan: MFMA march kernel forced but shape/dtype unsupported");
+  if (march) {
+    return tv_ssd_march_launch(x, dt, A, Bm, Cm, D, dt_bias, init_state, y, final_state,
+                               total_decay, batch, seqlen, nheads, headdim, ngroups, dstate,
+                               x_stride_b, x_stride_l, dt_stride_b, dt_stride_l, b_stride_b,
+                               b_stride_l, c_stride_b, c_stride_l, y_stride_b, y_stride_l, dtype,
+                               dt_softplus, dt_min, dt_max, group_map, workspace, workspace_bytes,
+                               st);
+  }
+  return tv_ssd_generic_launch(x, dt, A, Bm, Cm, D, dt_bias, init_state, y, final_state,
+                               total_decay, batch, seqlen, nheads, headdim, ngroups, dstate,
+                               x_stride_b, x_stride_l, dt_stride_b, dt_stride_l, b_stride_b,
+                               b_stride_l, c_stride_b, c_stride_l, y_stride_b, y_stride_l, dtype,
+                               dt_softplus, dt_min, dt_max, group_map, st);
+}

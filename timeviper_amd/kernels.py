@@ -1,0 +1,408 @@
+"""Operator API of the TimeViper hot path, bound to the gfx950 kernels.
+
+Each function keeps the NAME and ARGUMENT MEANING of the third-party operator
+the reference calls (SURVEY.md §8b "inner boundary"), so `NemotronHMamba2Mixer`
+and friends read like the reference's:
+
+    causal_conv1d_fn / causal_conv1d_update      modeling_nano.py:619-624 / :495-501
+    mamba_chunk_scan_combined                    modeling_nano.py:639-653
+    selective_state_update                       modeling_nano.py:528-539
+    rmsnorm_fn                                   modeling_nano.py:372-380
+    flash_attn_func / _flash_attention_forward   modeling_nano.py:1198-1209
+    flash_attn_varlen_qkvpacked_func             flash_attention_class.py:59-66
+    scaled_dot_product_attention                 cross_attention.py:310-317
+
+torch is plumbing only (device memory, current stream).  There is no CPU or
+eager fallback: tensors must live on the GPU and the HIP library must be built.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from . import _capi
+from ._capi import TV_BF16, TV_F16, TV_F32, TimeViperHipError, check
+
+_DT = {torch.float32: TV_F32, torch.bfloat16: TV_BF16, torch.float16: TV_F16}
+
+
+def _dt(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TimeViperHipError(f"unsupported dtype {t.dtype}") from None
+
+
+def _gpu(*ts: Optional[torch.Tensor]) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise TimeViperHipError(
+                "timeviper_amd kernels run on the GPU only (got a CPU tensor); "
+                "there is no CPU fallback in the product path"
+            )
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _rows2d(t: torch.Tensor) -> torch.Tensor:
+    """View (..., D) as (rows, D) with one row stride, copying only if needed."""
+    if t.stride(-1) != 1:
+        t = t.contiguous()
+    if t.dim() == 2:
+        return t
+    try:
+        return t.view(-1, t.shape[-1])
+    except RuntimeError:
+        return t.reshape(-1, t.shape[-1])
+
+
+# --------------------------------------------------------------------- conv1d
+def causal_conv1d_fn(x, weight, bias=None, seq_idx=None, initial_states=None,
+                     return_final_states=False, final_states_out=None, activation=None,
+                     halo=None):
+    """x: (B, C, L) — the reference passes the transposed view of a (B, L, C)
+    tensor, which is exactly the channels-last layout the kernel wants.
+    weight (C, K), bias (C).  Returns (B, C, L) (again a transposed view).
+    `halo` (B, K-1, C): rows preceding this shard (sequence sharding)."""
+    if seq_idx is not None or initial_states is not None or return_final_states:
+        raise TimeViperHipError("causal_conv1d_fn: seq_idx/initial_states/final_states unsupported")
+    if activation not in (None, "silu", "swish"):
+        raise TimeViperHipError(f"causal_conv1d_fn: activation {activation!r}")
+    _gpu(x, weight, bias, halo)
+    B, Cc, L = x.shape
+    xl = x.transpose(1, 2)  # (B, L, C)
+    if xl.stride(2) != 1:
+        xl = xl.contiguous()
+    K = weight.shape[-1]
+    w = weight.reshape(Cc, K).to(x.dtype).contiguous()
+    b = None if bias is None else bias.to(x.dtype).contiguous()
+    if halo is not None:
+        halo = halo.to(x.dtype).contiguous()
+        assert halo.shape == (B, K - 1, Cc)
+    y = torch.empty((B, L, Cc), dtype=x.dtype, device=x.device)
+    check(_capi.lib().tv_causal_conv1d_fwd(
+        _p(xl), _p(w), _p(b), _p(halo), _p(y), B, L, Cc, K, xl.stride(0), xl.stride(1),
+        y.stride(0), y.stride(1), _dt(x), int(activation in ("silu", "swish")), _stream()),
+        "tv_causal_conv1d_fwd")
+    return y.transpose(1, 2)
+
+
+def causal_conv1d_update(x, conv_state, weight, bias=None, activation=None):
+    """x (B, C); conv_state (B, C, K) updated in place; returns (B, C)."""
+    _gpu(x, conv_state, weight, bias)
+    B, Cc = x.shape
+    K = weight.shape[-1]
+    if not conv_state.is_contiguous() or conv_state.dtype != x.dtype:
+        raise TimeViperHipError("causal_conv1d_update: conv_state must be contiguous, x.dtype")
+    xc = x.contiguous()
+    w = weight.reshape(Cc, K).to(x.dtype).contiguous()
+    b = None if bias is None else bias.to(x.dtype).contiguous()
+    y = torch.empty_like(xc)
+    check(_capi.lib().tv_causal_conv1d_update(
+        _p(xc), _p(conv_state), _p(w), _p(b), _p(y), B, Cc, K, _dt(x),
+        int(activation in ("silu", "swish")), _stream()), "tv_causal_conv1d_update")
+    return y
+
+
+# ---------------------------------------------------------------------- norms
+def rms_norm(x, weight, eps, residual=None, return_sum=False):
+    """NemotronHRMSNorm (modeling_nano.py:897-903); with `residual`, normalises
+    s = x + residual (rounded to x.dtype like the reference's bf16 add, :966) and
+    can return s too."""
+    _gpu(x, weight, residual)
+    x2 = _rows2d(x)
+    r2 = None if residual is None else _rows2d(residual)
+    y = torch.empty(x2.shape, dtype=x.dtype, device=x.device)
+    s = torch.empty_like(y) if (return_sum and residual is not None) else None
+    w = weight if weight.dtype in (torch.float32, x.dtype) else weight.to(torch.float32)
+    w = w.contiguous()
+    check(_capi.lib().tv_rmsnorm_fwd(
+        _p(x2), _p(r2), _p(w), _p(s), _p(y), x2.shape[0], x2.shape[1], x2.stride(0),
+        0 if r2 is None else r2.stride(0), 0 if s is None else s.stride(0), y.stride(0),
+        float(eps), _dt(x), _dt(w), _stream()), "tv_rmsnorm_fwd")
+    y = y.view(x.shape)
+    if return_sum:
+        return y, (s.view(x.shape) if s is not None else x)
+    return y
+
+
+def rmsnorm_fn(x, weight, bias=None, z=None, eps=1e-6, group_size=None,
+               norm_before_gate=True, upcast=True):
+    """mamba_ssm.ops.triton.layernorm_gated.rmsnorm_fn as the reference calls it
+    (norm_before_gate=False): y = w * u * rsqrt(mean_group(u^2)+eps), u = x*silu(z)."""
+    if bias is not None:
+        raise TimeViperHipError("rmsnorm_fn: bias unsupported (reference passes None)")
+    if z is not None and norm_before_gate:
+        raise TimeViperHipError("rmsnorm_fn: only norm_before_gate=False is on the path")
+    _gpu(x, weight, z)
+    x2 = _rows2d(x)
+    z2 = None if z is None else _rows2d(z)
+    D = x2.shape[1]
+    gs = D if group_size is None else int(group_size)
+    y = torch.empty(x2.shape, dtype=x.dtype, device=x.device)
+    w = weight if weight.dtype in (torch.float32, x.dtype) else weight.to(torch.float32)
+    w = w.contiguous()
+    check(_capi.lib().tv_rmsnorm_gated_fwd(
+        _p(x2), _p(z2), _p(w), _p(y), x2.shape[0], D, gs, x2.stride(0),
+        0 if z2 is None else z2.stride(0), y.stride(0), float(eps), _dt(x), _dt(w), _stream()),
+        "tv_rmsnorm_gated_fwd")
+    return y.view(x.shape)
+
+
+# ------------------------------------------------------------------- SSD scan
+def _row_view(t: torch.Tensor, inner: int):
+    """(B, L, ...) tensor whose trailing dims are contiguous with `inner`
+    elements per row: return (tensor, stride_b, stride_l) without copying when
+    the rows are dense (slices of a wider projection keep their row stride)."""
+    ok = t.stride(-1) == 1
+    exp = 1
+    for d in range(t.dim() - 1, 1, -1):
+        ok = ok and t.stride(d) == exp
+        exp *= t.shape[d]
+    if not ok:
+        t = t.contiguous()
+    return t, t.stride(0), t.stride(1)
+
+
+def mamba_chunk_scan_combined(x, dt, A, B, C, chunk_size=None, D=None, z=None, dt_bias=None,
+                              initial_states=None, seq_idx=None, cu_seqlens=None,
+                              dt_softplus=False, dt_limit=(0.0, float("inf")),
+                              return_final_states=False, return_varlen_states=False,
+                              group_map="block", return_total_decay=False):
+    """x (B,L,H,P), dt (B,L,H), A (H), B/C (B,L,G,N), D (H), dt_bias (H),
+    initial_states (B,H,P,N).  Returns y (B,L,H,P) [, final_states (B,H,P,N) fp32]
+    [, total_decay (B,H) fp32].  `chunk_size` is accepted for signature parity
+    and ignored (the result is chunk-invariant).  `group_map`: "block"
+    (h // (H/G), GPU reference) or "tile" (h % G, reference CPU quirk)."""
+    if z is not None or seq_idx is not None or cu_seqlens is not None or return_varlen_states:
+        raise TimeViperHipError("mamba_chunk_scan_combined: z/seq_idx/cu_seqlens unsupported")
+    if D is not None and D.dim() != 1:
+        raise TimeViperHipError("mamba_chunk_scan_combined: D must be (nheads,)")
+    _gpu(x, dt, A, B, C, D, dt_bias, initial_states)
+    Bsz, L, H, P = x.shape
+    G, N = B.shape[2], B.shape[3]
+    if dt.dtype != x.dtype:
+        dt = dt.to(x.dtype)
+    if B.dtype != x.dtype:
+        B = B.to(x.dtype)
+    if C.dtype != x.dtype:
+        C = C.to(x.dtype)
+    x, xsb, xsl = _row_view(x, H * P)
+    dt, dsb, dsl = _row_view(dt, H)
+    B, bsb, bsl = _row_view(B, G * N)
+    C, csb, csl = _row_view(C, G * N)
+    f32 = lambda t: None if t is None else t.to(torch.float32).contiguous()
+    A, D, dt_bias, initial_states = f32(A), f32(D), f32(dt_bias), f32(initial_states)
+    y = torch.empty((Bsz, L, H, P), dtype=x.dtype, device=x.device)
+    final = torch.empty((Bsz, H, P, N), dtype=torch.float32, device=x.device) \
+        if return_final_states else None
+    decay = torch.empty((Bsz, H), dtype=torch.float32, device=x.device) \
+        if return_total_decay else None
+    lib = _capi.lib()
+    ws_bytes = lib.tv_ssd_scan_workspace_bytes(Bsz, L, H, P, G, N, _dt(x))
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
+    check(lib.tv_ssd_scan_fwd(
+        _p(x), _p(dt), _p(A), _p(B), _p(C), _p(D), _p(dt_bias), _p(initial_states), _p(y),
+        _p(final), _p(decay), Bsz, L, H, P, G, N, xsb, xsl, dsb, dsl, bsb, bsl, csb, csl,
+        y.stride(0), y.stride(1), _dt(x), int(bool(dt_softplus)), float(dt_limit[0]),
+        float(min(dt_limit[1], 3.0e38)), {"block": 0, "tile": 1}[group_map], _p(ws), ws_bytes,
+        _stream()), "tv_ssd_scan_fwd")
+    out = (y,)
+    if return_final_states:
+        out += (final,)
+    if return_total_decay:
+        out += (decay,)
+    return out[0] if len(out) == 1 else out
+
+
+def selective_state_update(state, x, dt, A, B, C, D=None, z=None, dt_bias=None,
+                           dt_softplus=False):
+    """Single decode step.  state (B,H,P,N) fp32, in place.  The reference passes
+    A/dt/dt_bias/D expanded over (P[,N]) from per-head values (:514-522); the
+    kernel takes the per-head values, so expanded views are reduced here."""
+    if z is not None:
+        raise TimeViperHipError("selective_state_update: z unsupported (reference passes None)")
+    _gpu(state, x, dt, A, B, C, D, dt_bias)
+    Bsz, H, P = x.shape
+    G, N = B.shape[1], B.shape[2]
+    if state.dtype != torch.float32 or not state.is_contiguous():
+        raise TimeViperHipError("selective_state_update: state must be contiguous fp32")
+    head = lambda t, nd: None if t is None else \
+        (t if t.dim() == nd else t[(..., *([0] * (t.dim() - nd)))]).to(torch.float32).contiguous()
+    A1, D1, b1 = head(A, 1), head(D, 1), head(dt_bias, 1)
+    dt1 = (dt if dt.dim() == 2 else dt[..., 0]).to(x.dtype).contiguous()
+    xc, Bc, Cc = x.contiguous(), B.to(x.dtype).contiguous(), C.to(x.dtype).contiguous()
+    y = torch.empty_like(xc)
+    check(_capi.lib().tv_selective_state_update(
+        _p(state), _p(xc), _p(dt1), _p(A1), _p(Bc), _p(Cc), _p(D1), _p(b1), _p(y), Bsz, H, P, G,
+        N, _dt(x), int(bool(dt_softplus)), _stream()), "tv_selective_state_update")
+    return y
+
+
+def ssd_scan_set_impl(impl: int) -> None:
+    """0 auto, 1 generic fp32-recurrence kernel, 2 MFMA chunk-march kernel."""
+    _capi.lib().tv_ssd_scan_set_impl(int(impl))
+
+
+# ------------------------------------------------------------------ attention
+def flash_attn_func(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False,
+                    return_lse=False):
+    """q (B,Lq,Hq,D), k/v (B,Lk,Hkv,D) -> (B,Lq,Hq,D).  GQA without repeat_kv;
+    causal mask bottom-right aligned (flash-attn >= 2.1 semantics)."""
+    if dropout_p:
+        raise TimeViperHipError("flash_attn_func: dropout is not on the inference path")
+    _gpu(q, k, v)
+    B, Lq, Hq, D = q.shape
+    Lk, Hkv = k.shape[1], k.shape[2]
+    fix = lambda t: t if t.stride(-1) == 1 else t.contiguous()
+    q, k, v = fix(q), fix(k), fix(v)
+    if D % 8:
+        raise TimeViperHipError(f"flash_attn_func: head_dim {D} must be a multiple of 8")
+    for t in (q, k, v):
+        if any(s % 8 for s in t.stride()[:3]) or t.data_ptr() % 16:
+            raise TimeViperHipError("flash_attn_func: strides must be multiples of 8 elements")
+    scale = 1.0 / math.sqrt(D) if softmax_scale is None else float(softmax_scale)
+    o = torch.empty((B, Lq, Hq, D), dtype=q.dtype, device=q.device)
+    lse = torch.empty((B, Hq, Lq), dtype=torch.float32, device=q.device) if return_lse else None
+    check(_capi.lib().tv_flash_attn_fwd(
+        _p(q), _p(k), _p(v), _p(o), _p(lse), B, Lq, Lk, Hq, Hkv, D,
+        q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
+        v.stride(0), v.stride(1), v.stride(2), o.stride(0), o.stride(1), o.stride(2),
+        scale, int(bool(causal)), _dt(q), _stream()), "tv_flash_attn_fwd")
+    return (o, lse) if return_lse else o
+
+
+def _flash_attention_forward(query_states, key_states, value_states, attention_mask=None,
+                             query_length=None, is_causal=True, dropout=0.0, position_ids=None,
+                             softmax_scale=None, sliding_window=None, use_top_left_mask=False,
+                             **kwargs):
+    """transformers' helper as NemotronHFlashAttention2 calls it (:1198-1209)."""
+    if attention_mask is not None or sliding_window is not None:
+        raise TimeViperHipError("_flash_attention_forward: padding mask / sliding window unsupported")
+    causal = is_causal and not (use_top_left_mask and query_states.shape[1] == 1)
+    return flash_attn_func(query_states, key_states, value_states, dropout,
+                           softmax_scale=softmax_scale, causal=causal)
+
+
+def scaled_dot_product_attention(query, key, value, attn_mask=None, dropout_p=0.0,
+                                 is_causal=False, scale=None):
+    """F.scaled_dot_product_attention layout: (B, H, L, D) in and out."""
+    if attn_mask is not None:
+        raise TimeViperHipError("scaled_dot_product_attention: attn_mask unsupported")
+    o = flash_attn_func(query.transpose(1, 2), key.transpose(1, 2), value.transpose(1, 2),
+                        dropout_p, softmax_scale=scale, causal=is_causal)
+    return o.transpose(1, 2)
+
+
+def flash_attn_varlen_qkvpacked_func(qkv, cu_seqlens, max_seqlen, dropout_p=0.0,
+                                     softmax_scale=None, causal=False, **kwargs):
+    """qkv (nnz, 3, H, D) with equal-length sequences (what the InternVideo2 ViT
+    produces: every clip has the same token count, flash_attention_class.py:59)."""
+    nnz, three, H, D = qkv.shape
+    assert three == 3
+    nseq = cu_seqlens.numel() - 1
+    if nnz != nseq * max_seqlen:
+        raise TimeViperHipError("flash_attn_varlen_qkvpacked_func: ragged batches unsupported")
+    x = qkv.view(nseq, max_seqlen, 3, H, D)
+    o = flash_attn_func(x[:, :, 0], x[:, :, 1], x[:, :, 2], dropout_p, softmax_scale, causal)
+    return o.reshape(nnz, H, D)
+
+
+# --------------------------------------------------------------- token ops
+def gather_rows(src: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
+    """dst[r] = src[index[r]] for a (rows, D) tensor; index int64 on the GPU."""
+    _gpu(src, index)
+    s2 = _rows2d(src)
+    idx = index.to(torch.int64).contiguous()
+    out = torch.empty((idx.numel(), s2.shape[1]), dtype=src.dtype, device=src.device)
+    check(_capi.lib().tv_gather_rows(_p(s2), _p(idx), _p(out), idx.numel(), s2.shape[1],
+                                     s2.stride(0), out.stride(0), _dt(src), _stream()),
+          "tv_gather_rows")
+    return out
+
+
+def uniform_keep_indices(n_tokens: int, keep: int, offset: int = 0, device="cuda"):
+    """torch.linspace(0, n-1, keep, dtype=long) with CPU semantics, + offset
+    (modeling_nano.py:1946-1957), produced on the GPU, bit-exact."""
+    out = torch.empty((keep,), dtype=torch.int64, device=device)
+    check(_capi.lib().tv_uniform_keep_indices(_p(out), int(n_tokens), int(keep), int(offset),
+                                              _stream()), "tv_uniform_keep_indices")
+    return out
+
+
+def dropped_indices(keep_sorted: torch.Tensor, start: int, n: int) -> torch.Tensor:
+    """[start, start+n) minus keep_sorted, ascending (modeling_nano.py:1966-1970)."""
+    _gpu(keep_sorted)
+    ks = keep_sorted.to(torch.int64).contiguous()
+    out = torch.empty((n - ks.numel(),), dtype=torch.int64, device=ks.device)
+    check(_capi.lib().tv_dropped_indices(_p(ks), ks.numel(), int(start), int(n), _p(out),
+                                         _stream()), "tv_dropped_indices")
+    return out
+
+
+def attn_rank_scores(q_row: torch.Tensor, k: torch.Tensor, n_keys: int, vis_start: int,
+                     n_vis: int, scale: Optional[float] = None) -> torch.Tensor:
+    """Importance of each vision token for pdrop "attn" (modeling_nano.py:1914-1939):
+    q_row (Hq, D) = last prompt token's queries, k (L, Hkv, D); softmax over keys
+    [0, n_keys) per head in fp32, mean over heads, slice [vis_start, vis_start+n_vis)."""
+    _gpu(q_row, k)
+    Hq, D = q_row.shape
+    L, Hkv, _ = k.shape
+    q_row = q_row.contiguous()
+    if k.stride(-1) != 1:
+        k = k.contiguous()
+    scale = 1.0 / math.sqrt(D) if scale is None else float(scale)
+    lib = _capi.lib()
+    ws_bytes = lib.tv_attn_rank_workspace_bytes(int(n_keys), Hq)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=k.device)
+    scores = torch.empty((n_vis,), dtype=torch.float32, device=k.device)
+    check(lib.tv_attn_rank_scores(_p(q_row), _p(k), _p(scores), int(n_keys), Hq, Hkv, D,
+                                  k.stride(0), k.stride(1), int(vis_start), int(n_vis), scale,
+                                  _dt(k), _p(ws), ws_bytes, _stream()), "tv_attn_rank_scores")
+    return scores
+
+
+# ---------------------------------------------------------------- patch embed
+def patch_embed(pixels, weight, bias=None, pos=None, patch: Optional[int] = None):
+    """pixels (F, C, H, W) -> (F, gh*gw, Dout); weight is the Conv2d weight
+    (Dout, C, p, p) (or Conv3d (Dout, C, 1, p, p)); pos (gh*gw, Dout) optional."""
+    _gpu(pixels, weight, bias, pos)
+    F_, Cin, H, W = pixels.shape
+    Dout = weight.shape[0]
+    p = int(weight.shape[-1]) if patch is None else int(patch)
+    pixels = pixels.contiguous()
+    w = weight.reshape(Dout, -1).to(pixels.dtype).contiguous()
+    assert w.shape[1] == Cin * p * p
+    b = None if bias is None else bias.to(pixels.dtype).contiguous()
+    ps = None if pos is None else pos.reshape(-1, Dout).to(pixels.dtype).contiguous()
+    out = torch.empty((F_, (H // p) * (W // p), Dout), dtype=pixels.dtype, device=pixels.device)
+    check(_capi.lib().tv_patch_embed_fwd(_p(pixels), _p(w), _p(b), _p(ps), _p(out), F_, Cin, H,
+                                         W, p, Dout, _dt(pixels), _stream()),
+          "tv_patch_embed_fwd")
+    return out
+
+
+def patch_embed_video(pixels, weight, bias=None, pos=None):
+    """Conv3d k=s=(1,p,p) on (B, C, T, H, W) -> (B, T*gh*gw, Dout), token order
+    (t, py, px) as vit_scale_clean.py:455-460."""
+    _gpu(pixels, weight, bias, pos)
+    B, Cin, T, H, W = pixels.shape
+    Dout, p = weight.shape[0], int(weight.shape[-1])
+    pixels = pixels.contiguous()
+    w = weight.reshape(Dout, -1).to(pixels.dtype).contiguous()
+    b = None if bias is None else bias.to(pixels.dtype).contiguous()
+    ps = None if pos is None else pos.reshape(-1, Dout).to(pixels.dtype).contiguous()
+    npatch = (H // p) * (W // p)
+    out = torch.empty((B, T * npatch, Dout), dtype=pixels.dtype, device=pixels.device)
+    check(_capi.lib().tv_patch_embed_strided_fwd(
+        _p(pixels), _p(w), _p(b), _p(ps), _p(out), B * T, Cin, H, W, p, Dout, T,
+        Cin * T * H * W, H * W, T * H * W, _dt(pixels), _stream()), "tv_patch_embed_strided_fwd")
+    return out
