@@ -1,0 +1,399 @@
+"""Parity of every HIP operator against the CPU oracle (same seeded inputs) and the
+reference-generated golden fixtures.  Calls go through the C ABI (ctypes)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_state_dict, load_golden
+from oracle import ops as R
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def close(a, b, rtol, atol, what=""):
+    a, b = a.detach().double().cpu(), torch.as_tensor(b).double().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    bad = (err > tol)
+    assert not bad.any(), f"{what}: {bad.sum().item()} / {bad.numel()} out of tolerance, max abs err {err.max().item():.3e}"
+
+
+TOL = {torch.float32: (1e-4, 1e-5), torch.bfloat16: (2e-2, 2e-2), torch.float16: (4e-3, 4e-3)}
+
+
+@pytest.fixture(scope="module")
+def K():
+    from timeviper_amd import kernels
+    return kernels
+
+
+# ------------------------------------------------------------------ conv1d
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,L,C,Kw", [(2, 45, 96, 4), (1, 200, 256, 4), (1, 3, 64, 4),
+                                      (1, 1, 64, 2), (2, 130, 2048 + 64, 3)])
+def test_conv1d(K, dtype, B, L, C, Kw):
+    g = torch.Generator().manual_seed(L * 7 + C)
+    x = torch.randn(B, L, C, generator=g)
+    w = torch.randn(C, Kw, generator=g) * 0.5
+    b = torch.randn(C, generator=g) * 0.1
+    xd, wd, bd = (t.to(dtype) for t in (x, w, b))
+    ref = R.causal_conv1d_ref(xd.float(), wd.float(), bd.float())
+    y = K.causal_conv1d_fn(xd.to(DEV).transpose(1, 2), wd.to(DEV), bd.to(DEV), activation="silu")
+    assert y.shape == (B, C, L)
+    close(y.transpose(1, 2), ref, *TOL[dtype], "conv1d")
+    # no bias / no activation
+    y2 = K.causal_conv1d_fn(xd.to(DEV).transpose(1, 2), wd.to(DEV), None, activation=None)
+    close(y2.transpose(1, 2), R.causal_conv1d_ref(xd.float(), wd.float(), None, None), *TOL[dtype])
+
+
+def test_conv1d_strided_slice_and_halo(K):
+    """x is a column slice of a wider projection (row stride > C); halo continues a shard."""
+    g = torch.Generator().manual_seed(1)
+    wide = torch.randn(1, 70, 64 + 128 + 8, generator=g).to(torch.bfloat16)
+    w = (torch.randn(128, 4, generator=g) * 0.5).to(torch.bfloat16)
+    b = (torch.randn(128, generator=g) * 0.1).to(torch.bfloat16)
+    xs = wide[:, :, 64:192]
+    ref = R.causal_conv1d_ref(xs.float(), w.float(), b.float())
+    wd = wide.to(DEV)
+    y = K.causal_conv1d_fn(wd[:, :, 64:192].transpose(1, 2), w.to(DEV), b.to(DEV), activation="silu")
+    close(y.transpose(1, 2), ref, *TOL[torch.bfloat16])
+    y2 = K.causal_conv1d_fn(wd[:, 30:, 64:192].transpose(1, 2), w.to(DEV), b.to(DEV),
+                            activation="silu", halo=wd[:, 27:30, 64:192])
+    close(y2.transpose(1, 2), ref[:, 30:], *TOL[torch.bfloat16])
+
+
+def test_conv1d_golden(K):
+    g = load_golden("mixer_g1")
+    sd = golden_state_dict(g)
+    x = torch.from_numpy(g["xBC_pre"]).to(DEV)
+    y = K.causal_conv1d_fn(x.transpose(1, 2), sd["conv1d.weight"].squeeze(1).to(DEV),
+                           sd["conv1d.bias"].to(DEV), activation="silu")
+    close(y.transpose(1, 2), g["xBC_conv"], 1e-4, 1e-5)
+
+
+def test_conv1d_update(K):
+    g = torch.Generator().manual_seed(3)
+    st = torch.randn(2, 96, 4, generator=g).to(torch.bfloat16)
+    x = torch.randn(2, 96, generator=g).to(torch.bfloat16)
+    w = (torch.randn(96, 4, generator=g) * 0.5).to(torch.bfloat16)
+    b = (torch.randn(96, generator=g) * 0.1).to(torch.bfloat16)
+    yr, sr = R.causal_conv1d_update_ref(x.float(), st.float(), w.float(), b.float())
+    sd = st.to(DEV).clone()
+    y = K.causal_conv1d_update(x.to(DEV), sd, w.to(DEV), b.to(DEV), "silu")
+    close(y, yr, *TOL[torch.bfloat16])
+    close(sd, sr, 0, 0)
+
+
+# ------------------------------------------------------------------- norms
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,D", [(5, 64), (33, 4480), (2, 1152), (1, 8192)])
+def test_rmsnorm(K, dtype, rows, D):
+    if dtype == torch.float32 and D > 4096:
+        pytest.skip("fp32 rows are capped at 4096 columns")
+    g = torch.Generator().manual_seed(D)
+    x = (torch.randn(rows, D, generator=g) * 2).to(dtype)
+    w = (1 + 0.1 * torch.randn(D, generator=g)).to(dtype)
+    y = K.rms_norm(x.to(DEV), w.to(DEV), 1e-5)
+    close(y, R.rmsnorm_ref(x.float(), w.float(), 1e-5), *TOL[dtype])
+    # fused residual add: sum rounded to dtype first, like the reference's bf16 add
+    d = (torch.randn(rows, D, generator=g)).to(dtype)
+    y2, s2 = K.rms_norm(x.to(DEV), w.to(DEV), 1e-5, residual=d.to(DEV), return_sum=True)
+    s_ref = (x + d)
+    assert torch.equal(s2.cpu(), s_ref), "residual sum must be bit-exact"
+    close(y2, R.rmsnorm_ref(s_ref.float(), w.float(), 1e-5), *TOL[dtype])
+
+
+def test_rmsnorm_golden(K):
+    g = load_golden("rmsnorm")
+    y = K.rms_norm(torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(g["w"]).to(DEV), float(g["eps"]))
+    close(y, g["y"], 1e-5, 1e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,D,gs", [(7, 64, 64), (19, 10240, 1280), (3, 256, 32), (2, 2048, 2048)])
+def test_rmsnorm_gated(K, dtype, rows, D, gs):
+    if dtype == torch.float32 and gs > 1024:
+        pytest.skip("fp32 groups are capped at 1024 columns")
+    g = torch.Generator().manual_seed(D + gs)
+    x = torch.randn(rows, D, generator=g).to(dtype)
+    z = torch.randn(rows, D, generator=g).to(dtype)
+    w = (1 + 0.1 * torch.randn(D, generator=g)).to(dtype)
+    y = K.rmsnorm_fn(x.to(DEV), w.to(DEV), None, z.to(DEV), 1e-5, gs, norm_before_gate=False)
+    close(y, R.rmsnorm_gated_ref(x.float(), w.float(), z.float(), 1e-5, gs), *TOL[dtype])
+    y2 = K.rmsnorm_fn(x.to(DEV), w.to(DEV), None, None, 1e-5, gs, norm_before_gate=False)
+    close(y2, R.rmsnorm_gated_ref(x.float(), w.float(), None, 1e-5, gs), *TOL[dtype])
+
+
+# --------------------------------------------------------------------- scan
+def scan_inputs(B, L, H, P, G, N, seed, dtype):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, L, H, P, generator=g).to(dtype)
+    dt = (torch.randn(B, L, H, generator=g) * 0.5).to(dtype)
+    A = -(torch.rand(H, generator=g) * 15 + 1)
+    Bm = (torch.randn(B, L, G, N, generator=g) * 0.5).to(dtype)
+    Cm = (torch.randn(B, L, G, N, generator=g) * 0.5).to(dtype)
+    D = torch.rand(H, generator=g) + 0.5
+    dtv = torch.exp(torch.rand(H, generator=g) * (math.log(0.1) - math.log(1e-3)) + math.log(1e-3))
+    dt_bias = dtv + torch.log(-torch.expm1(-dtv))
+    return x, dt, A, Bm, Cm, D, dt_bias
+
+
+def run_scan(K, x, dt, A, Bm, Cm, D, dt_bias, **kw):
+    d = lambda t: None if t is None else t.to(DEV)
+    return K.mamba_chunk_scan_combined(d(x), d(dt), d(A), d(Bm), d(Cm), chunk_size=64, D=d(D),
+                                       dt_bias=d(dt_bias), dt_softplus=True,
+                                       return_final_states=True, return_total_decay=True, **kw)
+
+
+@pytest.mark.parametrize("impl", [1, 0])
+@pytest.mark.parametrize("dtype,B,L,H,P,G,N", [
+    (torch.float32, 1, 1024, 32, 64, 1, 16),      # BASELINE config 1
+    (torch.float32, 2, 77, 8, 8, 2, 16),
+    (torch.float32, 1, 5, 4, 24, 4, 40),
+    (torch.bfloat16, 1, 300, 16, 80, 2, 128),     # Nano head shape
+    (torch.bfloat16, 2, 129, 8, 64, 8, 128),
+    (torch.bfloat16, 1, 1, 8, 80, 1, 128),
+])
+def test_ssd_scan(K, impl, dtype, B, L, H, P, G, N):
+    K.ssd_scan_set_impl(impl)
+    try:
+        ins = scan_inputs(B, L, H, P, G, N, L + H, dtype)
+        f = [t.float() for t in ins]
+        y_ref, fin_ref, dec_ref = R.ssd_recurrence_ref(*f[:5], D=f[5], dt_bias=f[6])
+        y, fin, dec = run_scan(K, *ins)
+        rt, at = TOL[dtype]
+        close(y, y_ref, rt, at * 2, "y")
+        close(fin, fin_ref, rt, at, "final state")
+        close(dec, dec_ref, 1e-4, 1e-4, "total decay")
+    finally:
+        K.ssd_scan_set_impl(0)
+
+
+@pytest.mark.parametrize("dtype,H,P,G,N", [(torch.float32, 8, 16, 2, 16), (torch.bfloat16, 16, 80, 8, 128)])
+def test_ssd_scan_initial_state_and_sharding(K, dtype, H, P, G, N):
+    """shard chaining through initial_states == single pass."""
+    L, s = 333, 140
+    ins = scan_inputs(1, L, H, P, G, N, 11, dtype)
+    x, dt, A, Bm, Cm, D, dt_bias = ins
+    y, fin, dec = run_scan(K, *ins)
+    y0, f0, d0 = run_scan(K, x[:, :s], dt[:, :s], A, Bm[:, :s], Cm[:, :s], D, dt_bias)
+    y1, f1, d1 = run_scan(K, x[:, s:], dt[:, s:], A, Bm[:, s:], Cm[:, s:], D, dt_bias,
+                          initial_states=f0)
+    rt, at = TOL[dtype]
+    close(torch.cat([y0, y1], 1), y.cpu(), rt, at * 2)
+    close(f1, fin.cpu(), rt, at)
+    close(d0 + d1, dec.cpu(), 1e-4, 1e-4)
+    f = [t.float() for t in ins]
+    _, fin_ref, _ = R.ssd_recurrence_ref(*f[:5], D=f[5], dt_bias=f[6])
+    close(f1, fin_ref, rt, at)
+
+
+def test_ssd_scan_golden_and_group_maps(K):
+    for tag, gmap in [("g1", "block"), ("g2_tile", "tile"), ("g4_tile", "tile")]:
+        g = load_golden(f"mixer_{tag}")
+        sd = golden_state_dict(g)
+        A = -torch.exp(sd["A_log"])
+        T = lambda k: torch.from_numpy(g[k])
+        y, fin = K.mamba_chunk_scan_combined(
+            T("scan_x").to(DEV), T("scan_dt").to(DEV), A.to(DEV), T("scan_B").to(DEV),
+            T("scan_C").to(DEV), chunk_size=16, D=sd["D"].to(DEV), dt_bias=sd["dt_bias"].to(DEV),
+            dt_softplus=True, return_final_states=True, group_map=gmap)
+        close(y, g["scan_y"], 1e-4, 2e-5, tag)
+        close(fin, g["scan_final"], 1e-4, 2e-5, tag)
+
+
+def test_ssd_scan_strided_views(K):
+    """x/B/C are column slices of the conv output, dt of the in_proj output."""
+    H, P, G, N, L = 16, 80, 8, 128, 150
+    g = torch.Generator().manual_seed(5)
+    conv = (torch.randn(1, L, H * P + 2 * G * N, generator=g) * 0.5).to(torch.bfloat16)
+    proj = (torch.randn(1, L, 40 + H, generator=g) * 0.5).to(torch.bfloat16)
+    _, _, A, _, _, D, dt_bias = scan_inputs(1, L, H, P, G, N, 5, torch.bfloat16)
+    x, Bm, Cm = conv.split([H * P, G * N, G * N], dim=-1)
+    dt = proj[..., 40:]
+    y_ref, fin_ref, _ = R.ssd_recurrence_ref(x.float().view(1, L, H, P), dt.float(), A,
+                                             Bm.float().view(1, L, G, N), Cm.float().view(1, L, G, N),
+                                             D=D, dt_bias=dt_bias)
+    cd, pd = conv.to(DEV), proj.to(DEV)
+    xd, Bd, Cd = cd.split([H * P, G * N, G * N], dim=-1)
+    y, fin = K.mamba_chunk_scan_combined(
+        xd.view(1, L, H, P), pd[..., 40:], A.to(DEV), Bd.view(1, L, G, N), Cd.view(1, L, G, N),
+        chunk_size=128, D=D.to(DEV), dt_bias=dt_bias.to(DEV), dt_softplus=True,
+        return_final_states=True)
+    close(y, y_ref, 2e-2, 4e-2)
+    close(fin, fin_ref, 2e-2, 2e-2)
+
+
+def test_selective_state_update(K):
+    B, H, P, G, N = 2, 8, 16, 2, 32
+    ins = scan_inputs(B, 1, H, P, G, N, 9, torch.bfloat16)
+    x, dt, A, Bm, Cm, D, dt_bias = ins
+    g = torch.Generator().manual_seed(2)
+    st = torch.randn(B, H, P, N, generator=g)
+    y_ref, fin_ref, _ = R.ssd_recurrence_ref(x.float(), dt.float(), A, Bm.float(), Cm.float(), D=D,
+                                             dt_bias=dt_bias, initial_states=st)
+    sd = st.to(DEV).clone()
+    y = K.selective_state_update(sd, x[:, 0].to(DEV), dt[:, 0].to(DEV), A.to(DEV), Bm[:, 0].to(DEV),
+                                 Cm[:, 0].to(DEV), D.to(DEV), dt_bias=dt_bias.to(DEV), dt_softplus=True)
+    close(y, y_ref[:, 0], 2e-2, 2e-2)
+    close(sd, fin_ref, 1e-4, 1e-5)
+
+
+# ---------------------------------------------------------------- attention
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,Lq,Lk,Hq,Hkv,D,causal", [
+    (1, 200, 200, 8, 2, 128, True),
+    (2, 129, 129, 4, 4, 64, True),
+    (1, 64, 64, 5, 1, 128, True),
+    (1, 100, 333, 8, 2, 128, False),     # TransV cross attention: few queries, many keys
+    (1, 9, 21, 4, 2, 16 * 0 + 64, False),
+    (3, 729, 729, 2, 2, 72, False),      # SigLIP ViT heads
+    (2, 257, 257, 2, 2, 88, False),      # InternVideo2 ViT heads
+    (1, 50, 180, 4, 2, 128, True),       # bottom-right aligned causal (Lk > Lq)
+    (1, 1, 77, 8, 2, 128, True),         # decode-like single query
+    (1, 300, 300, 4, 2, 80, True),
+    (1, 130, 130, 4, 2, 96, False),
+])
+def test_flash_attention(K, dtype, B, Lq, Lk, Hq, Hkv, D, causal):
+    g = torch.Generator().manual_seed(Lq * 3 + Lk + D)
+    q = torch.randn(B, Lq, Hq, D, generator=g).to(dtype)
+    k = torch.randn(B, Lk, Hkv, D, generator=g).to(dtype)
+    v = torch.randn(B, Lk, Hkv, D, generator=g).to(dtype)
+    o_ref, lse_ref = R.attention_ref(q.float(), k.float(), v.float(), causal)
+    o, lse = K.flash_attn_func(q.to(DEV), k.to(DEV), v.to(DEV), causal=causal, return_lse=True)
+    rt, at = (2e-2, 1e-2) if dtype == torch.bfloat16 else (4e-3, 2e-3)
+    close(o, o_ref, rt, at, "o")
+    close(lse, lse_ref, 1e-3, 2e-3, "lse")
+
+
+def test_flash_attention_spiked_max(K):
+    """force large running-max jumps at chosen tiles (guide rule 26)."""
+    g = torch.Generator().manual_seed(0)
+    B, L, H, D = 1, 400, 2, 128
+    q = torch.randn(B, L, H, D, generator=g)
+    k = torch.randn(B, L, H, D, generator=g)
+    v = torch.randn(B, L, H, D, generator=g)
+    for pos in (70, 200, 390):
+        k[0, pos, :, :] = q[0, 399, :, :] * 3.0
+    q, k, v = (t.to(torch.bfloat16) for t in (q, k, v))
+    o_ref, _ = R.attention_ref(q.float(), k.float(), v.float(), True)
+    o = K.flash_attn_func(q.to(DEV), k.to(DEV), v.to(DEV), causal=True)
+    close(o, o_ref, 2e-2, 1e-2)
+
+
+def test_attention_golden_module_level(K):
+    """q/k/v projections in torch, attention in HIP: reference NemotronHSdpaAttention output."""
+    g = load_golden("attention")
+    sd = {k_: v_.to(DEV).to(torch.bfloat16) for k_, v_ in golden_state_dict(g).items()}
+    h = torch.from_numpy(g["hidden"]).to(DEV).to(torch.bfloat16)
+    Hq, Hkv, D = (int(v) for v in g["meta"])
+    B, L, _ = h.shape
+    q = (h @ sd["q_proj.weight"].t()).view(B, L, Hq, D)
+    k = (h @ sd["k_proj.weight"].t()).view(B, L, Hkv, D)
+    v = (h @ sd["v_proj.weight"].t()).view(B, L, Hkv, D)
+    o = K.flash_attn_func(q, k, v, causal=True).reshape(B, L, Hq * D) @ sd["o_proj.weight"].t()
+    close(o, g["out"], 5e-2, 3e-2)
+
+
+def test_sdpa_and_varlen_wrappers(K):
+    g = torch.Generator().manual_seed(4)
+    q = torch.randn(2, 4, 33, 64, generator=g).to(torch.bfloat16)
+    k = torch.randn(2, 4, 33, 64, generator=g).to(torch.bfloat16)
+    v = torch.randn(2, 4, 33, 64, generator=g).to(torch.bfloat16)
+    o_ref, _ = R.attention_ref(q.float().transpose(1, 2), k.float().transpose(1, 2), v.float().transpose(1, 2), False)
+    o = K.scaled_dot_product_attention(q.to(DEV), k.to(DEV), v.to(DEV))
+    close(o.transpose(1, 2), o_ref, 2e-2, 1e-2)
+    qkv = torch.stack([q, k, v], dim=0).permute(1, 3, 0, 2, 4).reshape(2 * 33, 3, 4, 64).contiguous()
+    cu = torch.tensor([0, 33, 66], dtype=torch.int32)
+    o2 = K.flash_attn_varlen_qkvpacked_func(qkv.to(DEV), cu.to(DEV), 33)
+    close(o2.view(2, 33, 4, 64), o_ref, 2e-2, 1e-2)
+
+
+# --------------------------------------------------------------- token ops
+def test_gather_rows(K):
+    g = torch.Generator().manual_seed(8)
+    src = torch.randn(500, 4480, generator=g).to(torch.bfloat16)
+    idx = torch.randperm(500, generator=g)[:123].sort().values
+    out = K.gather_rows(src.to(DEV), idx.to(DEV))
+    assert torch.equal(out.cpu(), src[idx])
+    src32 = torch.randn(40, 64, generator=g)
+    assert torch.equal(K.gather_rows(src32.to(DEV), idx[:10].to(DEV) % 40).cpu(), src32[idx[:10] % 40])
+    assert K.gather_rows(src.to(DEV), idx[:0].to(DEV)).shape == (0, 4480)
+
+
+def test_uniform_keep_indices_bit_exact(K):
+    g = load_golden("uniform_indices")
+    for n, keep in g["cases"]:
+        n, keep = int(n), int(keep)
+        got = K.uniform_keep_indices(n, keep).cpu()
+        assert torch.equal(got, R.uniform_keep_indices_ref(n, keep)), (n, keep)
+        assert torch.equal(got, torch.linspace(0, n - 1, keep, dtype=torch.long)), (n, keep)
+    # BASELINE full sizes, with the vision offset
+    for n, keep in [(163840, 131072), (160000, 128000), (131072, 98304), (32768, 26214)]:
+        got = K.uniform_keep_indices(n, keep, offset=20).cpu()
+        assert torch.equal(got, torch.linspace(0, n - 1, keep, dtype=torch.long) + 20)
+        assert (got[1:] > got[:-1]).all()          # strictly increasing -> already sorted
+    assert torch.equal(K.uniform_keep_indices(10, 1).cpu(), torch.zeros(1, dtype=torch.long))
+
+
+def test_dropped_indices(K):
+    g = torch.Generator().manual_seed(6)
+    n, start = 1000, 37
+    keep = (torch.randperm(n, generator=g)[:600].sort().values + start)
+    allidx = torch.arange(start, start + n)
+    ref = allidx[~torch.isin(allidx, keep)]
+    got = K.dropped_indices(keep.to(DEV), start, n).cpu()
+    assert torch.equal(got, ref)
+    assert K.dropped_indices(allidx.to(DEV), start, n).numel() == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attn_rank_scores(K, dtype):
+    g = torch.Generator().manual_seed(12)
+    L, Dm, Hq, Hkv, D = 300, 64, 8, 2, 32
+    hidden = torch.randn(L, Dm, generator=g).to(dtype)
+    qw = (torch.randn(Hq * D, Dm, generator=g) / 8).to(dtype)
+    kw = (torch.randn(Hkv * D, Dm, generator=g) / 8).to(dtype)
+    vis_start, n_vis, qrow = 10, 250, 279
+    ref = R.attn_rank_scores_ref(hidden, qw, kw, Hq, Hkv, D, qrow, vis_start, n_vis)
+    hd = hidden.to(DEV)
+    q = (hd[qrow:qrow + 1] @ qw.to(DEV).t()).view(Hq, D)
+    k = (hd @ kw.to(DEV).t()).view(L, Hkv, D)
+    got = K.attn_rank_scores(q, k, qrow + 1, vis_start, n_vis)
+    if dtype == torch.float32:
+        close(got, ref, 1e-4, 1e-7)
+        keep = 100
+        assert torch.equal(R.topk_keep_ref(got.cpu(), keep).sort().values,
+                           R.topk_keep_ref(ref, keep).sort().values)
+    else:
+        close(got, ref.float(), 5e-2, 2e-4)
+
+
+# -------------------------------------------------------------- patch embed
+@pytest.mark.parametrize("F_,C,H,W,p,Dout", [(3, 3, 56, 56, 14, 128), (2, 3, 42, 70, 14, 192),
+                                             (1, 3, 32, 32, 16, 64), (5, 3, 28, 28, 14, 1152)])
+def test_patch_embed(K, F_, C, H, W, p, Dout):
+    g = torch.Generator().manual_seed(H + Dout)
+    pix = torch.randn(F_, C, H, W, generator=g).to(torch.bfloat16)
+    w = (torch.randn(Dout, C, p, p, generator=g) / math.sqrt(C * p * p)).to(torch.bfloat16)
+    b = (torch.randn(Dout, generator=g) * 0.1).to(torch.bfloat16)
+    pos = (torch.randn((H // p) * (W // p), Dout, generator=g) * 0.1).to(torch.bfloat16)
+    ref = R.patch_embed_ref(pix.float(), w.float(), b.float(), pos.float())
+    out = K.patch_embed(pix.to(DEV), w.to(DEV), b.to(DEV), pos.to(DEV))
+    close(out, ref, 2e-2, 2e-2)
+    out2 = K.patch_embed(pix.to(DEV), w.to(DEV))
+    close(out2, R.patch_embed_ref(pix.float(), w.float()), 2e-2, 2e-2)
+
+
+def test_patch_embed_video(K):
+    g = torch.Generator().manual_seed(77)
+    pix = torch.randn(2, 3, 4, 28, 42, generator=g).to(torch.bfloat16)
+    w = (torch.randn(96, 3, 1, 14, 14, generator=g) / 24).to(torch.bfloat16)
+    b = (torch.randn(96, generator=g) * 0.1).to(torch.bfloat16)
+    ref = R.patch_embed_video_ref(pix.float(), w.float(), b.float())
+    out = K.patch_embed_video(pix.to(DEV), w.to(DEV), b.to(DEV))
+    close(out, ref, 2e-2, 2e-2)

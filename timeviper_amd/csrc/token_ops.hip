@@ -173,9 +173,9 @@ int launch_rank(const void* q, const void* k, void* scores, int n_keys, int Hq, 
 extern "C" int tv_gather_rows(const void* src, const int64_t* index, void* dst, int64_t n_rows,
                               int dim, int64_t src_stride, int64_t dst_stride, int dtype,
                               void* stream) {
-  TV_CHECK_ARG(src && index && dst, "gather_rows: null pointer");
   TV_CHECK_ARG(n_rows >= 0 && dim > 0, "gather_rows: bad sizes");
   if (n_rows == 0) return TV_OK;
+  TV_CHECK_ARG(src && index && dst, "gather_rows: null pointer");
   const int vec = dtype == TV_F32 ? 4 : 8;
   if (dim % vec || src_stride % vec || dst_stride % vec || ((uintptr_t)src & 15) ||
       ((uintptr_t)dst & 15))
