@@ -1,0 +1,229 @@
+"""bench.py — TimeViper-9B long-video forward (prefill) on N MI355X, synthetic data.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames T]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of `GenericTimeViperVLM.forward` (ViT over 256-frame clips ->
+ToMe+MLP projector -> fusion -> 56-layer Nemotron-Nano-9B-v2 hybrid stack with TransV
+pdrop -> last-token logits) over T frames that are already resident in HBM.  With N > 1
+the frame/token sequence is sharded over the ranks (timeviper_amd.distributed) and the
+total work is fixed ("scaling": "strong").  Rank 0 prints ONE JSON line.
+
+roofline: the SSD selective-scan kernel — algorithmic bytes (45 312 B per
+token per Mamba layer at Nano dims, bf16) / its launch durations measured live with
+events on the launch stream inside the timed steps.
+cpu_baseline: the CPU oracle (eager PyTorch fp32 restatement of the reference path),
+timed on this box's host cores on a bounded sample and scaled to frames/s.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+PDROP = "uni_14_0.8-attn_21_0.6-attn_30_0.4-attn_39_0.2"   # evaluate.py:170 defaults
+TOK_PER_FRAME = 16                                         # arch_specifier tome_mlp-16
+HBM_PEAK_GBS = 8000.0                                      # MI355X_MICROARCH.md
+
+
+def scan_bytes_per_token(cfg) -> int:
+    H, P, G, N = cfg.mamba_num_heads, cfg.mamba_head_dim, cfg.n_groups, cfg.ssm_state_size
+    return 2 * H * P + 2 * H + 2 * 2 * G * N + 2 * H * P   # x, dt, B+C read; y written (bf16)
+
+
+class ScanTimer:
+    """Wraps kernels.mamba_chunk_scan_combined with start/stop events on the launch stream."""
+
+    def __init__(self, K):
+        self.K, self.orig, self.rec, self.on = K, K.mamba_chunk_scan_combined, [], False
+
+    def __enter__(self):
+        def timed(x, *a, **kw):
+            if not self.on:
+                return self.orig(x, *a, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = self.orig(x, *a, **kw)
+            e1.record()
+            self.rec.append((e0, e1, x.shape[0] * x.shape[1]))
+            return out
+        self.K.mamba_chunk_scan_combined = timed
+        return self
+
+    def __exit__(self, *exc):
+        self.K.mamba_chunk_scan_combined = self.orig
+
+    def summary(self, bytes_per_token):
+        if not self.rec:
+            return None
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.rec)
+        tokens = sum(n for _, _, n in self.rec)
+        gbs = tokens * bytes_per_token / (ms * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": "ssd_scan (tv_ssd_scan_fwd)", "achieved": round(gbs, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                "traffic": None, "launches": len(self.rec),
+                "avg_launch_us": round(ms * 1e3 / len(self.rec), 1),
+                "bytes_per_token": bytes_per_token}
+
+
+def cpu_baseline(cfg, frames_sample=64):
+    """Oracle (port of the reference's eager path) on the host cores, bounded sample:
+    one Mamba / attention / MLP layer at Nano-9B dims over `frames_sample` frames of tokens,
+    one SigLIP block on 2 frames; scaled by the layer counts to a whole forward."""
+    from oracle import model as om
+    from oracle import ops as R
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    ocfg = om.OracleConfig.from_hf(cfg)
+    L = frames_sample * TOK_PER_FRAME + 100
+    g = torch.Generator().manual_seed(0)
+    D, H, P, N, G = cfg.hidden_size, cfg.mamba_num_heads, cfg.mamba_head_dim, cfg.ssm_state_size, cfg.n_groups
+    d_in, conv = H * P, H * P + 2 * G * N
+    rn = lambda *s: torch.randn(*s, generator=g) * 0.02
+    sd = {"m.in_proj.weight": rn(d_in + conv + H, D), "m.conv1d.weight": rn(conv, 1, 4) * 10,
+          "m.conv1d.bias": rn(conv), "m.A_log": torch.log(torch.rand(H, generator=g) * 15 + 1),
+          "m.D": torch.ones(H), "m.dt_bias": torch.full((H,), -3.0), "m.norm.weight": torch.ones(d_in),
+          "m.out_proj.weight": rn(D, d_in),
+          "a.q_proj.weight": rn(cfg.num_attention_heads * cfg.head_dim, D),
+          "a.k_proj.weight": rn(cfg.num_key_value_heads * cfg.head_dim, D),
+          "a.v_proj.weight": rn(cfg.num_key_value_heads * cfg.head_dim, D),
+          "a.o_proj.weight": rn(D, cfg.num_attention_heads * cfg.head_dim),
+          "f.up_proj.weight": rn(cfg.intermediate_size, D), "f.down_proj.weight": rn(D, cfg.intermediate_size)}
+    h = torch.randn(1, L, D, generator=g)
+
+    def clock(fn):
+        fn()
+        t0 = time.perf_counter()
+        fn()
+        return time.perf_counter() - t0
+
+    with torch.no_grad():
+        t_m = clock(lambda: om.mamba_mixer_ref(sd, "m.", ocfg, h))
+        t_a = clock(lambda: om.attention_mixer_ref(sd, "a.", ocfg, h))
+        t_f = clock(lambda: om.mlp_mixer_ref(sd, "f.", h))
+        # one ViT block (so400m dims) on 2 frames
+        Dv, Hv, Mv, Np = 1152, 16, 4304, 729
+        xv = torch.randn(2, Np, Dv, generator=g)
+        wq, wp, w1, w2 = rn(3 * Dv, Dv), rn(Dv, Dv), rn(Mv, Dv), rn(Dv, Mv)
+
+        def vit_block():
+            qkv = (xv @ wq.t()).view(2, Np, 3, Hv, Dv // Hv)
+            o, _ = R.attention_ref(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], False)
+            y = xv + o.reshape(2, Np, Dv) @ wp.t()
+            return y + torch.nn.functional.gelu(y @ w1.t()) @ w2.t()
+        t_v = clock(vit_block)
+    bt = cfg.layers_block_type
+    llm_s = t_m * bt.count("mamba") + t_a * bt.count("attention") + t_f * bt.count("mlp")
+    vit_s = t_v * 26 * (frames_sample / 2)
+    total = llm_s + vit_s
+    return {"value": round(frames_sample / total, 4), "unit": "frames/s", "cores": cores,
+            "kind": "port",
+            "sample": (f"oracle (eager PyTorch fp32) at Nano-9B dims, {frames_sample} frames = {L} tokens: "
+                       f"1 Mamba layer {t_m:.2f}s x27, 1 attention layer {t_a:.2f}s x4, 1 MLP layer "
+                       f"{t_f:.2f}s x25, 1 SigLIP block on 2 frames {t_v:.2f}s x26 x{frames_sample // 2}; "
+                       f"no pdrop; scaled to a whole forward (extrapolated, attention is quadratic so this "
+                       f"over-estimates CPU throughput at long lengths)")}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=int(os.environ.get("TV_BENCH_FRAMES", 10240)))
+    ap.add_argument("--no-pdrop", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from timeviper_amd import kernels as K
+    from timeviper_amd.model import build_synthetic_timeviper
+    from timeviper_amd.model.llm.nano import NemotronHConfig
+
+    cfg = NemotronHConfig.nemotron_nano_9b_v2()
+    pd = None if args.no_pdrop else PDROP
+    vlm = build_synthetic_timeviper(cfg, "siglip-vit-so400m-384px", pdrop_type=pd,
+                                    merge_module="CrossAttention" if pd else "no_merge",
+                                    device=dev, seed=0)
+    T = args.frames
+    g = torch.Generator(device=dev).manual_seed(1)
+    tok = vlm.default_token_id
+    ids = torch.cat([torch.randint(3, 1000, (20,), device=dev, generator=g),
+                     torch.full((T,), tok, device=dev),
+                     torch.randint(3, 1000, (80,), device=dev, generator=g)])[None]
+    if world > 1:
+        from timeviper_amd.distributed import SequenceParallelTimeViper
+        runner = SequenceParallelTimeViper(vlm, rank, world)
+        lo, hi = runner.frame_range(T)
+        pix = torch.randn(hi - lo, 3, 384, 384, device=dev, dtype=torch.bfloat16, generator=g)
+        step = lambda: runner.forward(ids, pix, T)
+    else:
+        pix = torch.randn(T, 3, 384, 384, device=dev, dtype=torch.bfloat16, generator=g)
+        step = lambda: vlm(input_ids=ids, pixel_values_videos=pix).logits
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    with torch.inference_mode(), ScanTimer(K) as st:
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        st.on = True
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        barrier()
+        dt_s = time.perf_counter() - t0
+        st.on = False
+    assert torch.isfinite(out.float()).all(), "non-finite logits"
+    t = torch.tensor([dt_s], device=dev, dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    dt_s = float(t.item())
+
+    if rank == 0:
+        ms = dt_s / args.steps * 1e3
+        L = T * TOK_PER_FRAME + 100
+        line = {
+            "metric": "video frames/sec fwd, TimeViper-9B @10k frames, 1/2/4/8 MI355X",
+            "value": round(T * args.steps / dt_s, 2), "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic",
+            "config": {"workload": f"TimeViper-Nano-9B forward (prefill), {T} frames x 384px, SigLIP-so400m "
+                                   f"ViT (26 blocks) + ToMe 729->16 + 56-layer Nemotron-Nano-9B-v2 hybrid "
+                                   f"(27 Mamba2 / 25 MLP / 4 attention), {L} tokens, batch 1",
+                       "frames": T, "tokens": L, "pdrop": pd, "merge_module": "CrossAttention" if pd else "no_merge",
+                       "parallelism": "single GPU" if world == 1 else f"sequence-sharded x{world} (RCCL)",
+                       "weights": "random init, seed 0"},
+            "roofline": st.summary(scan_bytes_per_token(cfg)),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -258,5 +258,25 @@ def main():
         print("G8 fused layout fixture skipped:", repr(e))
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and os.environ.get("GOLDEN_ONLY") is None:
     main()
+
+
+@torch.no_grad()
+def make_tome_golden():
+    """G11: ToMe projector of the reference (timeviper/model/projector/tome.py), fp32."""
+    import_reference()
+    tome = importlib.import_module("timeviper.model.projector.tome")
+    torch.manual_seed(5)
+    proj = tome.ToMe16_mlp_hd64(64, 48, num_compressed_tokens=16).eval()
+    x = torch.randn(3, 729, 64)
+    y = proj(x, compress=True, local_num_frames=1)
+    merged = proj.merge_tokens(x, 16, "raw")
+    x2 = torch.randn(2, 4 * 100, 64)
+    y2 = proj(x2, compress=True, local_num_frames=4)
+    npz("tome", x=x, y=y, merged=merged, x2=x2, y2=y2,
+        **{"w." + k: v for k, v in proj.state_dict().items()})
+
+
+if __name__ == "__main__" and os.environ.get("GOLDEN_ONLY") in (None, "tome"):
+    make_tome_golden()

@@ -137,7 +137,8 @@ def parse_pdrop(pdrop_type: str):
 
 
 def pdrop_stage_ref(sd, bb: str, cfg: OracleConfig, features, stage: int, rank_layer: int,
-                    vision_index: int, num_vision_tokens: int, text_prompt_len: int):
+                    vision_index: int, num_vision_tokens: int, text_prompt_len: int,
+                    forced_kept=None):
     """pdrop_no_pack, eval / batch 1 / no padding (:1779-2095).  features (1,L,D).
     Returns (new_features (1,L',D), kept_indices (sorted, absolute), dropped_indices)."""
     types, layers, ratios = parse_pdrop(cfg.pdrop_type)
@@ -158,6 +159,9 @@ def pdrop_stage_ref(sd, bb: str, cfg: OracleConfig, features, stage: int, rank_l
     else:
         raise NotImplementedError(ctype)
     top = (top + vision_index).sort().values                              # :1957-1958
+    if forced_kept is not None:   # tests: follow the selection made by a lower-precision run
+        assert forced_kept.numel() == top.numel()
+        top = forced_kept.sort().values
     start_index = vision_index + image_tokens                             # :1961
     all_idx = torch.arange(vision_index, start_index)
     dropped = all_idx[~torch.isin(all_idx, top)]                          # :1966-1970
@@ -173,7 +177,7 @@ def pdrop_stage_ref(sd, bb: str, cfg: OracleConfig, features, stage: int, rank_l
 
 # ------------------------------------------------------------------------ L1
 def backbone_ref(sd, cfg: OracleConfig, inputs_embeds, pdrop_args: Optional[dict] = None,
-                 bb: str = "backbone.", collect: Optional[dict] = None):
+                 bb: str = "backbone.", collect: Optional[dict] = None, forced_kept=None):
     """NemotronHModel.forward (:1550-1746): per layer [pdrop before the block
     (:1635-1665)] -> x + mixer(RMSNorm(x)) (:929-967) ; final norm_f (:1715)."""
     h = inputs_embeds
@@ -185,7 +189,8 @@ def backbone_ref(sd, cfg: OracleConfig, inputs_embeds, pdrop_args: Optional[dict
             stage = layers.index(i)
             h, kept, dropped = pdrop_stage_ref(
                 sd, bb, cfg, h, stage, i, int(pdrop_args["first_vision_token_positions"][0]),
-                int(pdrop_args["num_vision_tokens"][0]), int(pdrop_args["text_prompt_lens"][0]))
+                int(pdrop_args["num_vision_tokens"][0]), int(pdrop_args["text_prompt_lens"][0]),
+                None if forced_kept is None else forced_kept[stage])
             if collect is not None:
                 collect.setdefault("kept", []).append(kept)
                 collect.setdefault("dropped", []).append(dropped)
@@ -204,9 +209,9 @@ def backbone_ref(sd, cfg: OracleConfig, inputs_embeds, pdrop_args: Optional[dict
 
 
 def causal_lm_ref(sd, cfg: OracleConfig, inputs_embeds, pdrop_args=None, last_only=False,
-                  collect=None):
+                  collect=None, forced_kept=None):
     """NemotronHForCausalLM.forward (:2378-2457): lm_head(backbone(x)).float()."""
-    h = backbone_ref(sd, cfg, inputs_embeds, pdrop_args, collect=collect)
+    h = backbone_ref(sd, cfg, inputs_embeds, pdrop_args, collect=collect, forced_kept=forced_kept)
     if last_only:
         h = h[:, -1:]
     return F.linear(h, sd["lm_head.weight"]).float()

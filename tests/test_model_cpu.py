@@ -1,0 +1,81 @@
+"""Host logic of the model mirror that needs no GPU: config / state-dict contract,
+fused-embedding layout, ToMe projector (plain torch) against reference golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_state_dict, load_golden
+from timeviper_amd.model.llm.nano import NemotronHConfig, NemotronHForCausalLM
+from timeviper_amd.model.projector.tome import ToMe16_mlp_hd64, merge_schedule
+
+PD = "uni_2_0.75-attn_3_0.5-attn_6_0.25"
+
+
+def toy_config(**kw):
+    base = dict(vocab_size=64, hidden_size=64, intermediate_size=96, num_hidden_layers=8,
+                hybrid_override_pattern="M-M*M-*M", num_attention_heads=4, head_dim=16,
+                num_key_value_heads=2, ssm_state_size=16, mamba_num_heads=8, mamba_n_groups=1,
+                mamba_head_dim=8, mamba_chunk_size=16)
+    base.update(kw)
+    return NemotronHConfig(**base)
+
+
+@pytest.mark.parametrize("tag,kw", [("plain", {}),
+                                    ("pdrop_nomerge", dict(use_pdrop=True, pdrop_type=PD)),
+                                    ("pdrop_transv", dict(use_pdrop=True, pdrop_type=PD,
+                                                          merge_module="CrossAttention"))])
+def test_state_dict_is_reference_compatible(tag, kw):
+    g = load_golden(f"toy_{tag}")
+    model = NemotronHForCausalLM(toy_config(**kw))
+    missing = model.load_state_dict(golden_state_dict(g), strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+
+
+def test_nano_9b_config_matches_survey():
+    c = NemotronHConfig.nemotron_nano_9b_v2()
+    bt = c.layers_block_type
+    assert len(bt) == 56 and bt.count("mamba") == 27 and bt.count("mlp") == 25
+    assert [i for i, t in enumerate(bt) if t == "attention"] == [14, 21, 30, 39]
+    assert (c.hidden_size, c.mamba_num_heads, c.mamba_head_dim, c.ssm_state_size, c.n_groups) == \
+        (4480, 128, 80, 128, 8)
+
+
+def test_embedding_key_rename_hook():
+    g = load_golden("toy_plain")
+    sd = golden_state_dict(g)
+    sd["backbone.embedding.weight"] = sd.pop("backbone.embeddings.weight")
+    NemotronHForCausalLM(toy_config()).load_state_dict(sd, strict=True)
+
+
+def test_tome_schedule():
+    assert merge_schedule(729, 16) == [364, 182, 91, 46, 23, 7]
+    assert merge_schedule(400, 64) == [200, 100, 36]
+
+
+def test_tome_projector_matches_reference():
+    g = load_golden("tome")
+    proj = ToMe16_mlp_hd64(64, 48, num_compressed_tokens=16).eval()
+    proj.load_state_dict(golden_state_dict(g), strict=True)
+    with torch.no_grad():
+        merged = proj.merge_tokens(torch.from_numpy(g["x"]), 16, "raw")
+        y = proj(torch.from_numpy(g["x"]), compress=True, local_num_frames=1)
+        y2 = proj(torch.from_numpy(g["x2"]), compress=True, local_num_frames=4)
+    assert torch.allclose(merged, torch.from_numpy(g["merged"]), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(y, torch.from_numpy(g["y"]), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(y2, torch.from_numpy(g["y2"]), rtol=1e-5, atol=1e-6)
+
+
+def test_fused_embedding_layout_matches_reference():
+    from types import SimpleNamespace
+    from timeviper_amd.model.generic_vlm import GenericTimeViperVLM
+    g = load_golden("fused_embeddings")
+    emb_w = torch.from_numpy(g["emb_w"])
+    embed = lambda ids: torch.nn.functional.embedding(ids, emb_w)
+    fake = SimpleNamespace(default_token_id=int(g["image_token_id"]),
+                           llm_backbone=SimpleNamespace(embed_input_ids=embed),
+                           dtype_of=lambda e: torch.float32)
+    vis = torch.from_numpy(g["vis"])
+    f1, _ = GenericTimeViperVLM.get_fused_data_nopacked(fake, vis, torch.from_numpy(g["ids"]))
+    f2, _ = GenericTimeViperVLM.get_fused_data_nopacked(fake, vis, torch.from_numpy(g["ids2"]))
+    assert torch.equal(f1, torch.from_numpy(g["fused"]))      # contiguous-run fast path
+    assert torch.equal(f2, torch.from_numpy(g["fused2"]))     # interleaved text: general walk

@@ -1,0 +1,86 @@
+"""`GenericLLMBackbone` (reference timeviper/model/llm/llm_factory.py:41-198): thin
+wrapper owning `.llm` (the causal LM), the tokenizer and the `<image>` token.  There is
+no network here, so instead of `from_pretrained` the backbone is built from a config
+(random init, the reference's `_from_config` branch :101) and the tokenizer is either
+handed in or a minimal stand-in that only knows the special-token ids."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .nano import NemotronHConfig, NemotronHForCausalLM
+
+MODEL_REGISTRY = {
+    # llm_registry.py:64-97 — ids the reference accepts for the nano family
+    "nanov2-9b": "nvidia/NVIDIA-Nemotron-Nano-9B-v2",
+    "nanov2-9b-base": "nvidia/NVIDIA-Nemotron-Nano-9B-v2-Base",
+}
+DEFAULT_TOKEN = "<image>"
+
+
+def get_llm_config(llm_backbone_id: str, **over) -> NemotronHConfig:
+    if llm_backbone_id in MODEL_REGISTRY:
+        return NemotronHConfig.nemotron_nano_9b_v2(**over)
+    raise ValueError(f"LLM backbone `{llm_backbone_id}` is not supported!")
+
+
+class SyntheticTokenizer:
+    """Stand-in used for synthetic benchmarks/tests (no tokenizer files offline)."""
+
+    def __init__(self, vocab_size: int):
+        self.vocab_size = vocab_size
+        self.image_token_id = vocab_size - 1
+        self.eos_token_id = 2
+        self.pad_token_id = 0
+
+    def convert_tokens_to_ids(self, tok):
+        return self.image_token_id if tok == DEFAULT_TOKEN else 3
+
+    def __len__(self):
+        return self.vocab_size
+
+
+class GenericLLMBackbone(nn.Module):
+    def __init__(self, llm_backbone_id: str, config: Optional[NemotronHConfig] = None,
+                 tokenizer=None, llm_max_length: Optional[int] = None, inference_mode: bool = True,
+                 attn_implementation: str = "flash_attention_2", merge_module: str = "no_merge",
+                 use_pdrop: bool = False, pdrop_type: Optional[str] = None) -> None:
+        super().__init__()
+        self.identifier = llm_backbone_id
+        self.llm_family = "nano"
+        self.llm_max_length = llm_max_length
+        self.inference_mode = inference_mode
+        if config is None:
+            config = get_llm_config(llm_backbone_id, merge_module=merge_module, use_pdrop=use_pdrop,
+                                    pdrop_type=pdrop_type)
+        else:
+            config.merge_module, config.use_pdrop, config.pdrop_type = merge_module, use_pdrop, pdrop_type
+        config._attn_implementation = attn_implementation
+        self.llm = NemotronHForCausalLM(config)
+        self.tokenizer = tokenizer or SyntheticTokenizer(config.vocab_size)
+        self.terminators = [self.tokenizer.eos_token_id]
+
+    @property
+    def embed_dim(self) -> int:
+        return self.llm.config.hidden_size
+
+    @property
+    def half_precision_dtype(self) -> torch.dtype:
+        return torch.bfloat16
+
+    def embed_input_ids(self, input_ids: torch.LongTensor) -> torch.Tensor:
+        return self.llm.get_input_embeddings()(input_ids)
+
+    def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None,
+                inputs_embeds=None, labels=None, use_cache=None, output_attentions=None,
+                output_hidden_states=None, return_dict=None, inference_params=None,
+                num_last_tokens: int = 0, cache_position=None, logits_to_keep=None, seq_idx=None,
+                train_pdrop_args=None):
+        """llm_factory.py:177-198."""
+        return self.llm(input_ids=input_ids, attention_mask=attention_mask,
+                        position_ids=position_ids, past_key_values=past_key_values,
+                        inputs_embeds=inputs_embeds, labels=labels, use_cache=use_cache,
+                        output_hidden_states=output_hidden_states, cache_position=cache_position,
+                        logits_to_keep=logits_to_keep, train_pdrop_args=train_pdrop_args)

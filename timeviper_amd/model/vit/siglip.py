@@ -1,0 +1,167 @@
+"""SigLIP / DINOv2-style ViT image backbone with timm-compatible parameter names.
+
+The reference wraps `timm.create_model(...)` (third-party, not vendored; contract in
+timeviper/model/vit/base_vision.py:126-278): forward = `get_intermediate_layers(
+n={depth-2})` — patch-embed, + learned pos-embed, blocks 0..depth-2, no final norm,
+prefix tokens stripped — returning (B, num_patches, embed_dim).  This module
+re-states the public timm VisionTransformer forward for that path with:
+  * the patch embedding as the im2col-free MFMA GEMM (`kernels.patch_embed`, bias and
+    pos-embed fused in the epilogue),
+  * attention on the flash kernel (head_dim 72 for so400m, non-causal),
+  * Linear layers on torch (hipBLASLt), LayerNorm / GELU on torch.
+Parameter names follow timm (`patch_embed.proj`, `pos_embed`, `blocks.{i}.{norm1,attn.
+qkv,attn.proj,norm2,mlp.fc1,mlp.fc2}`, `norm`, `attn_pool.*`) so a timm checkpoint
+loads with strict=True; the pooling head is kept for that reason only and never run.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ... import kernels as K
+
+TIMM_VIT_CONFIGS = {
+    # public timm model definitions (not in the reference tree)
+    "vit_so400m_patch14_siglip_384": dict(img_size=384, patch_size=14, embed_dim=1152, depth=27,
+                                          num_heads=16, mlp_hidden=4304, class_token=False,
+                                          reg_tokens=0, pool="map"),
+    "vit_so400m_patch14_siglip_224": dict(img_size=224, patch_size=14, embed_dim=1152, depth=27,
+                                          num_heads=16, mlp_hidden=4304, class_token=False,
+                                          reg_tokens=0, pool="map"),
+    "vit_base_patch16_siglip_224": dict(img_size=224, patch_size=16, embed_dim=768, depth=12,
+                                        num_heads=12, mlp_hidden=3072, class_token=False,
+                                        reg_tokens=0, pool="map"),
+    "vit_base_patch16_siglip_256": dict(img_size=256, patch_size=16, embed_dim=768, depth=12,
+                                        num_heads=12, mlp_hidden=3072, class_token=False,
+                                        reg_tokens=0, pool="map"),
+    "vit_base_patch16_siglip_384": dict(img_size=384, patch_size=16, embed_dim=768, depth=12,
+                                        num_heads=12, mlp_hidden=3072, class_token=False,
+                                        reg_tokens=0, pool="map"),
+    "vit_large_patch14_reg4_dinov2.lvd142m": dict(img_size=224, patch_size=14, embed_dim=1024,
+                                                  depth=24, num_heads=16, mlp_hidden=4096,
+                                                  class_token=True, reg_tokens=4, pool="token",
+                                                  layer_scale=1e-5, no_embed_class=True),
+}
+
+
+class PatchEmbed(nn.Module):
+    def __init__(self, img_size, patch_size, in_chans, embed_dim):
+        super().__init__()
+        self.img_size, self.patch_size = (img_size, img_size), (patch_size, patch_size)
+        self.grid_size = (img_size // patch_size, img_size // patch_size)
+        self.num_patches = self.grid_size[0] * self.grid_size[1]
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+
+    def forward(self, x, pos: Optional[torch.Tensor] = None):
+        return K.patch_embed(x, self.proj.weight, self.proj.bias, pos)
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, num_heads):
+        super().__init__()
+        self.num_heads, self.head_dim = num_heads, dim // num_heads
+        self.scale = self.head_dim ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=True)
+        self.proj = nn.Linear(dim, dim, bias=True)
+
+    def forward(self, x):
+        B, N, C = x.shape
+        qkv = self.qkv(x).view(B, N, 3, self.num_heads, self.head_dim)
+        o = K.flash_attn_func(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], softmax_scale=self.scale,
+                              causal=False)
+        return self.proj(o.reshape(B, N, C))
+
+
+class Mlp(nn.Module):
+    def __init__(self, dim, hidden, act="gelu"):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.act = nn.GELU(approximate="tanh" if act == "gelu_tanh" else "none")
+        self.fc2 = nn.Linear(hidden, dim)
+
+    def forward(self, x):
+        return self.fc2(self.act(self.fc1(x)))
+
+
+class LayerScale(nn.Module):
+    def __init__(self, dim, init):
+        super().__init__()
+        self.gamma = nn.Parameter(init * torch.ones(dim))
+
+    def forward(self, x):
+        return x * self.gamma
+
+
+class Block(nn.Module):
+    def __init__(self, dim, num_heads, mlp_hidden, act="gelu", layer_scale=None, eps=1e-6):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=eps)
+        self.attn = Attention(dim, num_heads)
+        self.ls1 = LayerScale(dim, layer_scale) if layer_scale else nn.Identity()
+        self.norm2 = nn.LayerNorm(dim, eps=eps)
+        self.mlp = Mlp(dim, mlp_hidden, act)
+        self.ls2 = LayerScale(dim, layer_scale) if layer_scale else nn.Identity()
+
+    def forward(self, x):
+        x = x + self.ls1(self.attn(self.norm1(x)))
+        return x + self.ls2(self.mlp(self.norm2(x)))
+
+
+class AttentionPoolLatent(nn.Module):
+    """SigLIP 'map' head — parameters only (state-dict compatibility); the reference
+    never runs it (num_classes=0 and forward is get_intermediate_layers)."""
+
+    def __init__(self, dim, num_heads, mlp_hidden):
+        super().__init__()
+        self.latent = nn.Parameter(torch.zeros(1, 1, dim))
+        self.q = nn.Linear(dim, dim)
+        self.kv = nn.Linear(dim, dim * 2)
+        self.proj = nn.Linear(dim, dim)
+        self.norm = nn.LayerNorm(dim, eps=1e-6)
+        self.mlp = Mlp(dim, mlp_hidden)
+
+
+class VisionTransformer(nn.Module):
+    def __init__(self, img_size=384, patch_size=14, embed_dim=1152, depth=27, num_heads=16,
+                 mlp_hidden=4304, class_token=False, reg_tokens=0, pool="map", act="gelu",
+                 layer_scale=None, no_embed_class=False, in_chans=3):
+        super().__init__()
+        self.embed_dim, self.depth = embed_dim, depth
+        self.patch_embed = PatchEmbed(img_size, patch_size, in_chans, embed_dim)
+        self.num_prefix_tokens = (1 if class_token else 0) + reg_tokens
+        self.no_embed_class = no_embed_class
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim)) if class_token else None
+        self.reg_token = nn.Parameter(torch.zeros(1, reg_tokens, embed_dim)) if reg_tokens else None
+        n_pos = self.patch_embed.num_patches + (0 if no_embed_class else self.num_prefix_tokens)
+        self.pos_embed = nn.Parameter(torch.randn(1, n_pos, embed_dim) * 0.02)
+        self.blocks = nn.Sequential(*[Block(embed_dim, num_heads, mlp_hidden, act, layer_scale)
+                                      for _ in range(depth)])
+        self.norm = nn.LayerNorm(embed_dim, eps=1e-6)
+        self.attn_pool = AttentionPoolLatent(embed_dim, num_heads, mlp_hidden) if pool == "map" else None
+
+    def get_intermediate_layers(self, x, n=None):
+        """timm semantics for n={k}: run blocks 0..k, return block k's output with
+        the prefix tokens removed, no final norm."""
+        last = max(n) if n is not None else self.depth - 1
+        if self.num_prefix_tokens == 0:
+            x = self.patch_embed(x, self.pos_embed[0])          # bias + pos fused in the GEMM epilogue
+        else:
+            npatch = self.patch_embed.num_patches
+            if self.no_embed_class:
+                x = self.patch_embed(x, self.pos_embed[0])
+                prefix = [t for t in (self.cls_token, self.reg_token) if t is not None]
+                x = torch.cat([t.expand(x.shape[0], -1, -1) for t in prefix] + [x], dim=1)
+            else:
+                x = self.patch_embed(x, None)
+                prefix = [t for t in (self.cls_token, self.reg_token) if t is not None]
+                x = torch.cat([t.expand(x.shape[0], -1, -1) for t in prefix] + [x], dim=1)
+                x = x + self.pos_embed
+        for i in range(last + 1):
+            x = self.blocks[i](x)
+        return (x[:, self.num_prefix_tokens:],)
+
+    def forward(self, x):
+        return self.get_intermediate_layers(x, n={self.depth - 2})[0]
