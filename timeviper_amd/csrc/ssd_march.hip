@@ -3,30 +3,37 @@
 // One 512-thread workgroup owns (batch, head, a <=48-column slice of head_dim) and walks
 // the sequence in chunks of Q=64 tokens, carrying the running state X[n][p] (d_state x
 // slice) in MFMA accumulators for the whole sequence: x, dt, B, C are read ONCE and y is
-// written ONCE — no per-chunk states ever touch HBM (upstream's five-kernel pipeline moves
-// ~2.5x the algorithmic bytes).  With H*slices >= 256 workgroups every CU streams; heads
-// of one B/C group are mapped to one XCD (blockIdx % 8) so the group's B/C tiles are
-// fetched from HBM once and served to its 32 workgroups by that XCD's L2.
+// written ONCE — no per-chunk states, no C.B^T matrices and no dt/cumsum side arrays ever
+// touch HBM (upstream's five-kernel pipeline moves ~2.5x the algorithmic bytes).  With
+// H*slices >= 256 workgroups every CU streams; heads of one B/C group are mapped to one
+// XCD (blockIdx % 8) so the group's B/C tiles are fetched from HBM once and served to its
+// workgroups by that XCD's L2.
+//
+// Data movement: every input tile arrives by LDS-DMA (global_load_lds, 16 B per lane, no
+// VGPR round trip) into a 3-slot ring, two chunks ahead of the math; waits are counted
+// (s_waitcnt vmcnt(N), never 0 in the steady state) and the barriers are raw s_barrier, so
+// the DMA stays in flight across them.  B/C tiles are stored unpadded and XOR-swizzled on
+// the SOURCE address (chunk ^= row&15) so both the row-major (ds_read_b128) and the
+// transposing (ds_read_b64_tr_b16) fragment reads are bank-conflict free.
 //
 // Per chunk (all products on v_mfma_f32_16x16x32_bf16, fp32 accumulate):
-//   wave 0            dt = softplus(dt_raw + bias); cs = wave-prefix-sum(dt*A)   (64 lanes = Q)
-//   CB^T[s][t]      = sum_n B[s][n] C[t][n]                    causal 16x16 tiles only
-//   M[t][s]         = CB * exp(cs_t - cs_s) * dt_s * [s<=t]    -> LDS (bf16)
-//   Yoff^T[p][t]    = sum_n S[p][n] C[t][n]                    S = bf16 copy of X in LDS
-//   Ydiag^T[p][t]   = sum_s x[s][p] M[t][s]
-//   y[t][p]         = Ydiag + exp(cs_t) * Yoff + D x[t][p]     -> LDS tile -> 16-byte row stores
-//   X[n][p]         = exp(cs_Q) X[n][p] + sum_t B[t][n] (exp(cs_Q - cs_t) dt_t x[t][p])
-// Waves 0-3 own one 16-token row block of y each; waves 4-7 own two 16-row blocks of the
-// state each and the bulk of the CB tiles, so every SIMD carries one "y" and one "state"
-// wave.  Next-chunk tiles are prefetched into registers at the top of a step and written to
-// the other LDS buffer at its end (two barriers per step).  Operands that MFMA wants
-// k-major come from the row-major tiles through ds_read_b64_tr_b16.
-//
+//   wave 0            dt = softplus(dt_raw + bias); cs = DPP wave-prefix-sum(dt*A) for the
+//                     NEXT chunk (64 lanes = Q), off the critical path
+//   y-waves 0..3      (16 tokens each)
+//     Yoff^T[p][t]  = sum_n S[p][n] C[t][n]                    S = bf16 copy of X in LDS
+//     CB^T[s][t]    = sum_n B[s][n] C[t][n]                    causal 16x16 tiles only
+//     M^T[s][t]     = CB^T * exp(cs_t - cs_s) * dt_s * [s<=t]  in the accumulator registers,
+//                     which ARE the B operand of the next product (k permuted, no LDS trip)
+//     Ydiag^T[p][t] = sum_s x[s][p] M^T[s][t]
+//     y[t][p]       = Ydiag + exp(cs_t) * Yoff + D x[t][p]     -> LDS tile -> 16-byte row stores
+//   state-waves 4..7  (32 state rows each)
+//     X[n][p]       = exp(cs_Q) X[n][p] + sum_t B[t][n] (exp(cs_Q - cs_t) dt_t x[t][p])
 // Decay factors are only ever formed as exp(cs_i - cs_j) with i >= j inside one chunk
 // (never a quotient of exponentials), like the reference's segment_sum
 // (modeling_nano.py:159-186), so no input can overflow them.
 // Reference semantics: mamba_chunk_scan_combined call modeling_nano.py:639-653;
 // arithmetic :775-851.
+#include <stdlib.h>
 #include "common.hpp"
 
 namespace {
@@ -34,13 +41,14 @@ namespace {
 constexpr int MQ = 64;          // tokens per chunk (= wavefront width)
 constexpr int MN = 128;         // d_state
 constexpr int MTHREADS = 512;
-constexpr int BSTR = MN + 8;    // B/C/S tile row stride (elements): +16 B against bank conflicts
-constexpr int XSTR = 96;        // x tile row stride: 192 B == 48 dwords (mod 64) for tr-reads
-constexpr int MSTR = MQ + 8;    // M tile row stride
+constexpr int SSTR = MN + 8;    // S tile row stride (elements): +16 B against bank conflicts
 constexpr int YSTR = 48;        // y tile row stride
 constexpr int PMAX = 48;        // max head_dim columns per workgroup (3 MFMA tiles)
+constexpr int NSLOT = 3;        // LDS ring depth (prefetch distance 2 chunks)
 
 typedef __attribute__((address_space(3))) bf16x4 lds_v4;
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
 
 __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
@@ -48,21 +56,70 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
 __device__ __forceinline__ bf16x4 tr4(const bf16_t* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)p);
 }
-// k-major 16x32 operand fragment from a row-major [k][col] LDS tile: element j of lane
-// (c = lane&15, kq = lane>>4) is tile[k0 + 8kq + j][c0 + c].
-__device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int stride, int k0, int c0, int lane) {
-  const int kq = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
-  const bf16_t* base = tile + (k0 + 8 * kq + q4) * stride + c0 + 4 * p4;
-  const bf16x4 lo = tr4(base);
-  const bf16x4 hi = tr4(base + 4 * stride);
+__device__ __forceinline__ bf16x8 cat4(bf16x4 lo, bf16x4 hi) {
   bf16x8 r;
 #pragma unroll
   for (int j = 0; j < 4; ++j) { r[j] = lo[j]; r[4 + j] = hi[j]; }
   return r;
 }
-// row-major fragment: element j of lane (r = lane&15, kq) is tile[r0 + r][k0 + 8kq + j]
-__device__ __forceinline__ bf16x8 row_frag(const bf16_t* tile, int stride, int r0, int k0, int lane) {
-  return *(const bf16x8*)(tile + (r0 + (lane & 15)) * stride + k0 + 8 * (lane >> 4));
+// ---- swizzled [64][128] bf16 tile (B, C): element offset of 16-byte chunk cg of row r ----
+__device__ __forceinline__ int swz(int r, int cg) { return r * MN + ((cg ^ (r & 15)) << 3); }
+// row-major fragment: element j of lane (lc, kq) = tile[r0 + lc][k0 + 8kq + j]
+__device__ __forceinline__ bf16x8 row_frag_swz(const bf16_t* tile, int r0, int k0, int lc, int kq) {
+  return *(const bf16x8*)(tile + swz(r0 + lc, (k0 >> 3) + kq));
+}
+// k-major fragment: element j of lane (lc, kq) = tile[k0 + 8kq + j][c0 + lc]
+__device__ __forceinline__ bf16x8 tr_frag_swz(const bf16_t* tile, int k0, int c0, int lane) {
+  const int kq = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+  const int col = c0 + 4 * p4;
+  const int r_lo = k0 + 8 * kq + q4, r_hi = r_lo + 4;
+  const bf16x4 lo = tr4(tile + swz(r_lo, col >> 3) + (col & 4));
+  const bf16x4 hi = tr4(tile + swz(r_hi, col >> 3) + (col & 4));
+  return cat4(lo, hi);
+}
+// k-major fragment from a plain row-major tile; first rows of the two 4-row blocks are given
+__device__ __forceinline__ bf16x8 tr_frag_rows(const bf16_t* tile, int stride, int row_lo, int row_hi,
+                                               int c0, int lane) {
+  const int q4 = (lane & 15) >> 2, p4 = lane & 3;
+  const bf16x4 lo = tr4(tile + (row_lo + q4) * stride + c0 + 4 * p4);
+  const bf16x4 hi = tr4(tile + (row_hi + q4) * stride + c0 + 4 * p4);
+  return cat4(lo, hi);
+}
+
+// LDS-DMA as inline asm: hipcc then does not know an LDS write is in flight, so it inserts
+// no vmcnt(0) in front of the fragment reads (it does for the builtin + ds_read_tr); every
+// wait on these copies is the hand-counted s_waitcnt vmcnt(N) + barrier below.  M0 (the LDS
+// destination base) is saved and restored inside the statement.
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+  return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t*)p);
+}
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// one dword per lane, written at lds_dst + 4*lane
+__device__ __forceinline__ void glds4(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+               "global_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+// inclusive prefix sum over the 64 lanes with DPP row shifts / broadcasts (no LDS)
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float dpp_shift(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROWMASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_incl_scan_dpp(float v) {
+  v += dpp_shift<0x111, 0xf>(v);   // row_shr:1
+  v += dpp_shift<0x112, 0xf>(v);   // row_shr:2
+  v += dpp_shift<0x114, 0xf>(v);   // row_shr:4
+  v += dpp_shift<0x118, 0xf>(v);   // row_shr:8
+  v += dpp_shift<0x142, 0xa>(v);   // row_bcast:15 -> rows 1,3
+  v += dpp_shift<0x143, 0xc>(v);   // row_bcast:31 -> rows 2,3
+  return v;
 }
 
 struct MarchArgs {
@@ -74,59 +131,56 @@ struct MarchArgs {
   int64_t xsb, xsl, dsb, dsl, bsb, bsl, csb, csl, ysb, ysl;
   int softplus, group_map;
   float dt_min, dt_max;
+  int dbg;
 };
 
+struct __attribute__((aligned(16))) MarchSlot {
+  bf16_t Bt[MQ * MN];            // swizzled
+  bf16_t Ct[MQ * MN];            // swizzled
+  bf16_t xt[MQ * PMAX + 64];     // [64][pw] linear (+ finite guard: tile PT-1 reads past pw)
+};
 struct __attribute__((aligned(16))) MarchSmem {
-  bf16_t Bt[2][MQ * BSTR];
-  bf16_t Ct[2][MQ * BSTR];
-  bf16_t xt[2][MQ * XSTR];
-  bf16_t S[2][PMAX * BSTR];
-  bf16_t M[MQ * MSTR];
+  MarchSlot slot[NSLOT];
+  unsigned dtr[4][MQ];  // raw dt of heads (h&~1, h|1) per token, one chunk further ahead
+                        // than the tiles (ring of 4)
+  unsigned pad_[MQ];    // landing pad of the filler DMA
+  bf16_t S[PMAX * SSTR];
   bf16_t yt[MQ * YSTR];
   float cs[2][MQ];    // inclusive cumsum of dt*A inside the chunk
   float dtv[2][MQ];   // discretised dt
   float wts[2][MQ];   // exp(cs_last - cs_t) * dt_t
-  float ecs[2][MQ];   // exp(cs_t)
-  float dlast[2];     // exp(cs_last)
+  float dlast[2][4];  // exp(cs_last)
 };
-
-// causal CB tiles (t-tile, s-tile), s <= t
-__constant__ int kCbT[10] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3};
-__constant__ int kCbS[10] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3};
 
 template <int PT>
 __global__ __launch_bounds__(MTHREADS) void ssd_march_kernel(MarchArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   MarchSmem& sm = *reinterpret_cast<MarchSmem*>(smem_raw);
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lc = lane & 15, kq = lane >> 4;
   const int b = blockIdx.y;
   // blockIdx.x -> (group, head in group, slice): blocks with equal (blockIdx.x % G) share an
   // XCD under round-robin dispatch when G == 8 (speed only, never correctness)
   const int hpg = a.H / a.G;
-  int g, hig, slice;
-  {
-    const int bx = blockIdx.x;
-    g = bx % a.G;
-    const int rest = bx / a.G;
-    hig = rest / a.nslices;
-    slice = rest % a.nslices;
-  }
+  const int g = blockIdx.x % a.G;
+  const int rest = blockIdx.x / a.G;
+  const int hig = rest / a.nslices, slice = rest % a.nslices;
   const int h = a.group_map ? (hig * a.G + g) : (g * hpg + hig);
-  const int p_base = slice * a.pw;
-  const int pw = a.pw;
-  const int nchunks = (a.L + MQ - 1) / MQ;
+  const int pw = a.pw, p_base = slice * pw;
+  const int L = a.L;
+  const int nchunks = (L + MQ - 1) / MQ;
   const float Ah = a.A[h];
   const float Dh = a.D ? a.D[h] : 0.f;
   const float bias = a.dt_bias ? a.dt_bias[h] : 0.f;
 
   const bf16_t* xg = a.x + (int64_t)b * a.xsb + (int64_t)h * a.P + p_base;
-  const bf16_t* dtg = a.dt + (int64_t)b * a.dsb + h;
+  const bf16_t* dtg = a.dt + (int64_t)b * a.dsb + (h & ~1);   // dword holding heads (h&~1, h|1)
   const bf16_t* Bg = a.Bm + (int64_t)b * a.bsb + (int64_t)g * MN;
   const bf16_t* Cg = a.Cm + (int64_t)b * a.csb + (int64_t)g * MN;
   bf16_t* yg = a.y + (int64_t)b * a.ysb + (int64_t)h * a.P + p_base;
 
-  // ---- zero the LDS regions that are read but never (fully) written ----
+  // ---- zero LDS once: pad columns / guards must hold finite values ----
   {
     bf16x8 z = {};
     for (int i = tid; i < (int)(sizeof(MarchSmem) / 16); i += MTHREADS)
@@ -135,7 +189,8 @@ __global__ __launch_bounds__(MTHREADS) void ssd_march_kernel(MarchArgs a) {
   __syncthreads();
 
   const bool ywave = wave < 4;
-  // state accumulators X[n][p]: S-wave w owns n-tiles 2(w-4), 2(w-4)+1; col p = lane&15
+  const int sw = wave - 4;
+  // state accumulators X[n][p]: state-wave sw owns n-tiles 2sw, 2sw+1; col p = lane&15
   f32x4 xacc[2][PT];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -146,162 +201,163 @@ __global__ __launch_bounds__(MTHREADS) void ssd_march_kernel(MarchArgs a) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < PT; ++j) {
-        const int p = 16 * j + lc, n = 16 * (2 * (wave - 4) + i) + 4 * kq;
+        const int p = 16 * j + lc, n = 16 * (2 * sw + i) + 4 * kq;
         if (p < pw) {
           const f32x4 v = *(const f32x4*)(a.init + (((int64_t)b * a.H + h) * a.P + p_base + p) * MN + n);
           xacc[i][j] = v;
           bf16x4 o;
 #pragma unroll
           for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
-          *(bf16x4*)(sm.S[0] + p * BSTR + n) = o;
+          *(bf16x4*)(sm.S + p * SSTR + n) = o;
         }
       }
   }
 
-  // ---- staging registers for the next chunk ----
-  bf16x8 rB[2], rC[2], rX;
-  float rdt = 0.f;
-  const int npc = pw >> 3;                   // 16-byte pieces per x / y row
-  const int xrow = tid / npc, xch = tid % npc;
-  auto issue_loads = [&](int c) {
+  // ---- LDS-DMA issue: every wave moves 2 KB of B, 2 KB of C; waves 0..nxp-1 one x piece
+  //      each, wave 5 the 64 raw dt values.  Rows past L are clamped to a valid row (their dt
+  //      is forced to 0 in prep_chunk, so they contribute nothing).
+  const int npc = pw >> 3;                    // 16-byte pieces per x / y row
+  const int npx = MQ * npc;                   // 16-byte pieces per x / y tile
+  const int nxp = (npx + 63) >> 6;            // x wave-instructions per chunk (<= 5 for pw <= 40)
+  const int x_pc = wave < nxp ? wave : 0;
+  const int x_i = min(x_pc * 64 + lane, npx - 1);
+  const int x_row = x_i / npc, x_ch = x_i - x_row * npc;
+  auto issue = [&](int c) {
+    MarchSlot& s = sm.slot[c % NSLOT];
     const int t0 = c * MQ;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      const int i = tid + k * MTHREADS;      // 1024 16-byte pieces per tile
-      const int row = i >> 4, ch = i & 15;
-      const int t = t0 + row;
-      bf16x8 z = {};
-      rB[k] = t < a.L ? *(const bf16x8*)(Bg + (int64_t)t * a.bsl + ch * 8) : z;
-      rC[k] = t < a.L ? *(const bf16x8*)(Cg + (int64_t)t * a.csl + ch * 8) : z;
+      const int piece = 2 * wave + k;         // 16 pieces of 4 rows
+      const int row = 4 * piece + (lane >> 4);
+      const int cg = (lane & 15) ^ (row & 15);
+      const int64_t t = min(t0 + row, L - 1);
+      glds16(Bg + t * a.bsl + cg * 8, lds_addr_of(s.Bt + piece * 512));
+      glds16(Cg + t * a.csl + cg * 8, lds_addr_of(s.Ct + piece * 512));
     }
-    {
-      const int t = t0 + xrow;
-      bf16x8 z = {};
-      rX = (xrow < MQ && t < a.L) ? *(const bf16x8*)(xg + (int64_t)t * a.xsl + xch * 8) : z;
-    }
-    if (wave == 0) {
-      const int t = t0 + lane;
-      rdt = t < a.L ? (float)dtg[(int64_t)t * a.dsl] : -INFINITY;
+    // fifth DMA of this wave: an x piece (waves < nxp) or the raw dt (wave 6) — waves
+    // that own neither re-fetch x piece 0 into the scratch pad so that EVERY wave issues
+    // exactly 5 vm ops per step (uniform vmcnt bookkeeping)
+    if (wave == 6) {   // raw dt of the chunk AFTER this one (prep runs one step early)
+      const int64_t t = min(t0 + MQ + lane, L - 1);
+      glds4(dtg + t * a.dsl, lds_addr_of(sm.dtr[(c + 1) & 3]));
+    } else {
+      const int64_t t = min(t0 + x_row, L - 1);
+      if (wave < nxp) glds16(xg + t * a.xsl + x_ch * 8, lds_addr_of(s.xt + x_pc * 512));
+      else glds4(dtg + min((int64_t)t0, (int64_t)L - 1) * a.dsl, lds_addr_of(sm.pad_));
     }
   };
-  auto write_stage = [&](int buf) {
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int i = tid + k * MTHREADS;
-      const int row = i >> 4, ch = i & 15;
-      *(bf16x8*)(sm.Bt[buf] + row * BSTR + ch * 8) = rB[k];
-      *(bf16x8*)(sm.Ct[buf] + row * BSTR + ch * 8) = rC[k];
+  // discretise dt and prefix-sum dt*A for chunk c (one wave, 64 lanes = 64 tokens)
+  float decay_total = 0.f;
+  auto prep_chunk = [&](int c) {
+    const int ab = c & 1;
+    const int t = c * MQ + lane;
+    float d = 0.f;
+    if (t < L) {
+      const unsigned w = sm.dtr[c & 3][lane];
+      d = __uint_as_float((h & 1) ? (w & 0xffff0000u) : (w << 16)) + bias;
+      if (a.softplus) d = softplus_f(d);
+      d = fminf(fmaxf(d, a.dt_min), a.dt_max);
     }
-    if (xrow < MQ) *(bf16x8*)(sm.xt[buf] + xrow * XSTR + xch * 8) = rX;
-    if (wave == 0) {
-      // discretise dt and prefix-sum dt*A across the 64 lanes of the wave
-      float d = 0.f;
-      if (rdt != -INFINITY) {
-        d = rdt + bias;
-        if (a.softplus) d = softplus_f(d);
-        d = fminf(fmaxf(d, a.dt_min), a.dt_max);
-      }
-      const float cs = wave_incl_scan(d * Ah);
-      const float cl = __shfl(cs, 63, 64);
-      sm.cs[buf][lane] = cs;
-      sm.dtv[buf][lane] = d;
-      sm.wts[buf][lane] = __expf(cl - cs) * d;
-      sm.ecs[buf][lane] = __expf(cs);
-      if (lane == 0) sm.dlast[buf] = __expf(cl);
-      return cl;
-    }
-    return 0.f;
+    const float cs = wave_incl_scan_dpp(d * Ah);
+    const float cl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs), 63));
+    sm.cs[ab][lane] = cs;
+    sm.dtv[ab][lane] = d;
+    sm.wts[ab][lane] = __expf(cl - cs) * d;
+    if (lane == 0) sm.dlast[ab][0] = __expf(cl);
+    decay_total += cl;
   };
 
-  float decay_total = 0.f;
-  issue_loads(0);
-  decay_total += write_stage(0);
+  // ---- prologue: chunks 0 and 1 in flight, chunk 0 prepared ----
+  if (wave == 6) glds4(dtg + min((int64_t)lane, (int64_t)L - 1) * a.dsl, lds_addr_of(sm.dtr[0]));
+  issue(0);
+  if (nchunks > 1) issue(1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (wave == 0) prep_chunk(0);
   __syncthreads();
 
+  int yq[2], yc[2];                           // (row, 16-byte piece) of this lane's y stores
+#pragma unroll
+  for (int k = 0; k < 2; ++k) { yq[k] = (lane + 64 * k) / npc; yc[k] = (lane + 64 * k) - yq[k] * npc; }
   for (int c = 0; c < nchunks; ++c) {
-    const int buf = c & 1;
-    const bool more = c + 1 < nchunks;
-    if (more) issue_loads(c + 1);
+    const int ab = c & 1;
+    const MarchSlot& s = sm.slot[c % NSLOT];
+    const bool do_issue = (c + 2 < nchunks) && !(a.dbg & 2);
+    if (do_issue) issue(c + 2);
 
-    const bf16_t* Bt = sm.Bt[buf];
-    const bf16_t* Ct = sm.Ct[buf];
-    const bf16_t* xt = sm.xt[buf];
-    const bf16_t* Sc = sm.S[buf];
-
-    // ================= phase 1: Yoff (y-waves), CB^T -> M (mostly state-waves) ==========
-    f32x4 yoff[PT];
-    int ncb, cb0;
-    if (ywave) {
+    if (a.dbg & 1) {
+    } else if (ywave) {
+      // ======================= y-waves: 16 tokens t = 16*wave + lc ======================
+      const int t = 16 * wave + lc;
+      bf16x8 cf[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) cf[ks] = row_frag_swz(s.Ct, 16 * wave, 32 * ks, lc, kq);
+      f32x4 yoff[PT];
 #pragma unroll
       for (int j = 0; j < PT; ++j) yoff[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < MN / 32; ++ks) {
-        const bf16x8 cf = row_frag(Ct, BSTR, 16 * wave, 32 * ks, lane);
+      for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int j = 0; j < PT; ++j) {
-          const bf16x8 sf = row_frag(Sc, BSTR, 16 * j, 32 * ks, lane);
-          yoff[j] = mfma16(sf, cf, yoff[j]);
+          const bf16x8 sf = *(const bf16x8*)(sm.S + (16 * j + lc) * SSTR + 32 * ks + 8 * kq);
+          yoff[j] = mfma16(sf, cf[ks], yoff[j]);
         }
-      }
-      ncb = wave < 2 ? 1 : 0;
-      cb0 = 8 + wave;
-    } else {
-      ncb = 2;
-      cb0 = 2 * (wave - 4);
-    }
-    for (int ic = 0; ic < ncb; ++ic) {
-      const int ti = kCbT[cb0 + ic], si = kCbS[cb0 + ic];
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      // causal CB^T tiles for s-tiles 0..wave, scaled in registers
+      const float cst = sm.cs[ab][t];
+      bf16x4 mt[4];
 #pragma unroll
-      for (int ks = 0; ks < MN / 32; ++ks) {
-        const bf16x8 bf = row_frag(Bt, BSTR, 16 * si, 32 * ks, lane);   // rows s
-        const bf16x8 cf = row_frag(Ct, BSTR, 16 * ti, 32 * ks, lane);   // cols t
-        acc = mfma16(bf, cf, acc);
-      }
-      // acc[r] = CB^T[s = 16si + 4kq + r][t = 16ti + lc]
-      const int t = 16 * ti + lc, s0 = 16 * si + 4 * kq;
-      const float cst = sm.cs[buf][t];
-      const f32x4 css = *(const f32x4*)(&sm.cs[buf][s0]);
-      const f32x4 dts = *(const f32x4*)(&sm.dtv[buf][s0]);
-      bf16x4 o;
+      for (int i = 0; i < 4; ++i) {
+        bf16x4 o = {};
+        if (i <= wave) {
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float e = __expf(fminf(cst - css[r], 0.f));
-        o[r] = (s0 + r <= t) ? (bf16_t)(acc[r] * e * dts[r]) : (bf16_t)0.f;
+          for (int ks = 0; ks < 4; ++ks)
+            acc = mfma16(row_frag_swz(s.Bt, 16 * i, 32 * ks, lc, kq), cf[ks], acc);
+          // acc[r] = CB^T[s = 16i + 4kq + r][t]
+          const int s0 = 16 * i + 4 * kq;
+          const f32x4 css = *(const f32x4*)(&sm.cs[ab][s0]);
+          const f32x4 dts = *(const f32x4*)(&sm.dtv[ab][s0]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float e = __expf(fminf(cst - css[r], 0.f));
+            o[r] = (s0 + r <= t) ? (bf16_t)(acc[r] * e * dts[r]) : (bf16_t)0.f;
+          }
+        }
+        mt[i] = o;
       }
-      *(bf16x4*)(sm.M + t * MSTR + s0) = o;
-    }
-    __syncthreads();
-
-    // ================= phase 2: Ydiag + epilogue (y-waves), state update (state-waves) ===
-    if (ywave) {
+      // Ydiag^T = x^T . M^T : B operand = the packed accumulators; its k-slot j of lane
+      // (lc, kq) is s = 32ks + 4kq + j (j<4) | 32ks + 16 + 4kq + (j-4): x^T rows follow suit
       f32x4 yd[PT];
 #pragma unroll
       for (int j = 0; j < PT; ++j) yd[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const int nks = (wave >> 1) + 1;   // s k-steps of 32 covering s <= 16*wave + 15
-      for (int ks = 0; ks < nks; ++ks) {
-        const bf16x8 mf = row_frag(sm.M, MSTR, 16 * wave, 32 * ks, lane);   // cols t, k = s
 #pragma unroll
-        for (int j = 0; j < PT; ++j) {
-          const bf16x8 xf = tr_frag(xt, XSTR, 32 * ks, 16 * j, lane);       // rows p, k = s
-          yd[j] = mfma16(xf, mf, yd[j]);
+      for (int ks = 0; ks < 2; ++ks) {
+        if (2 * ks <= wave) {
+          const bf16x8 mf = cat4(mt[2 * ks], mt[2 * ks + 1]);
+#pragma unroll
+          for (int j = 0; j < PT; ++j) {
+            const bf16x8 xf = tr_frag_rows(s.xt, pw, 32 * ks + 4 * kq, 32 * ks + 16 + 4 * kq, 16 * j, lane);
+            yd[j] = mfma16(xf, mf, yd[j]);
+          }
         }
       }
-      // y^T[p = 16j + 4kq + r][t = 16wave + lc]
-      const int t = 16 * wave + lc;
-      const float e = sm.ecs[buf][t];
+      // y^T[p = 16j + 4kq + r][t]
+      const float e = __expf(cst);
 #pragma unroll
       for (int j = 0; j < PT; ++j) {
         const int p0 = 16 * j + 4 * kq;
-        const bf16x4 xv = *(const bf16x4*)(xt + t * XSTR + p0);
+        const bf16x4 xv = *(const bf16x4*)(s.xt + t * pw + p0);
         bf16x4 o;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           o[r] = (bf16_t)(yd[j][r] + e * yoff[j][r] + Dh * (float)xv[r]);
         *(bf16x4*)(sm.yt + t * YSTR + p0) = o;
       }
+      // wave 0 prepares dt / cumsum of the NEXT chunk (it landed at the end of the last step)
+      if (wave == 0 && c + 1 < nchunks) prep_chunk(c + 1);
     } else {
-      const float dl = sm.dlast[buf];
+      // ======================= state-waves: X[n][p], n in [32sw, 32sw+32) =================
+      const float dl = sm.dlast[ab][0];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -310,13 +366,13 @@ __global__ __launch_bounds__(MTHREADS) void ssd_march_kernel(MarchArgs a) {
           for (int r = 0; r < 4; ++r) xacc[i][j][r] *= dl;
 #pragma unroll
       for (int ks = 0; ks < MQ / 32; ++ks) {
-        // x~[t][p] = w_t x[t][p], k = t
-        const f32x4 w0 = *(const f32x4*)(&sm.wts[buf][32 * ks + 8 * kq]);
-        const f32x4 w1 = *(const f32x4*)(&sm.wts[buf][32 * ks + 8 * kq + 4]);
+        const f32x4 w0 = *(const f32x4*)(&sm.wts[ab][32 * ks + 8 * kq]);
+        const f32x4 w1 = *(const f32x4*)(&sm.wts[ab][32 * ks + 8 * kq + 4]);
         bf16x8 xs[PT];
 #pragma unroll
         for (int j = 0; j < PT; ++j) {
-          const bf16x8 xf = tr_frag(xt, XSTR, 32 * ks, 16 * j, lane);       // k = t, cols p
+          const int r0 = 32 * ks + 8 * kq;
+          const bf16x8 xf = tr_frag_rows(s.xt, pw, r0, r0 + 4, 16 * j, lane);   // k = t, cols p
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             xs[j][e] = (bf16_t)((float)xf[e] * w0[e]);
@@ -325,33 +381,47 @@ __global__ __launch_bounds__(MTHREADS) void ssd_march_kernel(MarchArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          const int n0 = 16 * (2 * (wave - 4) + i);
-          const bf16x8 bf = tr_frag(Bt, BSTR, 32 * ks, n0, lane);           // rows n, k = t
+          const bf16x8 bf = tr_frag_swz(s.Bt, 32 * ks, 16 * (2 * sw + i), lane);   // rows n, k = t
 #pragma unroll
           for (int j = 0; j < PT; ++j) xacc[i][j] = mfma16(bf, xs[j], xacc[i][j]);
         }
       }
-      // bf16 copy of the new state for the next chunk's Yoff: S[p][n]
-      bf16_t* Sn = sm.S[buf ^ 1];
+    }
+    // ---- barrier A: every Yoff read of S is done -> publish the new state (bf16) ----
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (!ywave && !(a.dbg & 1)) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < PT; ++j) {
-          const int p = 16 * j + lc, n = 16 * (2 * (wave - 4) + i) + 4 * kq;
+          const int p = 16 * j + lc, n = 16 * (2 * sw + i) + 4 * kq;
           bf16x4 o;
 #pragma unroll
           for (int r = 0; r < 4; ++r) o[r] = (bf16_t)xacc[i][j][r];
-          *(bf16x4*)(Sn + p * BSTR + n) = o;
+          *(bf16x4*)(sm.S + p * SSTR + n) = o;
         }
     }
-    if (more) decay_total += write_stage(buf ^ 1);
-    __syncthreads();
-
-    // ================= coalesced y store: 16 bytes per lane, whole rows =================
-    {
-      const int t = c * MQ + xrow;
-      if (xrow < MQ && t < a.L)
-        *(bf16x8*)(yg + (int64_t)t * a.ysl + xch * 8) = *(const bf16x8*)(sm.yt + xrow * YSTR + xch * 8);
+    // ---- barrier B: chunk c+1 has landed, S / cs visible.  Exactly 5 vm ops are younger
+    // than chunk c+1's DMA when a group was issued this step (its 5 copies; the y stores of
+    // the previous step are older than those) ----
+    if (!do_issue) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // ---- coalesced y store: each y-wave streams out the 16 rows it produced (whole rows,
+    // 16 bytes per lane; no other wave touches them, so no barrier is needed) ----
+    if (ywave && !(a.dbg & 4)) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int i = lane + 64 * k;
+        if (i < 16 * npc) {
+          const int row = 16 * wave + yq[k], ch = yc[k];
+          const int t = c * MQ + row;
+          if (t < L)
+            *(bf16x8*)(yg + (int64_t)t * a.ysl + ch * 8) = *(const bf16x8*)(sm.yt + row * YSTR + ch * 8);
+        }
+      }
     }
   }
 
@@ -360,7 +430,7 @@ __global__ __launch_bounds__(MTHREADS) void ssd_march_kernel(MarchArgs a) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < PT; ++j) {
-        const int p = 16 * j + lc, n = 16 * (2 * (wave - 4) + i) + 4 * kq;
+        const int p = 16 * j + lc, n = 16 * (2 * sw + i) + 4 * kq;
         if (p < pw)
           *(f32x4*)(a.final_state + (((int64_t)b * a.H + h) * a.P + p_base + p) * MN + n) = xacc[i][j];
       }
@@ -373,7 +443,6 @@ bool pick_slices(int P, int* nslices, int* pw) {
     if (P % ns) continue;
     const int w = P / ns;
     if (w <= PMAX && w % 8 == 0) {
-      // prefer >= 2 slices for P > 48 only; smaller heads take one slice
       *nslices = ns;
       *pw = w;
       return true;
@@ -390,7 +459,7 @@ bool tv_ssd_march_supported(int seqlen, int nheads, int headdim, int ngroups, in
   int ns, pw;
   if (dtype != TV_BF16 || dstate != MN || seqlen < 1) return false;
   if (!pick_slices(headdim, &ns, &pw)) return false;
-  if (xsl % 8 || bsl % 8 || csl % 8 || ysl % 8) return false;
+  if (xsl % 8 || bsl % 8 || csl % 8 || ysl % 8 || nheads % 2) return false;
   if (((uintptr_t)x & 15) || ((uintptr_t)Bm & 15) || ((uintptr_t)Cm & 15) || ((uintptr_t)y & 15))
     return false;
   if (headdim % 8) return false;
@@ -419,6 +488,7 @@ int tv_ssd_march_launch(const void* x, const void* dt, const void* A, const void
   a.xsb = xsb; a.xsl = xsl; a.dsb = dsb; a.dsl = dsl; a.bsb = bsb; a.bsl = bsl;
   a.csb = csb; a.csl = csl; a.ysb = ysb; a.ysl = ysl;
   a.softplus = dt_softplus; a.group_map = group_map; a.dt_min = dt_min; a.dt_max = dt_max;
+  { const char* e = getenv("TV_MARCH_DBG"); a.dbg = e ? atoi(e) : 0; }
   dim3 grid(nheads * a.nslices, batch);
   const size_t lds = sizeof(MarchSmem);
   const int pt = (a.pw + 15) / 16;

@@ -63,7 +63,8 @@ extern "C" int tv_ssd_scan_fwd(const void* x, const void* dt, const void* A, con
     if (total_decay) (void)hipMemsetAsync(total_decay, 0, (size_t)batch * nheads * sizeof(float), st);
     return TV_OK;
   }
-  bool march = g_ssd_impl != 1 &&
+  bool march = g_ssd_impl != 1 && dt_stride_l % 2 == 0 && dt_stride_b % 2 == 0 &&
+               (((uintptr_t)dt) & 3) == 0 &&
                tv_ssd_march_supported(seqlen, nheads, headdim, ngroups, dstate, dtype, x_stride_l,
                                       b_stride_l, c_stride_l, y_stride_l, x, Bm, Cm, y);
   if (g_ssd_impl == 2 && !march)
