@@ -61,6 +61,18 @@ int tv_causal_conv1d_fwd(const void* x, const void* weight, const void* bias,
                          int64_t x_stride_l, int64_t y_stride_b,
                          int64_t y_stride_l, int dtype, int silu, void* stream);
 
+/* Same convolution for the Mamba-2 mixer's xBC projection, with the three
+ * channel segments [x: d_inner | B: G*N | C: G*N] (the split of
+ * modeling_nano.py:628-636) written to three destinations: x as (B,L,d_inner)
+ * rows, B and C GROUP-MAJOR as (B,G,L,N) — the layout the scan kernel streams
+ * best.  Input x (B,L,d_inner+2GN) as in tv_causal_conv1d_fwd.               */
+int tv_causal_conv1d_xbc_fwd(const void* x, const void* weight, const void* bias,
+                             const void* halo, void* y_x, void* y_b, void* y_c,
+                             int batch, int seqlen, int d_inner, int ngroups,
+                             int dstate, int kernel, int64_t x_stride_b,
+                             int64_t x_stride_l, int dtype, int silu,
+                             void* stream);
+
 /* Single-token decode step, replaces causal_conv1d_update (:495-501).
  * conv_state (B,C,K) contiguous, updated in place (shift left, append x).   */
 int tv_causal_conv1d_update(const void* x, void* conv_state, const void* weight,
@@ -103,7 +115,11 @@ int tv_rmsnorm_gated_fwd(const void* x, const void* z, const void* weight,
  *   S_t   = exp(dt_t A_h) S_{t-1} + dt_t x_t (outer) B_t ;  S_{-1} = init
  *   y_t   = S_t . C_t + D_h x_t ;   final = S_{L-1}
  * x (B,L,H,P), dt (B,L,H), Bm/Cm (B,L,G,N), y (B,L,H,P) in `dtype` with
- * per-tensor (batch,row) strides; A, D, dt_bias (H) fp32; init_state /
+ * per-tensor (batch,row) strides; Bm/Cm additionally carry a group stride, so
+ * both the reference's token-major rows (stride_g = N) and the group-major
+ * layout (G,L,N) written by tv_causal_conv1d_xbc_fwd (stride_l = N, stride_g =
+ * L*N; consecutive tokens of one group are contiguous and spread over all L2
+ * channels) are accepted; A, D, dt_bias (H) fp32; init_state /
  * final_state (B,H,P,N) fp32 contiguous (either may be NULL); D, dt_bias may
  * be NULL.  group_map: 0 = head h reads group h / (H/G) (GPU reference and
  * checkpoints), 1 = h % G (quirk of the reference's CPU torch_forward,
@@ -122,8 +138,9 @@ int tv_ssd_scan_fwd(const void* x, const void* dt, const void* A,
                     int seqlen, int nheads, int headdim, int ngroups,
                     int dstate, int64_t x_stride_b, int64_t x_stride_l,
                     int64_t dt_stride_b, int64_t dt_stride_l,
-                    int64_t b_stride_b, int64_t b_stride_l, int64_t c_stride_b,
-                    int64_t c_stride_l, int64_t y_stride_b, int64_t y_stride_l,
+                    int64_t b_stride_b, int64_t b_stride_l, int64_t b_stride_g,
+                    int64_t c_stride_b, int64_t c_stride_l, int64_t c_stride_g,
+                    int64_t y_stride_b, int64_t y_stride_l,
                     int dtype, int dt_softplus, float dt_min, float dt_max,
                     int group_map, void* workspace, size_t workspace_bytes,
                     void* stream);

@@ -397,3 +397,32 @@ def test_patch_embed_video(K):
     ref = R.patch_embed_video_ref(pix.float(), w.float(), b.float())
     out = K.patch_embed_video(pix.to(DEV), w.to(DEV), b.to(DEV))
     close(out, ref, 2e-2, 2e-2)
+
+
+def test_conv1d_xbc_group_major(K):
+    """Mamba-2 xBC conv: same numbers as causal_conv1d_fn, B/C returned group-major."""
+    g = torch.Generator().manual_seed(21)
+    d_in, G, N, L = 160, 2, 128, 77
+    wide = torch.randn(2, L, 40 + d_in + 2 * G * N, generator=g).to(torch.bfloat16)
+    w = (torch.randn(d_in + 2 * G * N, 4, generator=g) * 0.5).to(torch.bfloat16)
+    b = (torch.randn(d_in + 2 * G * N, generator=g) * 0.1).to(torch.bfloat16)
+    xs = wide[:, :, 40:]
+    ref = R.causal_conv1d_ref(xs.float(), w.float(), b.float())
+    x, Bm, Cm = K.causal_conv1d_xbc(wide.to(DEV)[:, :, 40:], w.to(DEV), b.to(DEV), d_in, G, N)
+    assert Bm.shape == (2, L, G, N) and Bm.stride(2) == L * N and Bm.stride(1) == N
+    close(x, ref[..., :d_in], *TOL[torch.bfloat16])
+    close(Bm.reshape(2, L, G * N), ref[..., d_in:d_in + G * N], *TOL[torch.bfloat16])
+    close(Cm.reshape(2, L, G * N), ref[..., d_in + G * N:], *TOL[torch.bfloat16])
+    # identical bits to the unsplit kernel
+    y = K.causal_conv1d_fn(wide.to(DEV)[:, :, 40:].transpose(1, 2), w.to(DEV), b.to(DEV), activation="silu")
+    assert torch.equal(y.transpose(1, 2)[..., :d_in], x)
+    assert torch.equal(y.transpose(1, 2)[..., d_in:d_in + G * N], Bm.reshape(2, L, G * N))
+    # and the scan accepts the group-major views
+    H, P = 2, 80
+    A = -(torch.rand(H, generator=g) * 15 + 1)
+    dt = (torch.randn(2, L, H, generator=g) * 0.5).to(torch.bfloat16)
+    y2, fin = K.mamba_chunk_scan_combined(x.view(2, L, H, P), dt.to(DEV), A.to(DEV), Bm, Cm, dt_softplus=True,
+                                          return_final_states=True)
+    yr, fr, _ = R.ssd_recurrence_ref(x.float().cpu().view(2, L, H, P), dt.float(), A, Bm.float().cpu(), Cm.float().cpu())
+    close(y2, yr, 2e-2, 4e-2)
+    close(fin, fr, 2e-2, 2e-2)

@@ -23,11 +23,12 @@ SIGNATURES = {
     "tv_abi_version": (_i, []),
     "tv_last_error": (C.c_char_p, []),
     "tv_causal_conv1d_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _l, _l, _l, _l, _i, _i, _p]),
+    "tv_causal_conv1d_xbc_fwd": (_i, [_p] * 7 + [_i] * 6 + [_l, _l, _i, _i, _p]),
     "tv_causal_conv1d_update": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "tv_rmsnorm_fwd": (_i, [_p, _p, _p, _p, _p, _l, _i, _l, _l, _l, _l, _f, _i, _i, _p]),
     "tv_rmsnorm_gated_fwd": (_i, [_p, _p, _p, _p, _l, _i, _i, _l, _l, _l, _f, _i, _i, _p]),
     "tv_ssd_scan_workspace_bytes": (_z, [_i] * 7),
-    "tv_ssd_scan_fwd": (_i, [_p] * 11 + [_i] * 6 + [_l] * 10 + [_i, _i, _f, _f, _i, _p, _z, _p]),
+    "tv_ssd_scan_fwd": (_i, [_p] * 11 + [_i] * 6 + [_l] * 12 + [_i, _i, _f, _f, _i, _p, _z, _p]),
     "tv_ssd_scan_set_impl": (None, [_i]),
     "tv_selective_state_update": (_i, [_p] * 9 + [_i] * 7 + [_p]),
     "tv_flash_attn_fwd": (_i, [_p] * 5 + [_i] * 6 + [_l] * 12 + [_f, _i, _i, _p]),

@@ -22,7 +22,7 @@ struct SsdArgs {
   void* y;
   float *final_state, *total_decay;
   int L, H, P, G, N;
-  int64_t xsb, xsl, dsb, dsl, bsb, bsl, csb, csl, ysb, ysl;
+  int64_t xsb, xsl, dsb, dsl, bsb, bsl, bsg, csb, csl, csg, ysb, ysl;
   int softplus, group_map;
   float dt_min, dt_max;
 };
@@ -49,8 +49,8 @@ __global__ __launch_bounds__(GS_THREADS) void ssd_generic_kernel(SsdArgs a) {
 
   const T* xb = (const T*)a.x + (int64_t)b * a.xsb + (int64_t)h * a.P;
   const T* dtb = (const T*)a.dt + (int64_t)b * a.dsb + h;
-  const T* Bb = (const T*)a.Bm + (int64_t)b * a.bsb + (int64_t)g * N;
-  const T* Cb = (const T*)a.Cm + (int64_t)b * a.csb + (int64_t)g * N;
+  const T* Bb = (const T*)a.Bm + (int64_t)b * a.bsb + (int64_t)g * a.bsg;
+  const T* Cb = (const T*)a.Cm + (int64_t)b * a.csb + (int64_t)g * a.csg;
   T* yb = (T*)a.y + (int64_t)b * a.ysb + (int64_t)h * a.P;
 
   float s[NPT];
@@ -175,7 +175,7 @@ int tv_ssd_generic_launch(const void* x, const void* dt, const void* A, const vo
                           const void* init_state, void* y, void* final_state, void* total_decay,
                           int batch, int seqlen, int nheads, int headdim, int ngroups, int dstate,
                           int64_t xsb, int64_t xsl, int64_t dsb, int64_t dsl, int64_t bsb,
-                          int64_t bsl, int64_t csb, int64_t csl, int64_t ysb, int64_t ysl,
+                          int64_t bsl, int64_t bsg, int64_t csb, int64_t csl, int64_t csg, int64_t ysb, int64_t ysl,
                           int dtype, int dt_softplus, float dt_min, float dt_max, int group_map,
                           hipStream_t st) {
   SsdArgs a;
@@ -184,8 +184,8 @@ int tv_ssd_generic_launch(const void* x, const void* dt, const void* A, const vo
   a.init = (const float*)init_state; a.y = y; a.final_state = (float*)final_state;
   a.total_decay = (float*)total_decay;
   a.L = seqlen; a.H = nheads; a.P = headdim; a.G = ngroups; a.N = dstate;
-  a.xsb = xsb; a.xsl = xsl; a.dsb = dsb; a.dsl = dsl; a.bsb = bsb; a.bsl = bsl;
-  a.csb = csb; a.csl = csl; a.ysb = ysb; a.ysl = ysl;
+  a.xsb = xsb; a.xsl = xsl; a.dsb = dsb; a.dsl = dsl; a.bsb = bsb; a.bsl = bsl; a.bsg = bsg;
+  a.csb = csb; a.csl = csl; a.csg = csg; a.ysb = ysb; a.ysl = ysl;
   a.softplus = dt_softplus; a.group_map = group_map; a.dt_min = dt_min; a.dt_max = dt_max;
   switch (dtype) {
     case TV_F32: return launch_generic<float>(a, batch, st);

@@ -43,6 +43,7 @@ constexpr int MN = 128;         // d_state
 constexpr int MTHREADS = 512;
 constexpr int SSTR = MN + 8;    // S tile row stride (elements): +16 B against bank conflicts
 constexpr int YSTR = 48;        // y tile row stride
+constexpr int MSTR = MQ + 8;    // M tile row stride (144 B: conflict-free b128 row reads)
 constexpr int PMAX = 48;        // max head_dim columns per workgroup (3 MFMA tiles)
 constexpr int NSLOT = 3;        // LDS ring depth (prefetch distance 2 chunks)
 
@@ -128,7 +129,7 @@ struct MarchArgs {
   bf16_t* y;
   float *final_state, *total_decay;
   int L, H, P, G, nslices, pw;
-  int64_t xsb, xsl, dsb, dsl, bsb, bsl, csb, csl, ysb, ysl;
+  int64_t xsb, xsl, dsb, dsl, bsb, bsl, bsg, csb, csl, csg, ysb, ysl;
   int softplus, group_map;
   float dt_min, dt_max;
   int dbg;
@@ -146,6 +147,7 @@ struct __attribute__((aligned(16))) MarchSmem {
   unsigned pad_[MQ];    // landing pad of the filler DMA
   bf16_t S[PMAX * SSTR];
   bf16_t yt[MQ * YSTR];
+  bf16_t M[MQ * MSTR];          // decay-masked C.B^T of the chunk, [t][s]; s>t tiles stay 0
   float cs[2][MQ];    // inclusive cumsum of dt*A inside the chunk
   float dtv[2][MQ];   // discretised dt
   float wts[2][MQ];   // exp(cs_last - cs_t) * dt_t
@@ -176,8 +178,8 @@ __global__ __launch_bounds__(MTHREADS) void ssd_march_kernel(MarchArgs a) {
 
   const bf16_t* xg = a.x + (int64_t)b * a.xsb + (int64_t)h * a.P + p_base;
   const bf16_t* dtg = a.dt + (int64_t)b * a.dsb + (h & ~1);   // dword holding heads (h&~1, h|1)
-  const bf16_t* Bg = a.Bm + (int64_t)b * a.bsb + (int64_t)g * MN;
-  const bf16_t* Cg = a.Cm + (int64_t)b * a.csb + (int64_t)g * MN;
+  const bf16_t* Bg = a.Bm + (int64_t)b * a.bsb + (int64_t)g * a.bsg;
+  const bf16_t* Cg = a.Cm + (int64_t)b * a.csb + (int64_t)g * a.csg;
   bf16_t* yg = a.y + (int64_t)b * a.ysb + (int64_t)h * a.P + p_base;
 
   // ---- zero LDS once: pad columns / guards must hold finite values ----
@@ -285,78 +287,98 @@ __global__ __launch_bounds__(MTHREADS) void ssd_march_kernel(MarchArgs a) {
     const bool do_issue = (c + 2 < nchunks) && !(a.dbg & 2);
     if (do_issue) issue(c + 2);
 
-    if (a.dbg & 1) {
-    } else if (ywave) {
-      // ======================= y-waves: 16 tokens t = 16*wave + lc ======================
-      const int t = 16 * wave + lc;
-      bf16x8 cf[4];
+    const bool skip_y = (a.dbg & 1) || (a.dbg & 16), skip_s = (a.dbg & 1) || (a.dbg & 32);
+    // ================= phase 1: Yoff (y-waves) | CB^T -> M (state-waves) ==================
+    f32x4 yoff[PT];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) cf[ks] = row_frag_swz(s.Ct, 16 * wave, 32 * ks, lc, kq);
-      f32x4 yoff[PT];
+    for (int j = 0; j < PT; ++j) yoff[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (ywave) {
+      if (!skip_y) {
 #pragma unroll
-      for (int j = 0; j < PT; ++j) yoff[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-        for (int j = 0; j < PT; ++j) {
-          const bf16x8 sf = *(const bf16x8*)(sm.S + (16 * j + lc) * SSTR + 32 * ks + 8 * kq);
-          yoff[j] = mfma16(sf, cf[ks], yoff[j]);
-        }
-      // causal CB^T tiles for s-tiles 0..wave, scaled in registers
-      const float cst = sm.cs[ab][t];
-      bf16x4 mt[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        bf16x4 o = {};
-        if (i <= wave) {
-          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks)
-            acc = mfma16(row_frag_swz(s.Bt, 16 * i, 32 * ks, lc, kq), cf[ks], acc);
-          // acc[r] = CB^T[s = 16i + 4kq + r][t]
-          const int s0 = 16 * i + 4 * kq;
-          const f32x4 css = *(const f32x4*)(&sm.cs[ab][s0]);
-          const f32x4 dts = *(const f32x4*)(&sm.dtv[ab][s0]);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float e = __expf(fminf(cst - css[r], 0.f));
-            o[r] = (s0 + r <= t) ? (bf16_t)(acc[r] * e * dts[r]) : (bf16_t)0.f;
-          }
-        }
-        mt[i] = o;
-      }
-      // Ydiag^T = x^T . M^T : B operand = the packed accumulators; its k-slot j of lane
-      // (lc, kq) is s = 32ks + 4kq + j (j<4) | 32ks + 16 + 4kq + (j-4): x^T rows follow suit
-      f32x4 yd[PT];
-#pragma unroll
-      for (int j = 0; j < PT; ++j) yd[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        if (2 * ks <= wave) {
-          const bf16x8 mf = cat4(mt[2 * ks], mt[2 * ks + 1]);
+        for (int ks = 0; ks < 4; ++ks) {
+          const bf16x8 cf = row_frag_swz(s.Ct, 16 * wave, 32 * ks, lc, kq);
 #pragma unroll
           for (int j = 0; j < PT; ++j) {
-            const bf16x8 xf = tr_frag_rows(s.xt, pw, 32 * ks + 4 * kq, 32 * ks + 16 + 4 * kq, 16 * j, lane);
-            yd[j] = mfma16(xf, mf, yd[j]);
+            const bf16x8 sf = *(const bf16x8*)(sm.S + (16 * j + lc) * SSTR + 32 * ks + 8 * kq);
+            yoff[j] = mfma16(sf, cf, yoff[j]);
           }
         }
       }
-      // y^T[p = 16j + 4kq + r][t]
-      const float e = __expf(cst);
+    } else if (!skip_s) {
+      // causal CB^T tiles (t-tile, s-tile): sw0 (3,0)(3,1)(0,0) | sw1 (3,2)(3,3)(1,1) |
+      // sw2 (2,0)(2,1) | sw3 (2,2)(1,0): two tiles share the C rows, chains interleave
+      const int tA = sw < 2 ? 3 : 2;
+      const int sA0 = sw == 0 ? 0 : sw == 1 ? 2 : sw == 2 ? 0 : 2;
+      const int sA1 = sw == 3 ? -1 : sA0 + 1;             // second tile of the shared row
+      const int tB = sw == 0 ? 0 : 1;                      // the odd tile (sw2 has none)
+      const int sB = sw == 3 ? 0 : sw;                     // (0,0) (1,1) - (1,0)
+      f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0;
 #pragma unroll
-      for (int j = 0; j < PT; ++j) {
-        const int p0 = 16 * j + 4 * kq;
-        const bf16x4 xv = *(const bf16x4*)(s.xt + t * pw + p0);
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 cfa = row_frag_swz(s.Ct, 16 * tA, 32 * ks, lc, kq);
+        c0 = mfma16(row_frag_swz(s.Bt, 16 * sA0, 32 * ks, lc, kq), cfa, c0);
+        if (sA1 >= 0) c1 = mfma16(row_frag_swz(s.Bt, 16 * sA1, 32 * ks, lc, kq), cfa, c1);
+        if (sw != 2)
+          c2 = mfma16(row_frag_swz(s.Bt, 16 * sB, 32 * ks, lc, kq),
+                      row_frag_swz(s.Ct, 16 * tB, 32 * ks, lc, kq), c2);
+      }
+      auto emit = [&](const f32x4& acc, int ti, int si) {
+        // acc[r] = CB^T[s = 16si + 4kq + r][t = 16ti + lc]  ->  M[t][s] (bf16)
+        const int t = 16 * ti + lc, s0 = 16 * si + 4 * kq;
+        const float cst = sm.cs[ab][t];
+        const f32x4 css = *(const f32x4*)(&sm.cs[ab][s0]);
+        const f32x4 dts = *(const f32x4*)(&sm.dtv[ab][s0]);
         bf16x4 o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          o[r] = (bf16_t)(yd[j][r] + e * yoff[j][r] + Dh * (float)xv[r]);
-        *(bf16x4*)(sm.yt + t * YSTR + p0) = o;
+        for (int r = 0; r < 4; ++r) {
+          const float e = __expf(fminf(cst - css[r], 0.f));
+          o[r] = (s0 + r <= t) ? (bf16_t)(acc[r] * e * dts[r]) : (bf16_t)0.f;
+        }
+        *(bf16x4*)(sm.M + t * MSTR + s0) = o;
+      };
+      emit(c0, tA, sA0);
+      if (sA1 >= 0) emit(c1, tA, sA1);
+      if (sw != 2) emit(c2, tB, sB);
+    }
+    // ---- barrier A: M visible; every Yoff read of S is done ----
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // ================= phase 2: Ydiag + epilogue (y-waves) | state update (state-waves) ====
+    if (ywave) {
+      if (!skip_y) {
+        const int t = 16 * wave + lc;
+        f32x4 yd[PT];
+#pragma unroll
+        for (int j = 0; j < PT; ++j) yd[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          if (ks == 0 || wave >= 2) {   // s > t tiles of M are zero and never needed
+            const bf16x8 mf = *(const bf16x8*)(sm.M + t * MSTR + 32 * ks + 8 * kq);   // k = s
+#pragma unroll
+            for (int j = 0; j < PT; ++j) {
+              const int r0 = 32 * ks + 8 * kq;
+              const bf16x8 xf = tr_frag_rows(s.xt, pw, r0, r0 + 4, 16 * j, lane);     // rows p
+              yd[j] = mfma16(xf, mf, yd[j]);
+            }
+          }
+        }
+        // y^T[p = 16j + 4kq + r][t]
+        const float e = __expf(sm.cs[ab][t]);
+#pragma unroll
+        for (int j = 0; j < PT; ++j) {
+          const int p0 = 16 * j + 4 * kq;
+          const bf16x4 xv = *(const bf16x4*)(s.xt + t * pw + p0);
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            o[r] = (bf16_t)(yd[j][r] + e * yoff[j][r] + Dh * (float)xv[r]);
+          *(bf16x4*)(sm.yt + t * YSTR + p0) = o;
+        }
       }
-      // wave 0 prepares dt / cumsum of the NEXT chunk (it landed at the end of the last step)
-      if (wave == 0 && c + 1 < nchunks) prep_chunk(c + 1);
-    } else {
-      // ======================= state-waves: X[n][p], n in [32sw, 32sw+32) =================
+      // wave 0 prepares dt / cumsum of the NEXT chunk (its dt landed a step ago)
+      if (wave == 0 && c + 1 < nchunks && !(a.dbg & 1)) prep_chunk(c + 1);
+    } else if (!skip_s) {
+      // X[n][p], n in [32sw, 32sw+32)
       const float dl = sm.dlast[ab][0];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -386,11 +408,8 @@ __global__ __launch_bounds__(MTHREADS) void ssd_march_kernel(MarchArgs a) {
           for (int j = 0; j < PT; ++j) xacc[i][j] = mfma16(bf, xs[j], xacc[i][j]);
         }
       }
-    }
-    // ---- barrier A: every Yoff read of S is done -> publish the new state (bf16) ----
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (!ywave && !(a.dbg & 1)) {
+      // publish the new state (bf16) for the next chunk's Yoff: all reads of S finished
+      // before barrier A
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -405,7 +424,8 @@ __global__ __launch_bounds__(MTHREADS) void ssd_march_kernel(MarchArgs a) {
     // ---- barrier B: chunk c+1 has landed, S / cs visible.  Exactly 5 vm ops are younger
     // than chunk c+1's DMA when a group was issued this step (its 5 copies; the y stores of
     // the previous step are older than those) ----
-    if (!do_issue) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (a.dbg & 2) {}   // ablation: nothing in flight
+    else if (!do_issue) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -418,8 +438,11 @@ __global__ __launch_bounds__(MTHREADS) void ssd_march_kernel(MarchArgs a) {
         if (i < 16 * npc) {
           const int row = 16 * wave + yq[k], ch = yc[k];
           const int t = c * MQ + row;
-          if (t < L)
-            *(bf16x8*)(yg + (int64_t)t * a.ysl + ch * 8) = *(const bf16x8*)(sm.yt + row * YSTR + ch * 8);
+          if (t < L) {
+            bf16_t* dstp = (a.dbg & 8) ? a.y + ((int64_t)(b * gridDim.x + blockIdx.x) * L + t) * pw + ch * 8
+                                       : yg + (int64_t)t * a.ysl + ch * 8;
+            *(bf16x8*)dstp = *(const bf16x8*)(sm.yt + row * YSTR + ch * 8);
+          }
         }
       }
     }
@@ -454,12 +477,12 @@ bool pick_slices(int P, int* nslices, int* pw) {
 }  // namespace
 
 bool tv_ssd_march_supported(int seqlen, int nheads, int headdim, int ngroups, int dstate,
-                            int dtype, int64_t xsl, int64_t bsl, int64_t csl, int64_t ysl,
+                            int dtype, int64_t xsl, int64_t bsl, int64_t bsg, int64_t csl, int64_t csg, int64_t ysl,
                             const void* x, const void* Bm, const void* Cm, const void* y) {
   int ns, pw;
   if (dtype != TV_BF16 || dstate != MN || seqlen < 1) return false;
   if (!pick_slices(headdim, &ns, &pw)) return false;
-  if (xsl % 8 || bsl % 8 || csl % 8 || ysl % 8 || nheads % 2) return false;
+  if (xsl % 8 || bsl % 8 || csl % 8 || bsg % 8 || csg % 8 || ysl % 8 || nheads % 2) return false;
   if (((uintptr_t)x & 15) || ((uintptr_t)Bm & 15) || ((uintptr_t)Cm & 15) || ((uintptr_t)y & 15))
     return false;
   if (headdim % 8) return false;
@@ -474,7 +497,7 @@ int tv_ssd_march_launch(const void* x, const void* dt, const void* A, const void
                         const void* init_state, void* y, void* final_state, void* total_decay,
                         int batch, int seqlen, int nheads, int headdim, int ngroups, int dstate,
                         int64_t xsb, int64_t xsl, int64_t dsb, int64_t dsl, int64_t bsb,
-                        int64_t bsl, int64_t csb, int64_t csl, int64_t ysb, int64_t ysl,
+                        int64_t bsl, int64_t bsg, int64_t csb, int64_t csl, int64_t csg, int64_t ysb, int64_t ysl,
                         int dtype, int dt_softplus, float dt_min, float dt_max, int group_map,
                         void* workspace, size_t workspace_bytes, hipStream_t st) {
   (void)workspace; (void)workspace_bytes; (void)dtype; (void)dstate;
@@ -485,8 +508,8 @@ int tv_ssd_march_launch(const void* x, const void* dt, const void* A, const void
   a.total_decay = (float*)total_decay;
   a.L = seqlen; a.H = nheads; a.P = headdim; a.G = ngroups;
   if (!pick_slices(headdim, &a.nslices, &a.pw)) TV_UNSUPPORTED("ssd_march: head_dim %d", headdim);
-  a.xsb = xsb; a.xsl = xsl; a.dsb = dsb; a.dsl = dsl; a.bsb = bsb; a.bsl = bsl;
-  a.csb = csb; a.csl = csl; a.ysb = ysb; a.ysl = ysl;
+  a.xsb = xsb; a.xsl = xsl; a.dsb = dsb; a.dsl = dsl; a.bsb = bsb; a.bsl = bsl; a.bsg = bsg;
+  a.csb = csb; a.csl = csl; a.csg = csg; a.ysb = ysb; a.ysl = ysl;
   a.softplus = dt_softplus; a.group_map = group_map; a.dt_min = dt_min; a.dt_max = dt_max;
   { const char* e = getenv("TV_MARCH_DBG"); a.dbg = e ? atoi(e) : 0; }
   dim3 grid(nheads * a.nslices, batch);

@@ -7,13 +7,13 @@ int tv_ssd_generic_launch(const void* x, const void* dt, const void* A, const vo
                           const void* init_state, void* y, void* final_state, void* total_decay,
                           int batch, int seqlen, int nheads, int headdim, int ngroups, int dstate,
                           int64_t xsb, int64_t xsl, int64_t dsb, int64_t dsl, int64_t bsb,
-                          int64_t bsl, int64_t csb, int64_t csl, int64_t ysb, int64_t ysl,
+                          int64_t bsl, int64_t bsg, int64_t csb, int64_t csl, int64_t csg, int64_t ysb, int64_t ysl,
                           int dtype, int dt_softplus, float dt_min, float dt_max, int group_map,
                           hipStream_t st);
 
 // ssd_march.hip
 bool tv_ssd_march_supported(int seqlen, int nheads, int headdim, int ngroups, int dstate,
-                            int dtype, int64_t xsl, int64_t bsl, int64_t csl, int64_t ysl,
+                            int dtype, int64_t xsl, int64_t bsl, int64_t bsg, int64_t csl, int64_t csg, int64_t ysl,
                             const void* x, const void* Bm, const void* Cm, const void* y);
 size_t tv_ssd_march_workspace_bytes(int batch, int seqlen, int nheads, int headdim, int ngroups,
                                     int dstate);
@@ -22,7 +22,7 @@ int tv_ssd_march_launch(const void* x, const void* dt, const void* A, const void
                         const void* init_state, void* y, void* final_state, void* total_decay,
                         int batch, int seqlen, int nheads, int headdim, int ngroups, int dstate,
                         int64_t xsb, int64_t xsl, int64_t dsb, int64_t dsl, int64_t bsb,
-                        int64_t bsl, int64_t csb, int64_t csl, int64_t ysb, int64_t ysl,
+                        int64_t bsl, int64_t bsg, int64_t csb, int64_t csl, int64_t csg, int64_t ysb, int64_t ysl,
                         int dtype, int dt_softplus, float dt_min, float dt_max, int group_map,
                         void* workspace, size_t workspace_bytes, hipStream_t st);
 
@@ -42,8 +42,9 @@ extern "C" int tv_ssd_scan_fwd(const void* x, const void* dt, const void* A, con
                                void* total_decay, int batch, int seqlen, int nheads, int headdim,
                                int ngroups, int dstate, int64_t x_stride_b, int64_t x_stride_l,
                                int64_t dt_stride_b, int64_t dt_stride_l, int64_t b_stride_b,
-                               int64_t b_stride_l, int64_t c_stride_b, int64_t c_stride_l,
-                               int64_t y_stride_b, int64_t y_stride_l, int dtype, int dt_softplus,
+                               int64_t b_stride_l, int64_t b_stride_g, int64_t c_stride_b,
+                               int64_t c_stride_l, int64_t c_stride_g, int64_t y_stride_b,
+                               int64_t y_stride_l, int dtype, int dt_softplus,
                                float dt_min, float dt_max, int group_map, void* workspace,
                                size_t workspace_bytes, void* stream) {
   TV_CHECK_ARG(x && dt && A && Bm && Cm && y, "ssd_scan: null pointer");
@@ -66,20 +67,20 @@ extern "C" int tv_ssd_scan_fwd(const void* x, const void* dt, const void* A, con
   bool march = g_ssd_impl != 1 && dt_stride_l % 2 == 0 && dt_stride_b % 2 == 0 &&
                (((uintptr_t)dt) & 3) == 0 &&
                tv_ssd_march_supported(seqlen, nheads, headdim, ngroups, dstate, dtype, x_stride_l,
-                                      b_stride_l, c_stride_l, y_stride_l, x, Bm, Cm, y);
+                                      b_stride_l, b_stride_g, c_stride_l, c_stride_g, y_stride_l, x, Bm, Cm, y);
   if (g_ssd_impl == 2 && !march)
     TV_UNSUPPORTED("ssd_scan: MFMA march kernel forced but shape/dtype unsupported");
   if (march) {
     return tv_ssd_march_launch(x, dt, A, Bm, Cm, D, dt_bias, init_state, y, final_state,
                                total_decay, batch, seqlen, nheads, headdim, ngroups, dstate,
                                x_stride_b, x_stride_l, dt_stride_b, dt_stride_l, b_stride_b,
-                               b_stride_l, c_stride_b, c_stride_l, y_stride_b, y_stride_l, dtype,
+                               b_stride_l, b_stride_g, c_stride_b, c_stride_l, c_stride_g, y_stride_b, y_stride_l, dtype,
                                dt_softplus, dt_min, dt_max, group_map, workspace, workspace_bytes,
                                st);
   }
   return tv_ssd_generic_launch(x, dt, A, Bm, Cm, D, dt_bias, init_state, y, final_state,
                                total_decay, batch, seqlen, nheads, headdim, ngroups, dstate,
                                x_stride_b, x_stride_l, dt_stride_b, dt_stride_l, b_stride_b,
-                               b_stride_l, c_stride_b, c_stride_l, y_stride_b, y_stride_l, dtype,
+                               b_stride_l, b_stride_g, c_stride_b, c_stride_l, c_stride_g, y_stride_b, y_stride_l, dtype,
                                dt_softplus, dt_min, dt_max, group_map, st);
 }

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--tokens", type=int, default=163940)
     ap.add_argument("--ops", default="scan,conv,gnorm,rmsnorm,attn,patch,gather")
     ap.add_argument("--impl", type=int, default=0)
+    ap.add_argument("--token-major", action="store_true", help="B/C as column slices of the conv rows")
     a = ap.parse_args()
     L = a.tokens
     dev = "cuda"
@@ -47,13 +48,20 @@ def main():
         print(f"conv1d      {ms*1e3:9.1f} us  {by/ms/1e6:8.1f} GB/s  ({by/ms/1e6/8000:.1%} of 8 TB/s)")
     if "scan" in ops:
         K.ssd_scan_set_impl(a.impl)
-        conv = K.causal_conv1d_fn(xBC.transpose(1, 2), w, b, activation="silu").transpose(1, 2)
-        x, Bm, Cm = conv.split([d_in, G * N, G * N], dim=-1)
+        if a.token_major:
+            conv = K.causal_conv1d_fn(xBC.transpose(1, 2), w, b, activation="silu").transpose(1, 2)
+            x, Bm, Cm = conv.split([d_in, G * N, G * N], dim=-1)
+            Bm, Cm = Bm.view(1, L, G, N), Cm.view(1, L, G, N)
+        else:
+            x, Bm, Cm = K.causal_conv1d_xbc(xBC, w, b, d_in, G, N)
+            ms = timeit(lambda: K.causal_conv1d_xbc(xBC, w, b, d_in, G, N))
+            by = L * 2 * 2 * conv_dim
+            print(f"conv1d xbc  {ms*1e3:9.1f} us  {by/ms/1e6:8.1f} GB/s  ({by/ms/1e6/8000:.1%} of 8 TB/s)")
         A = -(torch.rand(H, device=dev, generator=g) * 15 + 1)
         D = torch.ones(H, device=dev)
         dtb = torch.full((H,), -3.0, device=dev)
-        fn = lambda: K.mamba_chunk_scan_combined(x.view(1, L, H, P), dt, A, Bm.view(1, L, G, N),
-                                                 Cm.view(1, L, G, N), chunk_size=128, D=D, dt_bias=dtb,
+        fn = lambda: K.mamba_chunk_scan_combined(x.view(1, L, H, P), dt, A, Bm, Cm,
+                                                 chunk_size=128, D=D, dt_bias=dtb,
                                                  dt_softplus=True, return_final_states=True)
         ms = timeit(fn, iters=5 if a.impl == 1 else 10)
         by = L * (2 * d_in * 2 + 2 * H + 4 * G * N)

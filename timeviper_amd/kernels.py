@@ -95,6 +95,32 @@ def causal_conv1d_fn(x, weight, bias=None, seq_idx=None, initial_states=None,
     return y.transpose(1, 2)
 
 
+def causal_conv1d_xbc(xBC, weight, bias, d_inner: int, ngroups: int, dstate: int,
+                      activation="silu", halo=None):
+    """Mamba-2 mixer variant of causal_conv1d_fn + the [x | B | C] split of
+    modeling_nano.py:628-636 in one pass.  xBC (B, L, d_inner + 2*G*N) (any row stride).
+    Returns x (B, L, d_inner) and B, C as (B, L, G, N) VIEWS of group-major (B, G, L, N)
+    storage — the layout the scan kernel streams best."""
+    _gpu(xBC, weight, bias, halo)
+    Bsz, L, Cc = xBC.shape
+    assert Cc == d_inner + 2 * ngroups * dstate
+    if xBC.stride(2) != 1:
+        xBC = xBC.contiguous()
+    K = weight.shape[-1]
+    w = weight.reshape(Cc, K).to(xBC.dtype).contiguous()
+    b = None if bias is None else bias.to(xBC.dtype).contiguous()
+    if halo is not None:
+        halo = halo.to(xBC.dtype).contiguous()
+    yx = torch.empty((Bsz, L, d_inner), dtype=xBC.dtype, device=xBC.device)
+    yb = torch.empty((Bsz, ngroups, L, dstate), dtype=xBC.dtype, device=xBC.device)
+    yc = torch.empty((Bsz, ngroups, L, dstate), dtype=xBC.dtype, device=xBC.device)
+    check(_capi.lib().tv_causal_conv1d_xbc_fwd(
+        _p(xBC), _p(w), _p(b), _p(halo), _p(yx), _p(yb), _p(yc), Bsz, L, d_inner, ngroups, dstate,
+        K, xBC.stride(0), xBC.stride(1), _dt(xBC), int(activation in ("silu", "swish")), _stream()),
+        "tv_causal_conv1d_xbc_fwd")
+    return yx, yb.transpose(1, 2), yc.transpose(1, 2)
+
+
 def causal_conv1d_update(x, conv_state, weight, bias=None, activation=None):
     """x (B, C); conv_state (B, C, K) updated in place; returns (B, C)."""
     _gpu(x, conv_state, weight, bias)
@@ -197,8 +223,13 @@ def mamba_chunk_scan_combined(x, dt, A, B, C, chunk_size=None, D=None, z=None, d
         C = C.to(x.dtype)
     x, xsb, xsl = _row_view(x, H * P)
     dt, dsb, dsl = _row_view(dt, H)
-    B, bsb, bsl = _row_view(B, G * N)
-    C, csb, csl = _row_view(C, G * N)
+    # B/C: any (B, L, G, N) view with contiguous N (token-major rows or group-major storage)
+    if B.stride(3) != 1:
+        B = B.contiguous()
+    if C.stride(3) != 1:
+        C = C.contiguous()
+    bsb, bsl, bsg = B.stride(0), B.stride(1), B.stride(2)
+    csb, csl, csg = C.stride(0), C.stride(1), C.stride(2)
     f32 = lambda t: None if t is None else t.to(torch.float32).contiguous()
     A, D, dt_bias, initial_states = f32(A), f32(D), f32(dt_bias), f32(initial_states)
     y = torch.empty((Bsz, L, H, P), dtype=x.dtype, device=x.device)
@@ -211,7 +242,7 @@ def mamba_chunk_scan_combined(x, dt, A, B, C, chunk_size=None, D=None, z=None, d
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
     check(lib.tv_ssd_scan_fwd(
         _p(x), _p(dt), _p(A), _p(B), _p(C), _p(D), _p(dt_bias), _p(initial_states), _p(y),
-        _p(final), _p(decay), Bsz, L, H, P, G, N, xsb, xsl, dsb, dsl, bsb, bsl, csb, csl,
+        _p(final), _p(decay), Bsz, L, H, P, G, N, xsb, xsl, dsb, dsl, bsb, bsl, bsg, csb, csl, csg,
         y.stride(0), y.stride(1), _dt(x), int(bool(dt_softplus)), float(dt_limit[0]),
         float(min(dt_limit[1], 3.0e38)), {"block": 0, "tile": 1}[group_map], _p(ws), ws_bytes,
         _stream()), "tv_ssd_scan_fwd")

@@ -286,15 +286,16 @@ class NemotronHMamba2Mixer(nn.Module):
             xt = xBC.transpose(1, 2)
             cs = F.pad(xt, (Kw - seq_len, 0)) if seq_len < Kw else xt[..., -Kw:]
             cache_params.update_conv_state(self.layer_idx, cs.contiguous(), cache_init=True)
-        xBC_conv = K.causal_conv1d_fn(x=xBC.transpose(1, 2), weight=w, bias=self.conv1d.bias,
-                                      activation=self.activation, halo=conv_halo).transpose(1, 2)
-        x, Bm, Cm = torch.split(xBC_conv, [d_in, gts, gts], dim=-1)
+        # causal_conv1d_fn (:619-624) + the x|B|C split (:628-636) in one pass; B and C come
+        # back as (B, L, G, N) views of group-major storage
+        x, Bm, Cm = K.causal_conv1d_xbc(xBC, w, self.conv1d.bias, d_in, self.n_groups,
+                                        self.ssm_state_size, activation=self.activation,
+                                        halo=conv_halo)
         dt_limit = {} if self.time_step_limit == (0.0, float("inf")) \
             else {"dt_limit": self.time_step_limit}
         res = K.mamba_chunk_scan_combined(
-            x.view(batch_size, seq_len, -1, self.head_dim), dt, self._neg_A(),
-            Bm.view(batch_size, seq_len, self.n_groups, -1),
-            Cm.view(batch_size, seq_len, self.n_groups, -1), chunk_size=self.chunk_size, D=self.D,
+            x.view(batch_size, seq_len, -1, self.head_dim), dt, self._neg_A(), Bm, Cm,
+            chunk_size=self.chunk_size, D=self.D,
             z=None, seq_idx=None, return_final_states=True, dt_bias=self.dt_bias, dt_softplus=True,
             initial_states=initial_states, group_map=self.group_map,
             return_total_decay=return_shard_state, **dt_limit)
