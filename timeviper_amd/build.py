@@ -22,6 +22,8 @@ ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off",
          "-Wno-unused-result", "-DNDEBUG"]
+if os.environ.get("TV_MARCH_ABLATE"):   # dev only: compile the scan kernel's ablation switches in
+    FLAGS.append("-DTV_MARCH_ABLATE")
 
 
 def _sources():
