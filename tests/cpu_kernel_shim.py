@@ -1,0 +1,97 @@
+"""TEST INFRASTRUCTURE: oracle-backed stand-ins for `timeviper_amd.kernels`, so that the
+host-side logic that sits ABOVE the C ABI (model mirror, sequence-parallel runner) can be
+exercised on a CPU-only box (gloo, world_size 2).  Never imported by the product."""
+import contextlib
+import math
+
+import torch
+
+from oracle import ops as R
+
+
+def _conv_xbc(xBC, weight, bias, d_inner, ngroups, dstate, activation="silu", halo=None):
+    y = R.causal_conv1d_ref(xBC.float(), weight.float().reshape(xBC.shape[-1], -1),
+                            None if bias is None else bias.float(), activation,
+                            None if halo is None else halo.float()).to(xBC.dtype)
+    B, L, _ = xBC.shape
+    x, Bm, Cm = y.split([d_inner, ngroups * dstate, ngroups * dstate], dim=-1)
+    return x.contiguous(), Bm.reshape(B, L, ngroups, dstate), Cm.reshape(B, L, ngroups, dstate)
+
+
+def _conv_fn(x, weight, bias=None, activation=None, halo=None, **kw):
+    y = R.causal_conv1d_ref(x.transpose(1, 2).float(), weight.float().reshape(x.shape[1], -1),
+                            None if bias is None else bias.float(), activation,
+                            None if halo is None else halo.float())
+    return y.to(x.dtype).transpose(1, 2)
+
+
+def _scan(x, dt, A, B, C, chunk_size=None, D=None, z=None, dt_bias=None, initial_states=None,
+          dt_softplus=False, dt_limit=(0.0, float("inf")), return_final_states=False,
+          group_map="block", return_total_decay=False, **kw):
+    y, fin, dec = R.ssd_recurrence_ref(x, dt, A, B, C, D=D, dt_bias=dt_bias, dt_softplus=dt_softplus,
+                                       dt_limit=dt_limit, initial_states=initial_states,
+                                       group_map=group_map)
+    out = (y.to(x.dtype),)
+    if return_final_states:
+        out += (fin.float(),)
+    if return_total_decay:
+        out += (dec.float(),)
+    return out[0] if len(out) == 1 else out
+
+
+def _rms(x, weight, eps, residual=None, return_sum=False):
+    s = x if residual is None else (x + residual)
+    y = R.rmsnorm_ref(s, weight, eps).to(x.dtype)
+    return (y, s) if return_sum else y
+
+
+def _gated(x, weight, bias=None, z=None, eps=1e-6, group_size=None, norm_before_gate=True, **kw):
+    return R.rmsnorm_gated_ref(x, weight, z, eps, group_size).to(x.dtype)
+
+
+def _fa(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False, return_lse=False):
+    o, lse = R.attention_ref(q, k, v, causal, softmax_scale)
+    return (o.to(q.dtype), lse) if return_lse else o.to(q.dtype)
+
+
+def _fa_fwd(q, k, v, attention_mask=None, query_length=None, is_causal=True, **kw):
+    return _fa(q, k, v, causal=is_causal)
+
+
+def _rank(q_row, k, n_keys, vis_start, n_vis, scale=None):
+    H, D = q_row.shape
+    rep = H // k.shape[1]
+    dt = k.dtype
+    logit = torch.einsum("hd,khd->hk", q_row.float(), k[:n_keys].float().repeat_interleave(rep, 1)).to(dt)
+    logit = (logit.float() / math.sqrt(D)).to(dt).float()
+    p = torch.softmax(logit, dim=-1).to(dt).float()
+    return p.mean(0).to(dt).float()[vis_start:vis_start + n_vis]
+
+
+def _dropped(keep_sorted, start, n):
+    allidx = torch.arange(start, start + n)
+    return allidx[~torch.isin(allidx, keep_sorted)]
+
+
+@contextlib.contextmanager
+def cpu_kernels():
+    from timeviper_amd import kernels as K
+    patches = {
+        "causal_conv1d_xbc": _conv_xbc, "causal_conv1d_fn": _conv_fn,
+        "mamba_chunk_scan_combined": _scan, "rms_norm": _rms, "rmsnorm_fn": _gated,
+        "flash_attn_func": _fa, "_flash_attention_forward": _fa_fwd,
+        "gather_rows": lambda src, idx: src.reshape(-1, src.shape[-1])[idx],
+        "uniform_keep_indices": lambda n, keep, offset=0, device="cpu":
+            R.uniform_keep_indices_ref(n, keep) + offset,
+        "dropped_indices": _dropped, "attn_rank_scores": _rank,
+        "patch_embed": lambda pix, w, b=None, pos=None, patch=None:
+            R.patch_embed_ref(pix, w, b, pos).to(pix.dtype),
+    }
+    saved = {k: getattr(K, k) for k in patches}
+    for k, v in patches.items():
+        setattr(K, k, v)
+    try:
+        yield
+    finally:
+        for k, v in saved.items():
+            setattr(K, k, v)

@@ -1,0 +1,97 @@
+"""Sequence-parallel runner (timeviper_amd.distributed) with world_size 2 over gloo on the
+CPU: the collectives, shard bookkeeping, state chaining, KV gathering and sharded pdrop
+must reproduce the single-process forward.  Kernels are replaced by oracle-backed shims
+(tests/cpu_kernel_shim.py) — this exercises the host logic above the C ABI only."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from cpu_kernel_shim import cpu_kernels
+from timeviper_amd.distributed import chain_states, split_frames
+
+PD = "uni_2_0.75-attn_3_0.5-attn_6_0.25"
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def build(merge):
+    from timeviper_amd.model import HybridTimeViperVLM
+    from timeviper_amd.model.llm import GenericLLMBackbone, NemotronHConfig
+    from timeviper_amd.model.vit import TimmViTBackbone
+    torch.manual_seed(0)
+    cfg = NemotronHConfig(vocab_size=128, hidden_size=64, intermediate_size=96, num_hidden_layers=8,
+                          hybrid_override_pattern="M-M*M-*M", num_attention_heads=4, head_dim=16,
+                          num_key_value_heads=2, ssm_state_size=16, mamba_num_heads=8,
+                          mamba_n_groups=2, mamba_head_dim=8, mamba_chunk_size=16)
+    vb = TimmViTBackbone("siglip-vit-b16-224px", depth_override=2, default_image_size=96)
+    llm = GenericLLMBackbone("nanov2-9b", config=cfg, merge_module=merge, use_pdrop=True, pdrop_type=PD)
+    vlm = HybridTimeViperVLM("t", vb, llm, arch_specifier="tome_mlp-16").eval()
+    with torch.no_grad():
+        for n, p in vlm.named_parameters():
+            if n.endswith("alpha"):
+                p.fill_(0.7)
+            elif "q_proj" in n or "k_proj" in n:
+                p.mul_(20.0)
+    return vlm
+
+
+def worker(rank, world, port, merge, T, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    try:
+        from timeviper_amd.distributed import SequenceParallelTimeViper
+        vlm = build(merge)
+        tok = vlm.default_token_id
+        g = torch.Generator().manual_seed(1)
+        ids = torch.tensor([[5, 6, 7] + [tok] * T + [8, 9, 10, 11, 12]])
+        pix = torch.randn(T, 3, 96, 96, generator=g)
+        with cpu_kernels(), torch.no_grad():
+            runner = SequenceParallelTimeViper(vlm, rank, world)
+            lo, hi = runner.frame_range(T)
+            logits = runner.forward(ids, pix[lo:hi], T)
+            trace = [t.clone() for t in runner.trace]
+            if rank == 0:
+                ref = vlm(input_ids=ids, pixel_values_videos=pix).logits
+                ref_trace = [t["kept"] for t in vlm.llm_backbone.llm.backbone.last_pdrop_trace]
+                q.put((logits, ref, trace, ref_trace))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("merge", ["no_merge", "CrossAttention"])
+def test_sequence_parallel_matches_single_process(merge):
+    world, T = 2, 5
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = free_port()
+    procs = [ctx.Process(target=worker, args=(r, world, port, merge, T, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    logits, ref, trace, ref_trace = q.get()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert all(torch.equal(a, b) for a, b in zip(trace, ref_trace)), "kept indices differ"
+    assert torch.allclose(logits, ref, rtol=1e-4, atol=1e-5), (logits - ref).abs().max()
+
+
+def test_chain_states_and_split():
+    assert split_frames(10, 4) == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    g = torch.Generator().manual_seed(0)
+    S = torch.randn(3, 1, 2, 4, 5, generator=g)
+    d = -torch.rand(3, 1, 2, generator=g)
+    inc2 = chain_states(S, d, 2)
+    assert torch.allclose(inc2, torch.exp(d[1])[..., None, None] * S[0] + S[1])
+    assert torch.equal(chain_states(S, d, 0), torch.zeros_like(S[0]))

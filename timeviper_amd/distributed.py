@@ -1,0 +1,268 @@
+"""Sequence-sharded TimeViper forward over the GPUs of one node.
+
+The reference has no collective anywhere (multi-GPU is delegated to DeepSpeed / vLLM,
+SURVEY §2a); this is new design for the north star's "frame/token sequence shards across
+the 8 GPUs with RCCL all-gather of the SSM states over xGMI".  One process per GPU,
+`torch.distributed` backend "nccl" (= RCCL on ROCm); every rank holds the full weights.
+
+  * ViT + ToMe + projector: frames are independent -> rank r encodes its contiguous frame
+    range, which IS its token shard (16 tokens per frame); the text before the video goes
+    to rank 0's shard, the text after it to the last rank's.  No collective.
+  * RMSNorm / MLP / all GEMMs: row-local, no communication.
+  * Mamba-2 mixer: the causal conv needs the K-1 = 3 pre-conv rows of the previous shard
+    (74 KB halo); the scan runs on the shard from a zero state, the ranks all-gather their
+    final states S_r (H,P,N fp32 = 5.2 MB) and total log-decays L_r (H), every rank chains
+      In_0 = 0,  In_r = exp(L_{r-1}) In_{r-1} + S_{r-1}
+    locally and ranks > 0 rescan their shard from In_r (the scan is ~1 % of a step).
+  * attention (4 layers): K/V all-gather (variable shard lengths), causal attention of the
+    local queries against the keys up to the shard's end (bottom-right aligned mask).
+  * TransV / pdrop: "uni" indices are computed identically on every rank; "attn" scores
+    need one softmax over all keys -> per-head (max, sum-exp) partials are all-gathered,
+    the per-token scores are all-gathered, every rank runs the same stable top-k and keeps
+    its own rows; the dropped rows' K/V for the TransV cross-attention are all-gathered to
+    the rank that owns the trailing text.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+from . import kernels as K
+
+
+# ------------------------------------------------------------------ collectives
+def all_gather_varlen(t: torch.Tensor, group=None) -> List[torch.Tensor]:
+    """all-gather of tensors that differ in dim 0 (padded to the longest)."""
+    world = dist.get_world_size(group)
+    n = torch.tensor([t.shape[0]], device=t.device, dtype=torch.int64)
+    ns = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(ns, n, group=group)
+    ns = [int(v) for v in ns]
+    mx = max(ns)
+    pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    pad[: t.shape[0]] = t
+    out = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(out, pad, group=group)
+    return [o[:k] for o, k in zip(out, ns)]
+
+
+def chain_states(states: torch.Tensor, decays: torch.Tensor, rank: int) -> torch.Tensor:
+    """Incoming SSM state of shard `rank` from the per-shard (zero-init) final states
+    (R,B,H,P,N) and total log-decays (R,B,H):  In_r = exp(L_{r-1}) In_{r-1} + S_{r-1}."""
+    inc = torch.zeros_like(states[0])
+    for j in range(rank):
+        inc = inc * torch.exp(decays[j])[..., None, None] + states[j]
+    return inc
+
+
+def split_frames(n_frames: int, world: int) -> List[Tuple[int, int]]:
+    base, rem = divmod(n_frames, world)
+    out, lo = [], 0
+    for r in range(world):
+        hi = lo + base + (1 if r < rem else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+class SequenceParallelTimeViper:
+    def __init__(self, vlm, rank: int, world: int, group=None):
+        self.vlm, self.rank, self.world, self.group = vlm, rank, world, group
+        self.llm = vlm.llm_backbone.llm
+        self.bb = self.llm.backbone
+        self.cfg = self.llm.config
+
+    # ---------------------------------------------------------------- layout
+    def frame_range(self, n_frames: int) -> Tuple[int, int]:
+        return split_frames(n_frames, self.world)[self.rank]
+
+    def shard_layout(self, input_ids: torch.Tensor, n_frames: int, tok_per_frame: int):
+        """Global token ranges [start, end) of every rank's shard, for a prompt of the form
+        [text_before | <image> x T | text_after] (the benchmark / evaluate.py layout)."""
+        ids = input_ids[0]
+        is_img = ids == self.vlm.default_token_id
+        pos = is_img.nonzero().flatten()
+        first, last = int(pos[0]), int(pos[-1])
+        assert last - first + 1 == n_frames == int(is_img.sum()), "one contiguous <image> run expected"
+        n_before, n_after = first, ids.numel() - last - 1
+        bounds = []
+        for r, (lo, hi) in enumerate(split_frames(n_frames, self.world)):
+            s = n_before + lo * tok_per_frame if r > 0 else 0
+            e = n_before + hi * tok_per_frame + (n_after if r == self.world - 1 else 0)
+            bounds.append((s, e))
+        return bounds, n_before, n_after
+
+    # ---------------------------------------------------------------- mixers
+    def _mamba(self, mixer, normed):
+        Bsz, L, _ = normed.shape
+        proj = mixer.in_proj(normed)
+        d_in, gts = mixer.intermediate_size, mixer.n_groups * mixer.ssm_state_size
+        gate, xBC, dt = proj.split([d_in, mixer.conv_dim, mixer.num_heads], dim=-1)
+        Kw = mixer.conv_kernel_size
+        # halo: the K-1 pre-conv rows that precede this shard
+        tail = xBC[:, -(Kw - 1):].contiguous()
+        tails = [torch.empty_like(tail) for _ in range(self.world)]
+        dist.all_gather(tails, tail, group=self.group)
+        halo = tails[self.rank - 1] if self.rank > 0 else None
+        x, Bm, Cm = K.causal_conv1d_xbc(xBC, mixer.conv1d.weight.squeeze(1), mixer.conv1d.bias,
+                                        d_in, mixer.n_groups, mixer.ssm_state_size,
+                                        activation=mixer.activation, halo=halo)
+        xh = x.view(Bsz, L, mixer.num_heads, mixer.head_dim)
+        kw = dict(chunk_size=mixer.chunk_size, D=mixer.D, dt_bias=mixer.dt_bias, dt_softplus=True,
+                  return_final_states=True, group_map=mixer.group_map)
+        if mixer.time_step_limit != (0.0, float("inf")):
+            kw["dt_limit"] = mixer.time_step_limit
+        A = mixer._neg_A()
+        y, S, dec = K.mamba_chunk_scan_combined(xh, dt, A, Bm, Cm, return_total_decay=True, **kw)
+        S_all = [torch.empty_like(S) for _ in range(self.world)]
+        d_all = [torch.empty_like(dec) for _ in range(self.world)]
+        dist.all_gather(S_all, S, group=self.group)
+        dist.all_gather(d_all, dec, group=self.group)
+        if self.rank > 0:
+            inc = chain_states(torch.stack(S_all), torch.stack(d_all), self.rank)
+            y, _ = K.mamba_chunk_scan_combined(xh, dt, A, Bm, Cm, initial_states=inc, **kw)
+        y = mixer.norm(y.view(Bsz, L, d_in), gate)
+        return mixer.out_proj(y)
+
+    def _attention(self, attn, normed):
+        Bsz, L, _ = normed.shape
+        q = attn.q_proj(normed).view(Bsz, L, attn.num_heads, attn.head_dim)
+        k = attn.k_proj(normed).view(L, attn.num_key_value_heads * attn.head_dim)
+        v = attn.v_proj(normed).view(L, attn.num_key_value_heads * attn.head_dim)
+        ks = all_gather_varlen(k, self.group)
+        vs = all_gather_varlen(v, self.group)
+        kf = torch.cat(ks[: self.rank + 1]).view(1, -1, attn.num_key_value_heads, attn.head_dim)
+        vf = torch.cat(vs[: self.rank + 1]).view(1, -1, attn.num_key_value_heads, attn.head_dim)
+        o = K.flash_attn_func(q, kf, vf, causal=True)      # bottom-right aligned: Lk >= Lq
+        return attn.o_proj(o.reshape(Bsz, L, attn.num_heads * attn.head_dim))
+
+    # ---------------------------------------------------------------- pdrop
+    def _pdrop(self, stage: int, layer_idx: int, hidden, start: int, meta):
+        """Sharded pdrop_no_pack (eval, batch 1).  `start` = global index of hidden[0, 0].
+        Returns the new shard and its new global start."""
+        bb = self.bb
+        nv, vis0, txt_len = meta["num_vision_tokens"], meta["vision_index"], meta["text_prompt_len"]
+        image_tokens = int(nv * bb.pdrop_ratios[stage])
+        keep = int(nv * bb.pdrop_ratios[stage + 1])
+        ctype = bb.pdrop_compress_types[stage]
+        feats = hidden[0]
+        L = feats.shape[0]
+        dev = feats.device
+        vis_end = vis0 + image_tokens
+        if "attn" in ctype:
+            sa = bb.layers[layer_idx].mixer
+            row = txt_len + image_tokens - 1                      # global index of the query token
+            # the query row lives on the last rank: broadcast its projected queries
+            q_row = torch.empty((sa.num_heads, sa.head_dim), dtype=feats.dtype, device=dev)
+            if self.rank == self.world - 1:
+                q_row = sa.q_proj(feats[row - start: row - start + 1]).view(sa.num_heads, sa.head_dim).contiguous()
+            dist.broadcast(q_row, src=self.world - 1, group=self.group)
+            n_local = max(0, min(L, row + 1 - start))             # local keys that take part
+            k_loc = sa.k_proj(feats[:n_local]).view(n_local, sa.num_key_value_heads, sa.head_dim)
+            rep = sa.num_heads // sa.num_key_value_heads
+            # logits with the reference's roundings (q.K^T and /sqrt(d) in the activation dtype)
+            logit = torch.einsum("hd,khd->hk", q_row.float().view(sa.num_heads, sa.head_dim),
+                                 k_loc.float().repeat_interleave(rep, dim=1)).to(feats.dtype)
+            logit = (logit.float() / math.sqrt(sa.head_dim)).to(feats.dtype).float()
+            m_loc = logit.max(dim=1).values if n_local else torch.full((sa.num_heads,), -float("inf"), device=dev)
+            ms = [torch.empty_like(m_loc) for _ in range(self.world)]
+            dist.all_gather(ms, m_loc, group=self.group)
+            m = torch.stack(ms).max(dim=0).values
+            s_loc = torch.exp(logit - m[:, None]).sum(dim=1)
+            ss = [torch.empty_like(s_loc) for _ in range(self.world)]
+            dist.all_gather(ss, s_loc, group=self.group)
+            ssum = torch.stack(ss).sum(dim=0)
+            p = (torch.exp(logit - m[:, None]) / ssum[:, None]).to(feats.dtype).float()
+            sc = p.mean(dim=0).to(feats.dtype).float()            # (n_local,)
+            lo = max(vis0 - start, 0)
+            hi = max(min(vis_end - start, n_local), lo)
+            scores = torch.cat(all_gather_varlen(sc[lo:hi].contiguous(), self.group))
+            order = torch.sort(scores, descending=True, stable=True).indices
+            top = (order[:keep] + vis0).sort().values
+        elif "uni" in ctype:
+            top = K.uniform_keep_indices(image_tokens, keep, offset=vis0, device=dev)
+        else:
+            raise NotImplementedError(ctype)
+        # rows of this shard that survive: [pre-vision text | kept vision | trailing text]
+        end = start + L
+        g = torch.arange(start, end, device=dev)
+        mine = top[(top >= start) & (top < end)]
+        local_idx = torch.cat([g[g < vis0], mine, g[g >= vis_end]]) - start
+        new = K.gather_rows(feats, local_idx)
+        # TransV merge: trailing text (last rank) attends to ALL dropped vision rows
+        if bb.merge_modules is not None and bb.merge_module_names[stage] != "none":
+            is_vis = (g >= vis0) & (g < vis_end)
+            kept_here = torch.zeros(L, dtype=torch.bool, device=dev)
+            kept_here[mine - start] = True
+            dropped_local = feats[is_vis & ~kept_here]
+            mod = bb.merge_modules[stage]
+            kd = mod.k_proj(dropped_local)
+            vd = mod.v_proj(dropped_local)
+            kd = torch.cat(all_gather_varlen(kd, self.group))
+            vd = torch.cat(all_gather_varlen(vd, self.group))
+            if self.rank == self.world - 1:
+                n_text = int((g >= vis_end).sum())
+                text = new[new.shape[0] - n_text:]
+                qd = mod.q_proj(text).view(1, n_text, mod.num_heads, mod.head_dim)
+                o = K.flash_attn_func(qd, kd.view(1, -1, mod.num_key_value_heads, mod.head_dim),
+                                      vd.view(1, -1, mod.num_key_value_heads, mod.head_dim), causal=False)
+                merged = mod.o_proj(o.reshape(n_text, mod.num_heads * mod.head_dim))
+                new[new.shape[0] - n_text:] = text + bb.alpha[stage].tanh() * merged
+        # new global start = number of surviving rows on earlier ranks
+        n_new = torch.tensor([new.shape[0]], device=dev, dtype=torch.int64)
+        ns = [torch.zeros_like(n_new) for _ in range(self.world)]
+        dist.all_gather(ns, n_new, group=self.group)
+        new_start = int(sum(int(v) for v in ns[: self.rank]))
+        return new.unsqueeze(0), new_start, top
+
+    # ---------------------------------------------------------------- forward
+    @torch.no_grad()
+    def forward(self, input_ids: torch.Tensor, pixel_values_local: torch.Tensor, n_frames: int,
+                visual_embeddings_local: Optional[torch.Tensor] = None):
+        """input_ids: the FULL prompt (identical on every rank); pixel_values_local: this
+        rank's frames (frame_range).  Returns the last-token logits on every rank."""
+        vlm, bb = self.vlm, self.bb
+        vis = visual_embeddings_local if visual_embeddings_local is not None \
+            else vlm.encode_vision(pixel_values_local, is_video=True)
+        tpf = vis.shape[1]
+        bounds, n_before, n_after = self.shard_layout(input_ids, n_frames, tpf)
+        start, end = bounds[self.rank]
+        embed = vlm.llm_backbone.embed_input_ids
+        parts = []
+        if self.rank == 0 and n_before:
+            parts.append(embed(input_ids[:, :n_before]))
+        parts.append(vis.reshape(1, -1, vis.shape[-1]).to(vlm.dtype_of(embed)))
+        if self.rank == self.world - 1 and n_after:
+            parts.append(embed(input_ids[:, input_ids.shape[1] - n_after:]))
+        hidden = torch.cat(parts, dim=1)
+        assert hidden.shape[1] == end - start
+        meta = {"num_vision_tokens": n_frames * tpf, "vision_index": n_before,
+                "text_prompt_len": n_before + n_after}
+        self.trace = []
+        delta = None
+        for i, block in enumerate(bb.layers):
+            if bb.use_pdrop and i in bb.pdrop_layers:
+                if delta is not None:
+                    hidden, delta = hidden + delta, None
+                stage = bb.pdrop_layers.index(i)
+                hidden, start, top = self._pdrop(stage, i, hidden, start, meta)
+                self.trace.append(top)
+            if delta is None:
+                normed = block.norm(hidden)
+            else:
+                normed, hidden = block.norm(hidden, residual=delta, return_sum=True)
+            if block.block_type == "mamba":
+                delta = self._mamba(block.mixer, normed)
+            elif block.block_type == "attention":
+                delta = self._attention(block.mixer, normed)
+            else:
+                delta = block.mixer(normed)
+        hidden = bb.norm_f(hidden, residual=delta) if delta is not None else bb.norm_f(hidden)
+        logits = torch.empty((1, 1, self.cfg.vocab_size), dtype=torch.float32, device=hidden.device)
+        if self.rank == self.world - 1:
+            logits = self.llm.lm_head(hidden[:, -1:]).float()
+        dist.broadcast(logits, src=self.world - 1, group=self.group)
+        return logits
