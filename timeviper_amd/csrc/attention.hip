@@ -1,9 +1,10 @@
 // A1 / T3 / ViT: fused softmax attention forward on CDNA4 MFMA tiles.
 //
-// Structure (wave64, v_mfma_f32_32x32x16): a workgroup of 4 waves owns 128 query
-// rows of one (batch, q-head); each wave keeps its 32 query rows as MFMA B
-// fragments in registers for the whole kernel.  K/V tiles of 64 keys are staged
-// row-major in LDS and shared by the 4 waves.  The score tile is computed
+// Structure (wave64, v_mfma_f32_32x32x16): a workgroup of 8 waves owns 256 query
+// rows of one (batch, q-head) (4 waves / 128 rows for short queries); each wave keeps
+// its 32 query rows as MFMA B fragments in registers for the whole kernel.  K/V tiles
+// of 64 keys are double-buffered row-major in LDS and shared by the waves; the next
+// tile's global loads are in flight while the current one is multiplied.  The score tile is computed
 // TRANSPOSED, S^T = K . Q^T, so every lane owns one query column: the softmax
 // row statistics are per-lane scalars (one cross-half shuffle per tile), and the
 // P^T accumulator registers are, after a bf16 pack, directly the B operand of
@@ -19,10 +20,7 @@
 
 namespace {
 
-constexpr int FA_WAVES = 4;
-constexpr int FA_THREADS = FA_WAVES * 64;
 constexpr int FA_QW = 32;                  // query rows per wave
-constexpr int FA_QB = FA_QW * FA_WAVES;    // query rows per workgroup
 constexpr int FA_KB = 64;                  // keys per tile
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
@@ -59,19 +57,27 @@ struct AttnArgs {
   int causal;
 };
 
-// KS = ceil(D/16) k-steps of QK^T, DT = ceil(D/32) d-tiles of PV
-template <typename T, int KS, int DT>
-__global__ __launch_bounds__(FA_THREADS) void flash_fwd_kernel(AttnArgs a) {
+// KS = ceil(D/16) k-steps of QK^T, DT = ceil(D/32) d-tiles of PV, NW waves per workgroup.
+// K/V tiles are double-buffered in LDS: the global loads of tile j+1 are issued before the
+// math of tile j and land in registers while it runs; they are written to the other buffer
+// after it, so there is ONE barrier per tile and HBM/L2 latency hides under the MFMAs.
+template <typename T, int KS, int DT, int NW>
+__global__ __launch_bounds__(NW * 64) void flash_fwd_kernel(AttnArgs a) {
   typedef typename Frag<T>::v8 v8;
   typedef typename Frag<T>::v4 v4;
+  constexpr int THREADS = NW * 64;
+  constexpr int QB = NW * FA_QW;     // query rows per workgroup
   constexpr int DKP = KS * 16;       // padded K row (elements)
   constexpr int DVP = DT * 32;       // padded V row
   constexpr int KSTR = DKP + 8;      // +16 B: conflict-free ds_read_b128 across rows
   // V row stride == 16 or 48 dwords (mod 64): the 4 rows of a tr-read block land
   // on disjoint bank quarters
   constexpr int VSTR = (DVP % 64 == 32) ? DVP : DVP + 32;
-  __shared__ __attribute__((aligned(16))) T sK[FA_KB * KSTR];
-  __shared__ __attribute__((aligned(16))) T sV[FA_KB * VSTR];
+  constexpr int KCH = DKP / 8, VCH = DVP / 8;           // 16-byte chunks per row
+  constexpr int NKR = (FA_KB * KCH + THREADS - 1) / THREADS;
+  constexpr int NVR = (FA_KB * VCH + THREADS - 1) / THREADS;
+  __shared__ __attribute__((aligned(16))) T sK[2][FA_KB * KSTR];
+  __shared__ __attribute__((aligned(16))) T sV[2][FA_KB * VSTR];
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
@@ -80,7 +86,7 @@ __global__ __launch_bounds__(FA_THREADS) void flash_fwd_kernel(AttnArgs a) {
   const int qblk = a.causal ? (gridDim.x - 1 - blockIdx.x) : blockIdx.x;
   const int h = blockIdx.y, b = blockIdx.z;
   const int hk = h / (a.Hq / a.Hkv);
-  const int q0 = qblk * FA_QB + wave * FA_QW;   // first query row of this wave
+  const int q0 = qblk * QB + wave * FA_QW;      // first query row of this wave
   const int qrow = q0 + r;                      // this lane's query row
   const int D = a.D;
   const int shift = a.Lk - a.Lq;                // bottom-right causal alignment
@@ -106,110 +112,138 @@ __global__ __launch_bounds__(FA_THREADS) void flash_fwd_kernel(AttnArgs a) {
   float m_run = -INFINITY, l_run = 0.f;
 
   // key range this workgroup needs
-  const int wg_q_last = min(qblk * FA_QB + FA_QB, a.Lq) - 1;
+  const int wg_q_last = min(qblk * QB + QB, a.Lq) - 1;
   int k_end = a.causal ? min(a.Lk, wg_q_last + shift + 1) : a.Lk;
   if (k_end < 0) k_end = 0;
   const int ntiles = (k_end + FA_KB - 1) / FA_KB;
 
+  // ---- staging: global -> registers (issue) ... registers -> LDS (commit) ----
+  v8 rk[NKR], rv[NVR];
+  auto stage_issue = [&](int kt) {
+    const int kbase = kt * FA_KB;
+#pragma unroll
+    for (int i = 0; i < NKR; ++i) {
+      const int idx = tid + i * THREADS;
+      const int row = idx / KCH, c = idx % KCH;
+      const int key = kbase + row;
+      v8 z = {};
+      rk[i] = (idx < FA_KB * KCH && key < a.Lk && c * 8 < D)
+                  ? *(const v8*)(kp + (int64_t)key * a.ksl + c * 8) : z;
+    }
+#pragma unroll
+    for (int i = 0; i < NVR; ++i) {
+      const int idx = tid + i * THREADS;
+      const int row = idx / VCH, c = idx % VCH;
+      const int key = kbase + row;
+      v8 z = {};
+      rv[i] = (idx < FA_KB * VCH && key < a.Lk && c * 8 < D)
+                  ? *(const v8*)(vp + (int64_t)key * a.vsl + c * 8) : z;
+    }
+  };
+  auto stage_commit = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NKR; ++i) {
+      const int idx = tid + i * THREADS;
+      if (idx < FA_KB * KCH) *(v8*)(sK[buf] + (idx / KCH) * KSTR + (idx % KCH) * 8) = rk[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NVR; ++i) {
+      const int idx = tid + i * THREADS;
+      if (idx < FA_KB * VCH) *(v8*)(sV[buf] + (idx / VCH) * VSTR + (idx % VCH) * 8) = rv[i];
+    }
+  };
+
+  if (ntiles > 0) {
+    stage_issue(0);
+    stage_commit(0);
+  }
+  __syncthreads();
+
   for (int kt = 0; kt < ntiles; ++kt) {
     const int kbase = kt * FA_KB;
-    __syncthreads();  // previous tile fully consumed
-    // ---- stage K and V (zero-padded rows/cols) ----
-    {
-      constexpr int KCH = DKP / 8;  // 16-byte chunks per K row
-      for (int i = tid; i < FA_KB * KCH; i += FA_THREADS) {
-        const int row = i / KCH, c = i % KCH;
-        const int key = kbase + row;
-        v8 val = {};
-        if (key < a.Lk && c * 8 < D) val = *(const v8*)(kp + (int64_t)key * a.ksl + c * 8);
-        *(v8*)(sK + row * KSTR + c * 8) = val;
-      }
-      constexpr int VCH = DVP / 8;
-      for (int i = tid; i < FA_KB * VCH; i += FA_THREADS) {
-        const int row = i / VCH, c = i % VCH;
-        const int key = kbase + row;
-        v8 val = {};
-        if (key < a.Lk && c * 8 < D) val = *(const v8*)(vp + (int64_t)key * a.vsl + c * 8);
-        *(v8*)(sV + row * VSTR + c * 8) = val;
-      }
-    }
-    __syncthreads();
+    const int buf = kt & 1;
+    const bool more = kt + 1 < ntiles;
+    if (more) stage_issue(kt + 1);
+    const T* cK = sK[buf];
+    const T* cV = sV[buf];
 
     // wave-uniform skip of tiles entirely above this wave's causal diagonal
     const int wave_q_last = q0 + FA_QW - 1;
-    if (a.causal && kbase > wave_q_last + shift) continue;
-
-    // ---- S^T = K . Q^T  (2 key sub-tiles of 32) ----
-    f32x16 sacc[2];
+    if (!(a.causal && kbase > wave_q_last + shift)) {
+      // ---- S^T = K . Q^T  (2 key sub-tiles of 32) ----
+      f32x16 sacc[2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+      for (int t = 0; t < 2; ++t) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) sacc[t][i] = 0.f;
+        for (int i = 0; i < 16; ++i) sacc[t][i] = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const v8 kf = *(const v8*)(sK + (t * 32 + r) * KSTR + ks * 16 + hh * 8);
-        sacc[t] = Frag<T>::mfma(kf, qf[ks], sacc[t]);
-      }
-    }
-    // ---- mask, scale to log2 domain, running max ----
-    const bool need_mask = (kbase + FA_KB > a.Lk) || (a.causal && kbase + FA_KB - 1 > q0 + shift);
-    float tmax = -INFINITY;
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        float s = sacc[t][i] * a.scale_log2;
-        if (need_mask) {
-          const int key = kbase + t * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-          const bool ok = key < a.Lk && (!a.causal || key <= qrow + shift);
-          s = ok ? s : -INFINITY;
+        for (int ks = 0; ks < KS; ++ks) {
+          const v8 kf = *(const v8*)(cK + (t * 32 + r) * KSTR + ks * 16 + hh * 8);
+          sacc[t] = Frag<T>::mfma(kf, qf[ks], sacc[t]);
         }
-        sacc[t][i] = s;
-        tmax = fmaxf(tmax, s);
       }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    const float m_new = fmaxf(m_run, tmax);
-    // rows with nothing visible yet keep m=-inf: use 0 as the exponent base
-    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = exp2f(m_run - m_use);  // m_run=-inf -> 0
-    float psum = 0.f;
+      // ---- mask, scale to log2 domain, running max ----
+      const bool need_mask = (kbase + FA_KB > a.Lk) || (a.causal && kbase + FA_KB - 1 > q0 + shift);
+      float tmax = -INFINITY;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float p = exp2f(sacc[t][i] - m_use);
-        sacc[t][i] = p;
-        psum += p;
-      }
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
+        for (int i = 0; i < 16; ++i) {
+          float s = sacc[t][i] * a.scale_log2;
+          if (need_mask) {
+            const int key = kbase + t * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+            const bool ok = key < a.Lk && (!a.causal || key <= qrow + shift);
+            s = ok ? s : -INFINITY;
+          }
+          sacc[t][i] = s;
+          tmax = fmaxf(tmax, s);
+        }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float m_new = fmaxf(m_run, tmax);
+      // rows with nothing visible yet keep m=-inf: use 0 as the exponent base
+      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+      const float alpha = exp2f(m_run - m_use);  // m_run=-inf -> 0
+      float psum = 0.f;
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) oacc[dt][i] *= alpha;
+        for (int i = 0; i < 16; ++i) {
+          const float p = exp2f(sacc[t][i] - m_use);
+          sacc[t][i] = p;
+          psum += p;
+        }
+      l_run = l_run * alpha + psum;
+      m_run = m_new;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oacc[dt][i] *= alpha;
 
-    // ---- O^T += V^T . P^T over 4 k-steps of 16 keys ----
+      // ---- O^T += V^T . P^T over 4 k-steps of 16 keys ----
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int t = s >> 1, rb = (s & 1) * 8;
-      v8 pf;
+      for (int s = 0; s < 4; ++s) {
+        const int t = s >> 1, rb = (s & 1) * 8;
+        v8 pf;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) pf[j] = from_f32<T>(sacc[t][rb + j]);
-      // element j of this lane is key row 16s + 8(j>>2) + 4hh + (j&3) of the tile
-      const int key0 = s * 16 + 4 * hh;
-      const int q4 = (lane & 15) >> 2, p4 = lane & 3;
-      const int cb = 16 * ((lane >> 4) & 1);
+        for (int j = 0; j < 8; ++j) pf[j] = from_f32<T>(sacc[t][rb + j]);
+        // element j of this lane is key row 16s + 8(j>>2) + 4hh + (j&3) of the tile
+        const int key0 = s * 16 + 4 * hh;
+        const int q4 = (lane & 15) >> 2, p4 = lane & 3;
+        const int cb = 16 * ((lane >> 4) & 1);
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt) {
-        const T* base = sV + (key0 + q4) * VSTR + dt * 32 + cb + 4 * p4;
-        const v4 lo = Frag<T>::tr_read(base);
-        const v4 hi = Frag<T>::tr_read(base + 8 * VSTR);
-        v8 vf;
+        for (int dt = 0; dt < DT; ++dt) {
+          const T* base = cV + (key0 + q4) * VSTR + dt * 32 + cb + 4 * p4;
+          const v4 lo = Frag<T>::tr_read(base);
+          const v4 hi = Frag<T>::tr_read(base + 8 * VSTR);
+          v8 vf;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi[j]; }
-        oacc[dt] = Frag<T>::mfma(vf, pf, oacc[dt]);
+          for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi[j]; }
+          oacc[dt] = Frag<T>::mfma(vf, pf, oacc[dt]);
+        }
       }
     }
+    if (more) stage_commit(buf ^ 1);
+    __syncthreads();
   }
 
   // ---- epilogue: normalise and store O[q][d] ----
@@ -236,18 +270,25 @@ __global__ __launch_bounds__(FA_THREADS) void flash_fwd_kernel(AttnArgs a) {
   }
 }
 
+template <typename T, int KS, int DT>
+int launch_fa_d(const AttnArgs& a, int B, hipStream_t st) {
+  if (a.Lq > 128) {
+    dim3 grid((a.Lq + 255) / 256, a.Hq, B);
+    flash_fwd_kernel<T, KS, DT, 8><<<grid, 512, 0, st>>>(a);
+  } else {
+    dim3 grid((a.Lq + 127) / 128, a.Hq, B);
+    flash_fwd_kernel<T, KS, DT, 4><<<grid, 256, 0, st>>>(a);
+  }
+  TV_LAUNCH_CHECK();
+}
+
 template <typename T>
 int launch_fa(const AttnArgs& a, int B, hipStream_t st) {
-  dim3 grid((a.Lq + FA_QB - 1) / FA_QB, a.Hq, B);
-#define TV_FA(KS, DT)                                                         \
-  flash_fwd_kernel<T, KS, DT><<<grid, FA_THREADS, 0, st>>>(a);                \
-  TV_LAUNCH_CHECK();
   const int D = a.D;
-  if (D <= 64) { TV_FA(4, 2) }
-  if (D <= 80) { TV_FA(5, 3) }
-  if (D <= 96) { TV_FA(6, 3) }
-  if (D <= 128) { TV_FA(8, 4) }
-#undef TV_FA
+  if (D <= 64) return launch_fa_d<T, 4, 2>(a, B, st);
+  if (D <= 80) return launch_fa_d<T, 5, 3>(a, B, st);
+  if (D <= 96) return launch_fa_d<T, 6, 3>(a, B, st);
+  if (D <= 128) return launch_fa_d<T, 8, 4>(a, B, st);
   TV_UNSUPPORTED("flash_attn: headdim %d > 128", D);
 }
 
