@@ -202,13 +202,13 @@ __global__ __launch_bounds__(NW * 64) void flash_fwd_kernel(AttnArgs a) {
       const float m_new = fmaxf(m_run, tmax);
       // rows with nothing visible yet keep m=-inf: use 0 as the exponent base
       const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-      const float alpha = exp2f(m_run - m_use);  // m_run=-inf -> 0
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);  // m_run=-inf -> 0
       float psum = 0.f;
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const float p = exp2f(sacc[t][i] - m_use);
+          const float p = __builtin_amdgcn_exp2f(sacc[t][i] - m_use);
           sacc[t][i] = p;
           psum += p;
         }
