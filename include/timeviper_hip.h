@@ -93,6 +93,15 @@ int tv_rmsnorm_fwd(const void* x, const void* delta, const void* weight,
                    int64_t y_stride, float eps, int dtype, int wdtype,
                    void* stream);
 
+/* ViT blocks (V1/V2): LayerNorm with the residual add of the previous sub-layer fused in
+ * (timm Block: x = x + attn(norm1(x)); x = x + mlp(norm2(x))), and the exact (erf) GELU of
+ * the MLP.  s = x (+ delta) rounded to dtype -> sum_out; y = (s-mean)*rsqrt(var+eps)*w + b. */
+int tv_layernorm_fwd(const void* x, const void* delta, const void* weight,
+                     const void* bias, void* sum_out, void* y, int64_t rows, int dim,
+                     int64_t x_stride, int64_t delta_stride, int64_t sum_stride,
+                     int64_t y_stride, float eps, int dtype, void* stream);
+int tv_gelu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream);
+
 /* ------------------------------------------------------------------------
  * S4  gated, grouped RMSNorm.  Replaces mamba_ssm rmsnorm_fn(x, weight,
  * bias=None, z=gate, eps, group_size, norm_before_gate=False)

@@ -45,6 +45,13 @@ def _rms(x, weight, eps, residual=None, return_sum=False):
     return (y, s) if return_sum else y
 
 
+def _ln(x, weight, bias, eps, residual=None, return_sum=False):
+    s = x if residual is None else (x + residual)
+    y = torch.nn.functional.layer_norm(s.float(), (s.shape[-1],), weight.float(),
+                                       None if bias is None else bias.float(), eps).to(x.dtype)
+    return (y, s) if return_sum else y
+
+
 def _gated(x, weight, bias=None, z=None, eps=1e-6, group_size=None, norm_before_gate=True, **kw):
     return R.rmsnorm_gated_ref(x, weight, z, eps, group_size).to(x.dtype)
 
@@ -79,6 +86,7 @@ def cpu_kernels():
     patches = {
         "causal_conv1d_xbc": _conv_xbc, "causal_conv1d_fn": _conv_fn,
         "mamba_chunk_scan_combined": _scan, "rms_norm": _rms, "rmsnorm_fn": _gated,
+        "layer_norm": _ln, "gelu": lambda x, inplace=False: torch.nn.functional.gelu(x),
         "flash_attn_func": _fa, "_flash_attention_forward": _fa_fwd,
         "gather_rows": lambda src, idx: src.reshape(-1, src.shape[-1])[idx],
         "uniform_keep_indices": lambda n, keep, offset=0, device="cpu":

@@ -64,8 +64,13 @@ def worker(rank, world, port, merge, T, q):
             if rank == 0:
                 ref = vlm(input_ids=ids, pixel_values_videos=pix).logits
                 ref_trace = [t["kept"] for t in vlm.llm_backbone.llm.backbone.last_pdrop_trace]
-                q.put((logits, ref, trace, ref_trace))
+                q.put((logits.numpy(), ref.numpy(), [t.numpy() for t in trace],
+                       [t.numpy() for t in ref_trace]))
         dist.barrier()
+    except BaseException:
+        import traceback
+        traceback.print_exc()
+        os._exit(1)
     finally:
         dist.destroy_process_group()
 
@@ -74,15 +79,21 @@ def worker(rank, world, port, merge, T, q):
 def test_sequence_parallel_matches_single_process(merge):
     world, T = 2, 5
     ctx = mp.get_context("spawn")
-    q = ctx.SimpleQueue()
+    q = ctx.Queue()
     port = free_port()
     procs = [ctx.Process(target=worker, args=(r, world, port, merge, T, q)) for r in range(world)]
     for p in procs:
         p.start()
-    logits, ref, trace, ref_trace = q.get()
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
+    try:
+        logits, ref, trace, ref_trace = q.get(timeout=240)   # plain numpy: no shm handles to lose
+    finally:
+        for p in procs:
+            p.join(60)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs), "worker failed (see its traceback above)"
+    logits, ref = torch.from_numpy(logits), torch.from_numpy(ref)
+    trace, ref_trace = [torch.from_numpy(t) for t in trace], [torch.from_numpy(t) for t in ref_trace]
     assert all(torch.equal(a, b) for a, b in zip(trace, ref_trace)), "kept indices differ"
     assert torch.allclose(logits, ref, rtol=1e-4, atol=1e-5), (logits - ref).abs().max()
 

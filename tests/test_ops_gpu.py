@@ -426,3 +426,22 @@ def test_conv1d_xbc_group_major(K):
     yr, fr, _ = R.ssd_recurrence_ref(x.float().cpu().view(2, L, H, P), dt.float(), A, Bm.float().cpu(), Cm.float().cpu())
     close(y2, yr, 2e-2, 4e-2)
     close(fin, fr, 2e-2, 2e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_layernorm_and_gelu(K, dtype):
+    g = torch.Generator().manual_seed(31)
+    rows, D = 37, 1152
+    x = (torch.randn(rows, D, generator=g) * 2 + 0.5).to(dtype)
+    d = torch.randn(rows, D, generator=g).to(dtype)
+    w = (1 + 0.1 * torch.randn(D, generator=g)).to(dtype)
+    b = (0.1 * torch.randn(D, generator=g)).to(dtype)
+    ref = torch.nn.functional.layer_norm(x.float(), (D,), w.float(), b.float(), 1e-6)
+    y = K.layer_norm(x.to(DEV), w.to(DEV), b.to(DEV), 1e-6)
+    close(y, ref, *TOL[dtype])
+    s_ref = x + d
+    y2, s2 = K.layer_norm(x.to(DEV), w.to(DEV), b.to(DEV), 1e-6, residual=d.to(DEV), return_sum=True)
+    assert torch.equal(s2.cpu(), s_ref)
+    close(y2, torch.nn.functional.layer_norm(s_ref.float(), (D,), w.float(), b.float(), 1e-6), *TOL[dtype])
+    h = (torch.randn(33, 4304 * 2, generator=g) * 2).to(dtype)
+    close(K.gelu(h.to(DEV)), torch.nn.functional.gelu(h.float()), *TOL[dtype])

@@ -74,6 +74,87 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_kernel(
   }
 }
 
+// LayerNorm with optional fused residual add (ViT blocks): s = x (+ delta); y = (s-mean)*rstd*w + b
+template <typename T>
+__global__ __launch_bounds__(NORM_THREADS) void layernorm_kernel(
+    const T* __restrict__ x, const T* __restrict__ delta, const T* __restrict__ w,
+    const T* __restrict__ bias, T* __restrict__ sum_out, T* __restrict__ y, int D, int64_t xs,
+    int64_t ds, int64_t ss, int64_t ys, float eps) {
+  constexpr int V = Vec16<T>::N;
+  typedef typename Vec16<T>::type vec_t;
+  __shared__ float red[2][NORM_THREADS / 64];
+  const int64_t row = blockIdx.x;
+  const int nv = D / V;
+  const T* xr = x + row * xs;
+  const T* dr = delta ? delta + row * ds : nullptr;
+  float vals[NORM_MAXV][V];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < NORM_MAXV; ++k) {
+    const int iv = threadIdx.x + k * NORM_THREADS;
+    if (iv < nv) {
+      vec_t v = *(const vec_t*)(xr + (int64_t)iv * V);
+      if (dr) {
+        vec_t d = *(const vec_t*)(dr + (int64_t)iv * V);
+        vec_t sv;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          sv[i] = from_f32<T>(to_f32(v[i]) + to_f32(d[i]));
+          vals[k][i] = to_f32(sv[i]);
+        }
+        if (sum_out) *(vec_t*)(sum_out + row * ss + (int64_t)iv * V) = sv;
+      } else {
+#pragma unroll
+        for (int i = 0; i < V; ++i) vals[k][i] = to_f32(v[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < V; ++i) { s1 += vals[k][i]; s2 = fmaf(vals[k][i], vals[k][i], s2); }
+    }
+  }
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; }
+  __syncthreads();
+  float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NORM_THREADS / 64; ++i) { t1 += red[0][i]; t2 += red[1][i]; }
+  const float mean = t1 / (float)D;
+  const float var = fmaxf(t2 / (float)D - mean * mean, 0.f);
+  const float rstd = rsqrtf(var + eps);
+#pragma unroll
+  for (int k = 0; k < NORM_MAXV; ++k) {
+    const int iv = threadIdx.x + k * NORM_THREADS;
+    if (iv < nv) {
+      const vec_t wv = *(const vec_t*)(w + (int64_t)iv * V);
+      vec_t bv = {};
+      if (bias) bv = *(const vec_t*)(bias + (int64_t)iv * V);
+      vec_t o;
+#pragma unroll
+      for (int i = 0; i < V; ++i)
+        o[i] = from_f32<T>((vals[k][i] - mean) * rstd * to_f32(wv[i]) + to_f32(bv[i]));
+      *(vec_t*)(y + row * ys + (int64_t)iv * V) = o;
+    }
+  }
+}
+
+// exact (erf) GELU, elementwise, 16 bytes per lane, grid-stride
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                   int64_t nvec) {
+  constexpr int V = Vec16<T>::N;
+  typedef typename Vec16<T>::type vec_t;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+    const vec_t v = *(const vec_t*)(x + i * V);
+    vec_t o;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const float f = to_f32(v[j]);
+      o[j] = from_f32<T>(0.5f * f * (1.f + erff(f * 0.70710678118654752f)));
+    }
+    *(vec_t*)(y + i * V) = o;
+  }
+}
+
 // one wave per (row, group)
 template <typename T>
 __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_gated_kernel(
@@ -156,6 +237,19 @@ int launch_gated(const void* x, const void* z, const void* w, void* y, int64_t r
 
 bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+template <typename T>
+int launch_ln(const void* x, const void* delta, const void* w, const void* b, void* sum_out, void* y,
+              int64_t rows, int D, int64_t xs, int64_t ds, int64_t ss, int64_t ys, float eps,
+              hipStream_t s) {
+  constexpr int V = Vec16<T>::N;
+  if (D % V || D / V > NORM_THREADS * NORM_MAXV)
+    TV_UNSUPPORTED("layernorm: dim %d not a multiple of %d or larger than %d", D, V,
+                   V * NORM_THREADS * NORM_MAXV);
+  layernorm_kernel<T><<<dim3((unsigned)rows), NORM_THREADS, 0, s>>>(
+      (const T*)x, (const T*)delta, (const T*)w, (const T*)b, (T*)sum_out, (T*)y, D, xs, ds, ss, ys, eps);
+  TV_LAUNCH_CHECK();
+}
+
 }  // namespace
 
 extern "C" int tv_rmsnorm_fwd(const void* x, const void* delta, const void* weight,
@@ -215,4 +309,49 @@ extern "C" int tv_rmsnorm_gated_fwd(const void* x, const void* z, const void* we
                                  y_stride, eps, wf32, s);
   }
   TV_UNSUPPORTED("rmsnorm_gated: dtype %d", dtype);
+}
+
+extern "C" int tv_layernorm_fwd(const void* x, const void* delta, const void* weight,
+                                const void* bias, void* sum_out, void* y, int64_t rows, int dim,
+                                int64_t x_stride, int64_t delta_stride, int64_t sum_stride,
+                                int64_t y_stride, float eps, int dtype, void* stream) {
+  TV_CHECK_ARG(x && weight && y, "layernorm: null pointer");
+  TV_CHECK_ARG(rows >= 0 && dim > 0, "layernorm: bad sizes");
+  if (rows == 0) return TV_OK;
+  const int vec = dtype == TV_F32 ? 4 : 8;
+  if (!aligned16(x) || !aligned16(y) || !aligned16(weight) || (bias && !aligned16(bias)) ||
+      (delta && !aligned16(delta)) || (sum_out && !aligned16(sum_out)) || x_stride % vec ||
+      y_stride % vec || (delta && delta_stride % vec) || (sum_out && sum_stride % vec))
+    TV_UNSUPPORTED("layernorm: pointers/strides must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  switch (dtype) {
+    case TV_F32:
+      return launch_ln<float>(x, delta, weight, bias, sum_out, y, rows, dim, x_stride, delta_stride,
+                              sum_stride, y_stride, eps, s);
+    case TV_BF16:
+      return launch_ln<bf16_t>(x, delta, weight, bias, sum_out, y, rows, dim, x_stride,
+                               delta_stride, sum_stride, y_stride, eps, s);
+    case TV_F16:
+      return launch_ln<f16_t>(x, delta, weight, bias, sum_out, y, rows, dim, x_stride, delta_stride,
+                              sum_stride, y_stride, eps, s);
+  }
+  TV_UNSUPPORTED("layernorm: dtype %d", dtype);
+}
+
+extern "C" int tv_gelu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream) {
+  TV_CHECK_ARG(x && y, "gelu: null pointer");
+  TV_CHECK_ARG(n >= 0, "gelu: bad size");
+  if (n == 0) return TV_OK;
+  const int vec = dtype == TV_F32 ? 4 : 8;
+  if (n % vec || !aligned16(x) || !aligned16(y)) TV_UNSUPPORTED("gelu: size/pointers must be 16-byte multiples");
+  const int64_t nvec = n / vec;
+  const unsigned grid = (unsigned)((nvec + 255) / 256 < 16384 ? (nvec + 255) / 256 : 16384);
+  hipStream_t s = (hipStream_t)stream;
+  switch (dtype) {
+    case TV_F32: gelu_kernel<float><<<grid, 256, 0, s>>>((const float*)x, (float*)y, nvec); break;
+    case TV_BF16: gelu_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)x, (bf16_t*)y, nvec); break;
+    case TV_F16: gelu_kernel<f16_t><<<grid, 256, 0, s>>>((const f16_t*)x, (f16_t*)y, nvec); break;
+    default: TV_UNSUPPORTED("gelu: dtype %d", dtype);
+  }
+  TV_LAUNCH_CHECK();
 }

@@ -160,6 +160,35 @@ def rms_norm(x, weight, eps, residual=None, return_sum=False):
     return y
 
 
+def layer_norm(x, weight, bias, eps, residual=None, return_sum=False):
+    """nn.LayerNorm over the last dim, optionally of s = x + residual (rounded to x.dtype),
+    returning s too — the fused form of a pre-norm ViT block's residual add + norm."""
+    _gpu(x, weight, bias, residual)
+    x2 = _rows2d(x)
+    r2 = None if residual is None else _rows2d(residual)
+    y = torch.empty(x2.shape, dtype=x.dtype, device=x.device)
+    s = torch.empty_like(y) if (return_sum and residual is not None) else None
+    w = weight.to(x.dtype).contiguous()
+    b = None if bias is None else bias.to(x.dtype).contiguous()
+    check(_capi.lib().tv_layernorm_fwd(
+        _p(x2), _p(r2), _p(w), _p(b), _p(s), _p(y), x2.shape[0], x2.shape[1], x2.stride(0),
+        0 if r2 is None else r2.stride(0), 0 if s is None else s.stride(0), y.stride(0), float(eps),
+        _dt(x), _stream()), "tv_layernorm_fwd")
+    y = y.view(x.shape)
+    if return_sum:
+        return y, (s.view(x.shape) if s is not None else x)
+    return y
+
+
+def gelu(x, inplace=False):
+    """exact (erf) GELU, elementwise."""
+    _gpu(x)
+    xc = x if x.is_contiguous() else x.contiguous()
+    y = xc if inplace else torch.empty_like(xc)
+    check(_capi.lib().tv_gelu_fwd(_p(xc), _p(y), xc.numel(), _dt(xc), _stream()), "tv_gelu_fwd")
+    return y
+
+
 def rmsnorm_fn(x, weight, bias=None, z=None, eps=1e-6, group_size=None,
                norm_before_gate=True, upcast=True):
     """mamba_ssm.ops.triton.layernorm_gated.rmsnorm_fn as the reference calls it

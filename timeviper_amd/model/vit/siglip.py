@@ -80,10 +80,13 @@ class Mlp(nn.Module):
         super().__init__()
         self.fc1 = nn.Linear(dim, hidden)
         self.act = nn.GELU(approximate="tanh" if act == "gelu_tanh" else "none")
+        self.exact_gelu = act != "gelu_tanh"
         self.fc2 = nn.Linear(hidden, dim)
 
     def forward(self, x):
-        return self.fc2(self.act(self.fc1(x)))
+        h = self.fc1(x)
+        h = K.gelu(h, inplace=True) if self.exact_gelu else self.act(h)
+        return self.fc2(h)
 
 
 class LayerScale(nn.Module):
@@ -108,6 +111,19 @@ class Block(nn.Module):
     def forward(self, x):
         x = x + self.ls1(self.attn(self.norm1(x)))
         return x + self.ls2(self.mlp(self.norm2(x)))
+
+    def forward_fused(self, x, delta):
+        """Same block on the (stream, pending sub-layer output) pair: each residual add is
+        fused into the LayerNorm that follows it.  Returns (x', delta') with the block's
+        output = x' + delta'."""
+        n1, n2 = self.norm1, self.norm2
+        if delta is None:
+            h = K.layer_norm(x, n1.weight, n1.bias, n1.eps)
+        else:
+            h, x = K.layer_norm(x, n1.weight, n1.bias, n1.eps, residual=delta, return_sum=True)
+        a = self.ls1(self.attn(h))
+        h, x = K.layer_norm(x, n2.weight, n2.bias, n2.eps, residual=a, return_sum=True)
+        return x, self.ls2(self.mlp(h))
 
 
 class AttentionPoolLatent(nn.Module):
@@ -159,8 +175,10 @@ class VisionTransformer(nn.Module):
                 prefix = [t for t in (self.cls_token, self.reg_token) if t is not None]
                 x = torch.cat([t.expand(x.shape[0], -1, -1) for t in prefix] + [x], dim=1)
                 x = x + self.pos_embed
+        delta = None
         for i in range(last + 1):
-            x = self.blocks[i](x)
+            x, delta = self.blocks[i].forward_fused(x, delta)
+        x = x + delta
         return (x[:, self.num_prefix_tokens:],)
 
     def forward(self, x):
