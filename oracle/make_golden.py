@@ -280,3 +280,68 @@ def make_tome_golden():
 
 if __name__ == "__main__" and os.environ.get("GOLDEN_ONLY") in (None, "tome"):
     make_tome_golden()
+
+
+@torch.no_grad()
+def make_internvideo2_golden():
+    """G10: the reference's InternVideo2 tower (timeviper/model/vit/internvideo2/model.py,
+    vit_scale_clean.py) at toy width, fp32.  timm and flash_attn are absent, so the names the
+    file imports from them are stubbed (DropPath is inactive in eval, to_2tuple/trunc_normal_
+    are torch one-liners) and every block is switched to the file's own `_naive_attn`
+    branch — the arithmetic that runs is the reference's."""
+    sys.path.insert(0, REF)
+
+    def _mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__path__ = []
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+
+    import transformers.image_processing_utils, transformers.image_transforms  # noqa: F401 (before the timm stub)
+    import transformers.image_utils  # noqa: F401
+    _mod("timm"); _mod("timm.models")
+    _mod("timm.models.layers", DropPath=lambda p=0.0: torch.nn.Identity(),
+         to_2tuple=lambda v: v if isinstance(v, tuple) else (v, v),
+         trunc_normal_=torch.nn.init.trunc_normal_)
+    _mod("flash_attn"); _mod("flash_attn.bert_padding", pad_input=None, unpad_input=None)
+    _mod("flash_attn.flash_attn_interface", flash_attn_varlen_qkvpacked_func=None)
+    for name, path in [("timeviper", f"{REF}/timeviper"), ("timeviper.model", f"{REF}/timeviper/model"),
+                       ("timeviper.model.vit", f"{REF}/timeviper/model/vit"),
+                       ("timeviper.model.vit.internvideo2", f"{REF}/timeviper/model/vit/internvideo2")]:
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__path__ = [path]
+            sys.modules[name] = m
+    iv = importlib.import_module("timeviper.model.vit.internvideo2.model")
+    cfg = iv.InternVideo2VisionConfig(num_frames=4, hidden_size=64, num_hidden_layers=5,
+                                      num_attention_heads=2, image_size=28, patch_size=14)
+    torch.manual_seed(21)
+    tower = iv.InternVideo2VisionTower(cfg).eval().float()
+    vt = tower.vision_tower
+    init_pos = {"pos_embed_init": vt.pos_embed.clone(), "img_pos_embed_init": vt.img_pos_embed.clone()}
+    g = torch.Generator().manual_seed(22)
+    for name, p in vt.named_parameters():
+        if name.endswith(("ls1.weight", "ls2.weight")):
+            p.copy_(torch.rand(p.shape, generator=g) + 0.5)
+        elif "norm" in name:
+            p.copy_(torch.rand(p.shape, generator=g) + 0.5)
+        elif name in ("pos_embed", "img_pos_embed"):
+            p.add_(torch.randn(p.shape, generator=g) * 0.05)
+        elif name.endswith("bias"):
+            p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+        else:
+            p.copy_(torch.randn(p.shape, generator=g) * 0.08)
+    for blk in vt.blocks:
+        blk.attn.use_flash_attn = False
+    video = torch.randn(8, 1, 3, 28, 28, generator=g)
+    video_b2 = torch.randn(4, 2, 3, 28, 28, generator=g)
+    images = torch.randn(2, 1, 3, 28, 28, generator=g)
+    npz("internvideo2", video=video, video_out=tower(video, is_video=True),
+        video_b2=video_b2, video_b2_out=tower(video_b2, is_video=True),
+        images=images, images_out=tower(images, is_video=False),
+        depth=np.array(vt.depth), num_heads=np.array(2), **init_pos,
+        **{"w." + k: v for k, v in vt.state_dict().items()})
+
+
+if __name__ == "__main__" and os.environ.get("GOLDEN_ONLY") in (None, "internvideo2"):
+    make_internvideo2_golden()

@@ -32,3 +32,59 @@ def vit_intermediate_ref(sd, pixels, depth, num_heads, patch, take=None, eps=1e-
         h = F.gelu(F.linear(h, sd[p + "mlp.fc1.weight"].float(), sd[p + "mlp.fc1.bias"].float()))
         x = x + F.linear(h, sd[p + "mlp.fc2.weight"].float(), sd[p + "mlp.fc2.bias"].float())
     return x
+
+
+# ---------------------------------------------------------------- InternVideo2 tower
+def internvideo2_rmsnorm_ref(x, w, eps=1e-6):
+    """vit_scale_clean.py:152-163: fp32 statistics, cast back, then the weight."""
+    xf = x.float()
+    xf = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)
+    return w * xf.to(x.dtype)
+
+
+def internvideo2_tower_ref(sd, pixel_values, num_heads, is_video=None, eps=1e-6):
+    """`InternVideo2VisionTower.forward` (model.py:173-190) over
+    `PretrainVisionTransformer_clean.forward` (vit_scale_clean.py:664-722), PINNED by
+    tests/golden/internvideo2.npz (generated from the reference itself).
+    sd: vision_tower state dict (the number of `blocks.*` entries is the depth run).
+    pixel_values: (T, B, C, H, W) for video, (B, 1, C, H, W) for images."""
+    if is_video is None:
+        is_video = pixel_values.shape[1] > 1
+    if is_video:
+        T, B, C, H, W = pixel_values.shape
+        px = pixel_values.permute(1, 2, 0, 3, 4).reshape(B * (T // 4), C, 4, H, W)   # model.py:180-182
+    else:
+        px = pixel_values.permute(0, 2, 1, 3, 4)
+    w = sd["patch_embed.proj.weight"]
+    x = F.conv3d(px.to(w.dtype), w, sd["patch_embed.proj.bias"], stride=w.shape[2:])
+    x = x.flatten(3).permute(0, 2, 3, 1)                       # (B, T, L, D)  :455-460
+    Bc, Tc, L, D = x.shape
+    x = torch.cat([sd["cls_token"].expand(Bc, -1, -1), x.reshape(Bc, Tc * L, D)], dim=1)
+    if is_video:
+        pos = sd["pos_embed"]
+    elif "img_pos_embed" in sd:
+        pos = sd["img_pos_embed"]
+    else:                                                      # :688-703 joint table, frame mean
+        nf = (sd["pos_embed"].shape[1] - 1) // L
+        pos = torch.cat([sd["pos_embed"][:, :1],
+                         sd["pos_embed"][:, 1:].view(1, nf, L, D).mean(dim=1)], dim=1)
+    x = x + pos
+    depth = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("blocks."))
+    hd = D // num_heads
+    for i in range(depth):
+        p = f"blocks.{i}."
+        h = internvideo2_rmsnorm_ref(x, sd[p + "norm1.weight"], eps)
+        qkv = F.linear(h, sd[p + "attn.qkv.weight"], sd.get(p + "attn.qkv.bias"))
+        q, k, v = qkv.split(D, dim=-1)
+        q = internvideo2_rmsnorm_ref(q, sd[p + "attn.q_norm.weight"], eps)     # over all heads, :238-249
+        k = internvideo2_rmsnorm_ref(k, sd[p + "attn.k_norm.weight"], eps)
+        N = q.shape[1]
+        o, _ = ops.attention_ref(q.view(Bc, N, num_heads, hd), k.view(Bc, N, num_heads, hd),
+                                 v.reshape(Bc, N, num_heads, hd), causal=False, scale=hd ** -0.5)
+        a = F.linear(o.reshape(Bc, N, D).to(x.dtype), sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"])
+        x = x + (a.float() * sd[p + "ls1.weight"].float()).to(x.dtype)         # LayerScale fp32 :166-185
+        h = internvideo2_rmsnorm_ref(x, sd[p + "norm2.weight"], eps)
+        h = F.gelu(F.linear(h, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"]))
+        m = F.linear(h, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
+        x = x + (m.float() * sd[p + "ls2.weight"].float()).to(x.dtype)
+    return x[:, 1:, :]

@@ -75,6 +75,15 @@ def _rank(q_row, k, n_keys, vis_start, n_vis, scale=None):
     return p.mean(0).to(dt).float()[vis_start:vis_start + n_vis]
 
 
+def _patch_video(pix, w, b=None, pos=None):
+    y = torch.nn.functional.conv3d(pix.float(), w.float(), None if b is None else b.float(),
+                                   stride=w.shape[2:])
+    y = y.flatten(3).permute(0, 2, 3, 1).flatten(1, 2)
+    if pos is not None:
+        y = y + pos.float().reshape(-1, y.shape[-1])
+    return y.to(pix.dtype)
+
+
 def _dropped(keep_sorted, start, n):
     allidx = torch.arange(start, start + n)
     return allidx[~torch.isin(allidx, keep_sorted)]
@@ -94,6 +103,7 @@ def cpu_kernels():
         "dropped_indices": _dropped, "attn_rank_scores": _rank,
         "patch_embed": lambda pix, w, b=None, pos=None, patch=None:
             R.patch_embed_ref(pix, w, b, pos).to(pix.dtype),
+        "patch_embed_video": _patch_video,
     }
     saved = {k: getattr(K, k) for k in patches}
     for k, v in patches.items():

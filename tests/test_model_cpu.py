@@ -79,3 +79,30 @@ def test_fused_embedding_layout_matches_reference():
     f2, _ = GenericTimeViperVLM.get_fused_data_nopacked(fake, vis, torch.from_numpy(g["ids2"]))
     assert torch.equal(f1, torch.from_numpy(g["fused"]))      # contiguous-run fast path
     assert torch.equal(f2, torch.from_numpy(g["fused2"]))     # interleaved text: general walk
+
+
+def _toy_internvideo2():
+    from timeviper_amd.model.vit.internvideo2 import InternVideo2VisionConfig, InternVideo2VisionTower
+    cfg = InternVideo2VisionConfig(num_frames=4, hidden_size=64, num_hidden_layers=5,
+                                   num_attention_heads=2, image_size=28, patch_size=14)
+    return InternVideo2VisionTower(cfg).eval()
+
+
+def test_internvideo2_sincos_tables_match_reference():
+    g = load_golden("internvideo2")
+    vt = _toy_internvideo2().vision_tower
+    np.testing.assert_allclose(vt.pos_embed.numpy(), g["pos_embed_init"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(vt.img_pos_embed.numpy(), g["img_pos_embed_init"], rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("case,is_video", [("video", True), ("video_b2", True), ("images", False)])
+def test_internvideo2_mirror_matches_reference(case, is_video):
+    """Module wiring (clip regrouping, cls/pos tables, fused residual stream) with the
+    operators replaced by their CPU restatements; the HIP operators are checked on the GPU."""
+    from cpu_kernel_shim import cpu_kernels
+    g = load_golden("internvideo2")
+    tower = _toy_internvideo2()
+    tower.vision_tower.load_state_dict(golden_state_dict(g), strict=True)
+    with cpu_kernels():
+        out = tower(torch.from_numpy(g[case]), is_video=is_video)
+    np.testing.assert_allclose(out.numpy(), g[case + "_out"], rtol=1e-4, atol=3e-5)

@@ -180,6 +180,43 @@ def test_vit_vs_oracle():
     assert relerr(out, ref) < 2e-2
 
 
+@pytest.mark.parametrize("case,is_video", [("video", True), ("video_b2", True), ("images", False)])
+def test_internvideo2_tower_vs_reference_golden(case, is_video):
+    """InternVideo2 tower on the HIP operators (bf16) against the reference's own fp32
+    output (tests/golden/internvideo2.npz); tolerance = bf16 round-off through 4 blocks."""
+    from timeviper_amd.model.vit.internvideo2 import InternVideo2VisionConfig, InternVideo2VisionTower
+    g = load_golden("internvideo2")
+    cfg = InternVideo2VisionConfig(num_frames=4, hidden_size=64, num_hidden_layers=5,
+                                   num_attention_heads=2, image_size=28, patch_size=14)
+    tower = InternVideo2VisionTower(cfg).eval()
+    tower.vision_tower.load_state_dict(golden_state_dict(g), strict=True)
+    tower = tower.to(DEV).bfloat16()
+    out = tower(torch.from_numpy(g[case]).to(DEV).bfloat16(), is_video=is_video)
+    assert out.shape == g[case + "_out"].shape
+    assert relerr(out, torch.from_numpy(g[case + "_out"])) < 3e-2
+
+
+def test_internvideo2_full_width_block_runs():
+    """Real InternVideo2-1B widths (1408 = 16 heads x 88, MLP 6144) for one 4-frame clip,
+    2 blocks, against the oracle on the same bf16-rounded weights."""
+    from timeviper_amd.model.vit.internvideo2 import InternVideo2VisionConfig, InternVideo2VisionTower
+    torch.manual_seed(3)
+    cfg = InternVideo2VisionConfig(num_hidden_layers=3)          # depth = 3 - 2 + 1 = 2
+    tower = InternVideo2VisionTower(cfg).eval()
+    with torch.no_grad():
+        for n, p in tower.named_parameters():
+            if n.endswith(("ls1.weight", "ls2.weight")):
+                p.fill_(0.5)
+            elif p.dim() > 1 and "pos_embed" not in n:
+                p.normal_(0, 0.02)
+    px = torch.randn(4, 1, 3, 224, 224)
+    sd = {k: v.detach().bfloat16().float() for k, v in tower.vision_tower.state_dict().items()}
+    ref = ov.internvideo2_tower_ref(sd, px.bfloat16().float(), 16, is_video=True)
+    out = tower.to(DEV).bfloat16()(px.to(DEV).bfloat16(), is_video=True)
+    assert out.shape == (1, 4 * 256, 1408)
+    assert relerr(out, ref) < 2e-2
+
+
 def test_vlm_end_to_end_tiny():
     """pixels -> ViT -> ToMe+MLP -> fusion -> hybrid LM with pdrop+TransV; composite oracle."""
     from timeviper_amd.model import build_synthetic_timeviper

@@ -178,3 +178,14 @@ def test_fused_embedding_layout_matches_reference():
     close(f, g["fused"], 0, 0)
     f2 = om.fuse_embeddings_ref(T(g["ids2"]), T(g["vis"]), T(g["emb_w"]), tok)
     close(f2, g["fused2"], 0, 0)
+
+
+@pytest.mark.parametrize("case,is_video", [("video", True), ("video_b2", True), ("images", False)])
+def test_internvideo2_tower_matches_reference(case, is_video):
+    """G10: includes the (T,B,...)->4-frame-clip regrouping of model.py:178-182 on a
+    T=8, B=1 input, where the reference's reshape interleaves channels and frames."""
+    from oracle import vit as ov
+    g = load_golden("internvideo2")
+    out = ov.internvideo2_tower_ref(golden_state_dict(g), T(g[case]), int(g["num_heads"]),
+                                    is_video=is_video)
+    close(out, g[case + "_out"], 1e-4, 2e-5)

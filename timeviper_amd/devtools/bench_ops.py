@@ -102,6 +102,22 @@ def main():
         fl = 2 * 256 * 729 * 588 * 1152
         by = pix.numel() * 2 + 256 * 729 * 1152 * 2
         print(f"patch embed 256 frames {ms:9.2f} ms  {fl/ms/1e9:8.1f} TFLOP/s  {by/ms/1e6:8.1f} GB/s")
+    if "iv2" in ops:
+        from timeviper_amd.model.vit.internvideo2 import InternVideo2ViTBackbone
+        with torch.device("meta"):
+            vb = InternVideo2ViTBackbone()
+        vb = vb.to_empty(device=dev)
+        with torch.no_grad():
+            for n, p in vb.named_parameters():
+                if n.endswith(("ls1.weight", "ls2.weight")) or "norm" in n:
+                    p.fill_(1.0 if "norm" in n else 0.1)
+                else:
+                    p.normal_(0, 0.02, generator=g)
+        vb = vb.bfloat16().eval()
+        clip = rn(256, 1, 3, 224, 224)
+        ms = timeit(lambda: vb(clip, is_video=True), iters=3, warmup=1)
+        print(f"InternVideo2-1B tower, 256 frames (64 clips x 1025 tokens) {ms:9.2f} ms  "
+              f"{256/ms*1e3:8.1f} frames/s")
 
 
 if __name__ == "__main__":

@@ -8,12 +8,17 @@ import torch
 
 from .generic_vlm import GenericTimeViperVLM, HybridTimeViperVLM
 from .llm import GenericLLMBackbone, NemotronHConfig
-from .vit import TimmViTBackbone, VisionBackbone
+from .vit import (InternVideo2ViTBackbone, TimmViTBackbone, VisionBackbone,
+                  get_vision_backbone_config)
 
 
 def get_vision_backbone_and_transform(vision_backbone_id: str, image_resize_strategy: str = "resize-naive",
                                       use_zero3: bool = False, **kw):
-    vb = TimmViTBackbone(vision_backbone_id, image_resize_strategy, **kw)
+    cfg = get_vision_backbone_config(vision_backbone_id)
+    if cfg["type"] == "internvideo2":
+        vb = InternVideo2ViTBackbone(vision_backbone_id, image_resize_strategy, **kw)
+    else:
+        vb = TimmViTBackbone(vision_backbone_id, image_resize_strategy, **kw)
     return vb, vb.get_image_transform()
 
 

@@ -18,12 +18,20 @@ VISION_MODEL_REGISTRY = {
     "dinov2-vit-l": ("dinov2", "vit_large_patch14_reg4_dinov2.lvd142m", 224),
 }
 
+INTERNVIDEO2_REGISTRY = {      # registry.py:64-73
+    "internvideo2-1b-16-224px": {"default_image_size": 224, "num_frames": 4,
+                                 "vision_tower_path": "./ckpts/InternVideo2-1B_f4_vision.pt"},
+}
+
 
 def get_vision_backbone_config(vision_backbone_id: str) -> Dict[str, Any]:
     if vision_backbone_id in VISION_MODEL_REGISTRY:
         fam, timm_id, size = VISION_MODEL_REGISTRY[vision_backbone_id]
         return {"type": "timm", "timm_id": timm_id, "default_image_size": size,
                 "vision_family": fam, "identifier": fam}
+    if vision_backbone_id in INTERNVIDEO2_REGISTRY:
+        return {"type": "internvideo2", "vision_family": "internvideo2", "identifier": "internvideo2",
+                **INTERNVIDEO2_REGISTRY[vision_backbone_id]}
     raise ValueError(f"Vision Backbone `{vision_backbone_id}` is not supported!")
 
 
@@ -88,3 +96,7 @@ class TimmViTBackbone(VisionBackbone):
 
 
 TimmCheckpointBackbone = TimmViTBackbone
+
+
+from .internvideo2 import (InternVideo2ViTBackbone, InternVideo2VisionConfig,  # noqa: E402
+                           InternVideo2VisionTower)
