@@ -445,3 +445,6 @@ def test_layernorm_and_gelu(K, dtype):
     close(y2, torch.nn.functional.layer_norm(s_ref.float(), (D,), w.float(), b.float(), 1e-6), *TOL[dtype])
     h = (torch.randn(33, 4304 * 2, generator=g) * 2).to(dtype)
     close(K.gelu(h.to(DEV)), torch.nn.functional.gelu(h.float()), *TOL[dtype])
+    for n in (1, 7, 279 * 17):                       # ragged sizes (InternVideo2 toy MLP width 279)
+        r = (torch.randn(n, generator=g) * 2).to(dtype)
+        close(K.gelu(r.to(DEV)), torch.nn.functional.gelu(r.float()), *TOL[dtype])

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(NORM_THREADS) void layernorm_kernel(
 // exact (erf) GELU, elementwise, 16 bytes per lane, grid-stride
 template <typename T>
 __global__ __launch_bounds__(256) void gelu_kernel(const T* __restrict__ x, T* __restrict__ y,
-                                                   int64_t nvec) {
+                                                   int64_t nvec, int64_t n) {
   constexpr int V = Vec16<T>::N;
   typedef typename Vec16<T>::type vec_t;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
@@ -152,6 +152,13 @@ __global__ __launch_bounds__(256) void gelu_kernel(const T* __restrict__ x, T* _
       o[j] = from_f32<T>(0.5f * f * (1.f + erff(f * 0.70710678118654752f)));
     }
     *(vec_t*)(y + i * V) = o;
+  }
+  if (blockIdx.x == 0) {   // ragged tail (< one vector)
+    const int64_t i = nvec * V + threadIdx.x;
+    if (i < n) {
+      const float f = to_f32(x[i]);
+      y[i] = from_f32<T>(0.5f * f * (1.f + erff(f * 0.70710678118654752f)));
+    }
   }
 }
 
@@ -343,14 +350,14 @@ extern "C" int tv_gelu_fwd(const void* x, void* y, int64_t n, int dtype, void* s
   TV_CHECK_ARG(n >= 0, "gelu: bad size");
   if (n == 0) return TV_OK;
   const int vec = dtype == TV_F32 ? 4 : 8;
-  if (n % vec || !aligned16(x) || !aligned16(y)) TV_UNSUPPORTED("gelu: size/pointers must be 16-byte multiples");
+  if (!aligned16(x) || !aligned16(y)) TV_UNSUPPORTED("gelu: pointers must be 16-byte aligned");
   const int64_t nvec = n / vec;
-  const unsigned grid = (unsigned)((nvec + 255) / 256 < 16384 ? (nvec + 255) / 256 : 16384);
+  const unsigned grid = (unsigned)((nvec + 255) / 256 < 16384 ? (nvec + 255) / 256 + (nvec == 0) : 16384);
   hipStream_t s = (hipStream_t)stream;
   switch (dtype) {
-    case TV_F32: gelu_kernel<float><<<grid, 256, 0, s>>>((const float*)x, (float*)y, nvec); break;
-    case TV_BF16: gelu_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)x, (bf16_t*)y, nvec); break;
-    case TV_F16: gelu_kernel<f16_t><<<grid, 256, 0, s>>>((const f16_t*)x, (f16_t*)y, nvec); break;
+    case TV_F32: gelu_kernel<float><<<grid, 256, 0, s>>>((const float*)x, (float*)y, nvec, n); break;
+    case TV_BF16: gelu_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)x, (bf16_t*)y, nvec, n); break;
+    case TV_F16: gelu_kernel<f16_t><<<grid, 256, 0, s>>>((const f16_t*)x, (f16_t*)y, nvec, n); break;
     default: TV_UNSUPPORTED("gelu: dtype %d", dtype);
   }
   TV_LAUNCH_CHECK();
