@@ -149,7 +149,7 @@ def run_scan(K, x, dt, A, Bm, Cm, D, dt_bias, **kw):
                                        return_final_states=True, return_total_decay=True, **kw)
 
 
-@pytest.mark.parametrize("impl", [1, 0])
+@pytest.mark.parametrize("impl", [1, 0, 2, 3])
 @pytest.mark.parametrize("dtype,B,L,H,P,G,N", [
     (torch.float32, 1, 1024, 32, 64, 1, 16),      # BASELINE config 1
     (torch.float32, 2, 77, 8, 8, 2, 16),
@@ -159,6 +159,8 @@ def run_scan(K, x, dt, A, Bm, Cm, D, dt_bias, **kw):
     (torch.bfloat16, 1, 1, 8, 80, 1, 128),
 ])
 def test_ssd_scan(K, impl, dtype, B, L, H, P, G, N):
+    if impl >= 2 and dtype != torch.bfloat16:
+        pytest.skip("MFMA march kernels are bf16 / d_state 128")
     K.ssd_scan_set_impl(impl)
     try:
         ins = scan_inputs(B, L, H, P, G, N, L + H, dtype)
@@ -190,6 +192,29 @@ def test_ssd_scan_initial_state_and_sharding(K, dtype, H, P, G, N):
     f = [t.float() for t in ins]
     _, fin_ref, _ = R.ssd_recurrence_ref(*f[:5], D=f[5], dt_bias=f[6])
     close(f1, fin_ref, rt, at)
+
+
+@pytest.mark.parametrize("impl", [2, 3])
+@pytest.mark.parametrize("B,L,H,P,G", [(1, 1000, 16, 80, 8), (2, 449, 8, 64, 2), (1, 64, 4, 48, 1),
+                                       (1, 2049, 8, 80, 4), (1, 130, 4, 128, 2), (1, 65, 6, 24, 3)])
+def test_ssd_scan_march_kernels(K, impl, B, L, H, P, G):
+    """both MFMA march kernels (forced): long sequences, ragged tails, several slice widths,
+    initial state in, final state / total decay out, 'tile' head->group map."""
+    K.ssd_scan_set_impl(impl)
+    try:
+        ins = scan_inputs(B, L, H, P, G, 128, 3 * L + H, torch.bfloat16)
+        g = torch.Generator().manual_seed(L)
+        init = torch.randn(B, H, P, 128, generator=g)
+        f = [t.float() for t in ins]
+        for gmap in ("block", "tile"):
+            y_ref, fin_ref, dec_ref = R.ssd_recurrence_ref(*f[:5], D=f[5], dt_bias=f[6],
+                                                           initial_states=init, group_map=gmap)
+            y, fin, dec = run_scan(K, *ins, initial_states=init.to(DEV), group_map=gmap)
+            close(y, y_ref, 2e-2, 4e-2, f"y {gmap}")
+            close(fin, fin_ref, 2e-2, 2e-2, f"final state {gmap}")
+            close(dec, dec_ref, 1e-4, 1e-4, "total decay")
+    finally:
+        K.ssd_scan_set_impl(0)
 
 
 def test_ssd_scan_golden_and_group_maps(K):

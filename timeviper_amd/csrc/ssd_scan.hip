@@ -26,14 +26,31 @@ int tv_ssd_march_launch(const void* x, const void* dt, const void* A, const void
                         int dtype, int dt_softplus, float dt_min, float dt_max, int group_map,
                         void* workspace, size_t workspace_bytes, hipStream_t st);
 
+// ssd_slice.hip
+bool tv_ssd_slice_supported(int seqlen, int nheads, int headdim, int ngroups, int dstate,
+                            int dtype, int64_t xsl, int64_t bsl, int64_t bsg, int64_t csl, int64_t csg, int64_t ysl,
+                            const void* x, const void* Bm, const void* Cm, const void* y);
+size_t tv_ssd_slice_workspace_bytes(int batch, int seqlen, int nheads, int headdim, int ngroups,
+                                    int dstate);
+int tv_ssd_slice_launch(const void* x, const void* dt, const void* A, const void* Bm,
+                        const void* Cm, const void* D, const void* dt_bias,
+                        const void* init_state, void* y, void* final_state, void* total_decay,
+                        int batch, int seqlen, int nheads, int headdim, int ngroups, int dstate,
+                        int64_t xsb, int64_t xsl, int64_t dsb, int64_t dsl, int64_t bsb,
+                        int64_t bsl, int64_t bsg, int64_t csb, int64_t csl, int64_t csg, int64_t ysb, int64_t ysl,
+                        int dtype, int dt_softplus, float dt_min, float dt_max, int group_map,
+                        void* workspace, size_t workspace_bytes, hipStream_t st);
+
+// 0 auto, 1 generic recurrence, 2 chunk march (ssd_march.hip), 3 slice march (ssd_slice.hip)
 static int g_ssd_impl = 0;
+static const int kAutoImpl = 2;
 
 extern "C" void tv_ssd_scan_set_impl(int impl) { g_ssd_impl = impl; }
 
 extern "C" size_t tv_ssd_scan_workspace_bytes(int batch, int seqlen, int nheads, int headdim,
                                               int ngroups, int dstate, int dtype) {
-  if (dtype == TV_F32) return 0;
-  return tv_ssd_march_workspace_bytes(batch, seqlen, nheads, headdim, ngroups, dstate);
+  if (dtype != TV_BF16 || dstate != 128) return 0;
+  return tv_ssd_slice_workspace_bytes(batch, seqlen, nheads, headdim, ngroups, dstate);
 }
 
 extern "C" int tv_ssd_scan_fwd(const void* x, const void* dt, const void* A, const void* Bm,
@@ -68,8 +85,19 @@ extern "C" int tv_ssd_scan_fwd(const void* x, const void* dt, const void* A, con
                (((uintptr_t)dt) & 3) == 0 &&
                tv_ssd_march_supported(seqlen, nheads, headdim, ngroups, dstate, dtype, x_stride_l,
                                       b_stride_l, b_stride_g, c_stride_l, c_stride_g, y_stride_l, x, Bm, Cm, y);
-  if (g_ssd_impl == 2 && !march)
+  if (g_ssd_impl >= 2 && !march)
     TV_UNSUPPORTED("ssd_scan: MFMA march kernel forced but shape/dtype unsupported");
+  const int impl = g_ssd_impl ? g_ssd_impl : kAutoImpl;
+  if (march && impl == 3 && workspace &&
+      tv_ssd_slice_supported(seqlen, nheads, headdim, ngroups, dstate, dtype, x_stride_l,
+                             b_stride_l, b_stride_g, c_stride_l, c_stride_g, y_stride_l, x, Bm, Cm, y)) {
+    return tv_ssd_slice_launch(x, dt, A, Bm, Cm, D, dt_bias, init_state, y, final_state,
+                               total_decay, batch, seqlen, nheads, headdim, ngroups, dstate,
+                               x_stride_b, x_stride_l, dt_stride_b, dt_stride_l, b_stride_b,
+                               b_stride_l, b_stride_g, c_stride_b, c_stride_l, c_stride_g, y_stride_b, y_stride_l, dtype,
+                               dt_softplus, dt_min, dt_max, group_map, workspace, workspace_bytes,
+                               st);
+  }
   if (march) {
     return tv_ssd_march_launch(x, dt, A, Bm, Cm, D, dt_bias, init_state, y, final_state,
                                total_decay, batch, seqlen, nheads, headdim, ngroups, dstate,

@@ -308,7 +308,8 @@ def selective_state_update(state, x, dt, A, B, C, D=None, z=None, dt_bias=None,
 
 
 def ssd_scan_set_impl(impl: int) -> None:
-    """0 auto, 1 generic fp32-recurrence kernel, 2 MFMA chunk-march kernel."""
+    """0 auto, 1 generic fp32-recurrence kernel, 2 MFMA chunk-march kernel, 3 MFMA slice-march
+    kernel (C.B^T pre-pass + state-in-accumulator slice waves)."""
     _capi.lib().tv_ssd_scan_set_impl(int(impl))
 
 
