@@ -34,7 +34,7 @@ constexpr int SQ = 64;           // tokens per chunk
 constexpr int SN = 128;          // d_state
 constexpr int STHREADS = 768;    // 12 waves
 constexpr int NB = 3;            // B/C ring slots (prefetch distance 2 chunks)
-constexpr int DXS = 3;           // x prefetch distance (chunks); dt runs one chunk further
+constexpr int DXS = 4;           // x prefetch distance (chunks); dt runs one chunk further
 constexpr int NXS = DXS + 1;     // x ring slots
 constexpr int NDT = NXS + 2;     // raw-dt ring slots
 constexpr int NV = 3;            // cs / ecs / dt / weight vector buffers
@@ -109,12 +109,22 @@ struct SliceArgs {
   int64_t xsb, xsl, dsb, dsl, bsb, bsl, bsg, csb, csl, csg, ysb, ysl;
   int softplus, group_map;
   float dt_min, dt_max;
+  int dbg;
 };
+
+// -DTV_MARCH_ABLATE builds ablation switches (env TV_MARCH_DBG) into the kernel:
+// 1 slice-waves idle, 2 no B/C copies, 4 no x copies / y stores, 8 no mask build,
+// 16 no x~ / prep, 32 slice-waves: no state update, 64: no Yoff, 128: no Ydiag/epilogue
+#ifdef TV_MARCH_ABLATE
+#define SDBG(a, bit) ((a).dbg & (bit))
+#else
+#define SDBG(a, bit) 0
+#endif
 
 template <int PW>
 struct __attribute__((aligned(16))) SliceSmem {
   static constexpr int XSLOT = SQ * PW + 64;   // + finite guard (the last tile reads past PW)
-  bf16_t bt[NB][SQ * SN];     // B tiles [t][n], 16-byte chunks XOR-swizzled for ds_read_b64_tr
+  bf16_t bt[NB][SQ * SN];     // B tiles [t][n], 16-byte chunk index ^ 4(t & 3) (ds_read_b64_tr)
   bf16_t ct[NB][SQ * SN];     // C tiles [t][n], chunks XOR-swizzled for row reads
   bf16_t xr[NXS][XSLOT];      // x tiles [t][PW]
   bf16_t xs[2][XSLOT];        // x~ = exp(cs_Q - cs_t) dt_t x
@@ -122,24 +132,49 @@ struct __attribute__((aligned(16))) SliceSmem {
   bf16_t yt[2][SQ * PW];      // y tiles [t][PW]
   unsigned dtr[NDT][SQ];      // raw dt of heads (h&~1, h|1)
   unsigned pad_[SQ];
-  float cs[NV][SQ];           // inclusive cumsum of dt*A inside the chunk
+  float cs[NV][SQ];           // inclusive cumsum of dt*A inside the chunk, times log2(e)
   float ecs[NV][SQ];          // exp(cs)
   float dtv[NV][SQ];          // discretised dt
   float wts[NV][SQ];          // exp(cs_last - cs_t) * dt_t
   float dl[NV][4];            // exp(cs_last)
 };
 
+__device__ __forceinline__ unsigned lds_lane_addr(const void* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) void*)p;
+}
+// (a ^ k) + b in one VALU op (k: wave-uniform)
+__device__ __forceinline__ int xad(int a, int k, int b) {
+  int d;
+  asm("v_xad_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(k), "v"(b));
+  return d;
+}
+
 // wave roles
 constexpr int W_XIO = 3;                         // x / dt DMA + y stores
-__device__ __forceinline__ int bc_index(int w) { return w == 4 ? 0 : w == 5 ? 1 : w == 6 ? 2 : w == 8 ? 3 : -1; }
-__device__ __forceinline__ int mask_index(int w) { return w == 7 ? 0 : w == 11 ? 1 : -1; }
+// (waves w, w+4, w+8 share a SIMD: the two mask waves, the heaviest VALU helpers, sit on
+// different SIMDs; SIMD 3 has no slice-wave)
+__device__ __forceinline__ int bc_index(int w) { return w == 4 ? 0 : w == 5 ? 1 : w == 6 ? 2 : w == 11 ? 3 : -1; }
+__device__ __forceinline__ int mask_index(int w) { return w == 7 ? 0 : w == 8 ? 1 : -1; }
 __device__ __forceinline__ int scale_index(int w) { return w == 9 ? 0 : w == 10 ? 1 : -1; }
 
+// -DTV_SLICE_STAMP: every wave of workgroup 0 sums the cycles it spends parked at the step
+// barrier (s_memtime); tv_ssd_slice_debug_stamps() returns {wait[16], total[16]}.
+#ifdef TV_SLICE_STAMP
+__device__ unsigned long long g_slice_stamps[32];
+#define SLICE_BARRIER()                                   \
+  do {                                                    \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
+    const unsigned long long ta__ = clock64();            \
+    __builtin_amdgcn_s_barrier();                         \
+    stamp_wait += clock64() - ta__;                       \
+  } while (0)
+#else
 #define SLICE_BARRIER()                                   \
   do {                                                    \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
     __builtin_amdgcn_s_barrier();                         \
   } while (0)
+#endif
 
 template <int PT, int PW>
 __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
@@ -160,6 +195,10 @@ __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
   const int p_base = slice * PW;
   const int L = a.L, nchunks = a.nchunks;
 
+#ifdef TV_SLICE_STAMP
+  unsigned long long stamp_wait = 0;
+  const unsigned long long stamp_t0 = clock64();
+#endif
   {   // zero LDS once: guards / pad columns must hold finite values
     bf16x8 z = {};
     for (int i = tid; i < (int)(sizeof(Smem) / 16); i += STHREADS)
@@ -170,8 +209,8 @@ __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
   // The prologue fills the pipeline with three barriers (P1: first tiles landed, P2: chunks
   // 0/1 prepared, P3: x~_0 and M_0 built); then every role runs nchunks steps with one
   // barrier each.  At step c the slice-waves consume chunk c while the helpers produce
-  // x~_{c+1}, M_{c+1}, the vectors of chunk c+2, issue B/C of chunk c+2, x of chunk c+3,
-  // dt of chunk c+4 and store y_{c-1}.
+  // x~_{c+1}, M_{c+1}, the vectors of chunk c+2, issue B/C of chunk c+2, x of chunk c+4,
+  // dt of chunk c+5 and store y_{c-1}.
   if (wave < PT) {
     // ============================================================ slice-wave (16 columns)
     const int j = wave;
@@ -184,19 +223,17 @@ __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
     if (a.init && pvalid) {
 #pragma unroll
       for (int i = 0; i < 8; ++i)
-        xacc[i] = *(const f32x4*)(a.init + (((int64_t)b * a.H + h) * a.P + p_base + pcol) * SN + 16 * i + 4 * kq);
+        xacc[i] = *(const f32x4*)(a.init + (((int64_t)b * a.H + h) * a.P + p_base + pcol) * SN + 32 * (i >> 1) + 8 * kq + 4 * (i & 1));
     }
-    // C row fragments with the accumulator's k order: slots 0..3 = n 32m+4kq.., 4..7 = +16
-    const int c_lo = lc * 256 + (kq & 1) * 8;
-    int c_sw[4][2];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      c_sw[m][0] = c_lo + ((((4 * m + (kq >> 1)) ^ lc)) << 4);
-      c_sw[m][1] = c_lo + ((((4 * m + 2 + (kq >> 1)) ^ lc)) << 4);
-    }
-    // transposing reads of B: row t = 32ks + 8kq + q4 (+4), chunk (2i + p4/2) ^ s(t)
-    const int bsw = (2 * q4 + 8 * (kq & 1)) << 4;
-    const int b_lo = (8 * kq + q4) * 256 + (p4 >> 1) * 16 + (p4 & 1) * 8;
+    // State tiles 2m / 2m+1 hold the state rows n = 32m + 8kq + r / + 4 + r (r = accumulator
+    // register), so the pair is, as a B operand, the k slots n = 32m + 8kq + 0..7 — the order
+    // of a plain 16-byte row read of C.  16-byte chunk (4m + kq) ^ (t & 15) = 4m ^ c_z.
+    const int c_lo = lc * 256;
+    const int c_z = (kq ^ lc) << 4;
+    // transposing reads of B for tiles 2m, 2m+1: row t = 32ks + 8kq + q4 (+4), 8 bytes at
+    // chunk (4m + p4) ^ 4(t & 3), half = tile parity  ->  ((m ^ q4) << 6) + 16 p4 + 8 odd
+    const int bsw = q4 << 6;
+    const int b_lo = (8 * kq + q4) * 256 + p4 * 16;
     // transposing reads of x / x~ (B operand: k = token) and of x in accumulator layout
     const int trx = ((8 * kq + q4) * PW + 4 * p4) * 2 + j * 32;
     const int trd = ((4 * kq + q4) * PW + 4 * p4) * 2 + j * 32;
@@ -210,58 +247,134 @@ __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
       const unsigned char* xt = reinterpret_cast<const unsigned char*>(sm.xr[c % NXS]);
       const unsigned char* xw = reinterpret_cast<const unsigned char*>(sm.xs[c & 1]);
       const unsigned char* Mf = reinterpret_cast<const unsigned char*>(sm.M[c & 1]);
-      // state at the chunk start as B operands (k = n in accumulator order)
-      bf16x8 sb[4];
+      if (SDBG(a, 1)) { SLICE_BARRIER(); continue; }
+      typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+      typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+      typedef __attribute__((ext_vector_type(2))) float f32x2;
+      // Software pipeline in quarters.  Quarter q takes the 32 state rows n in [32q, 32q+32)
+      // (accumulator tiles 2q, 2q+1): it snapshots them as a bf16 B operand, adds their
+      // share C[:, block q] . X[block q] to the four Yoff tiles, then advances them with
+      // B^T x~.  The C columns and B tiles of quarter q+1 are read while quarter q computes
+      // (LDS returns in order, waits are counted); the scheduling fences keep hipcc from
+      // sinking those reads back next to their uses.
+      auto read_cq = [&](int q, bf16x8 (&cf)[4]) {     // [t-tile]
+        const unsigned char* cp = Ct + xad(c_z, 64 * q, c_lo);
 #pragma unroll
-      for (int m = 0; m < 4; ++m)
+        for (int ti = 0; ti < 4; ++ti) cf[ti] = ld8(cp + ti * 4096);
+      };
+      auto read_b2 = [&](int i0, bf16x4 (&dst)[2][4]) {   // tiles i0 = 2m, i0 + 1
+        const unsigned char* bp = Bt + xad(bsw, 32 * i0, b_lo);
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            dst[ii][2 * ks] = tr4(bp + ii * 8 + ks * 8192);
+            dst[ii][2 * ks + 1] = tr4(bp + ii * 8 + ks * 8192 + 1024);
+          }
+      };
+      f32x4 yo[4];
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti) yo[ti] = f32x4{0.f, 0.f, 0.f, 0.f};
+      auto quarter = [&](int q, const bf16x8 (&cf)[4], const bf16x4 (&bt2)[2][4],
+                         const bf16x8 (&xwf)[2], float dl) {
+        bf16x8 sbq;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          sb[m][r] = (bf16_t)xacc[2 * m][r];
-          sb[m][4 + r] = (bf16_t)xacc[2 * m + 1][r];
+          sbq[r] = (bf16_t)xacc[2 * q][r];
+          sbq[4 + r] = (bf16_t)xacc[2 * q + 1][r];
         }
-      // x fragments (k = token), raw and weighted
-      bf16x8 xf[2], xwf[2];
+        if (!SDBG(a, 64))
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) yo[ti] = mfma16(cf[ti], sbq, yo[ti]);
+        if (SDBG(a, 32)) return;
+        const f32x2 dl2 = {dl, dl};
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {   // v_pk_mul_f32: two state values per instruction
+          f32x2 a0 = {xacc[2 * q + ii][0], xacc[2 * q + ii][1]}, a1 = {xacc[2 * q + ii][2], xacc[2 * q + ii][3]};
+          a0 *= dl2;
+          a1 *= dl2;
+          xacc[2 * q + ii] = f32x4{a0[0], a0[1], a1[0], a1[1]};
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int ii = 0; ii < 2; ++ii)
+            xacc[2 * q + ii] = mfma16(cat4(bt2[ii][2 * ks], bt2[ii][2 * ks + 1]), xwf[ks], xacc[2 * q + ii]);
+      };
+      bf16x8 cq[2][4];
+      bf16x4 bq[2][2][4];
+      // ---- first reads
+      read_cq(0, cq[0]);
+      bf16x4 xq[2][2], xwq[2][2];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        xf[ks] = cat4(tr4(xt + trx + ks * (32 * PW * 2)), tr4(xt + trx + ks * (32 * PW * 2) + 4 * PW * 2));
-        xwf[ks] = cat4(tr4(xw + trx + ks * (32 * PW * 2)), tr4(xw + trx + ks * (32 * PW * 2) + 4 * PW * 2));
+        xwq[ks][0] = tr4(xw + trx + ks * (32 * PW * 2));
+        xwq[ks][1] = tr4(xw + trx + ks * (32 * PW * 2) + 4 * PW * 2);
       }
-      // X = exp(cs_Q) X + B^T x~
       const float dl = sm.dl[vb][0];
+      read_b2(0, bq[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      read_cq(1, cq[1]);
+      read_b2(2, bq[1]);
+      const bf16x8 xwf[2] = {cat4(xwq[0][0], xwq[0][1]), cat4(xwq[1][0], xwq[1][1])};
+      quarter(0, cq[0], bq[0], xwf, dl);
+      __builtin_amdgcn_sched_barrier(0);
+      read_cq(2, cq[0]);
+      read_b2(4, bq[0]);
+      quarter(1, cq[1], bq[1], xwf, dl);
+      __builtin_amdgcn_sched_barrier(0);
+      read_cq(3, cq[1]);
+      read_b2(6, bq[1]);
+      quarter(2, cq[0], bq[0], xwf, dl);
+      __builtin_amdgcn_sched_barrier(0);
+      // epilogue operands in flight under the last quarter
+      bf16x8 mf[NFRAG];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) xacc[i][r] *= dl;
-        const int bo = b_lo + ((32 * i) ^ bsw);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const bf16x8 bf = cat4(tr4(Bt + bo + ks * 8192), tr4(Bt + bo + ks * 8192 + 1024));
-          xacc[i] = mfma16(bf, xwf[ks], xacc[i]);
-        }
-      }
-      // y tile: Yoff (state at chunk start) + Ydiag + D x
+      for (int f = 0; f < NFRAG; ++f) mf[f] = ld8(Mf + f * 1024 + lane * 16);
+      f32x4 ev[4];
+      bf16x4 xv[4];
 #pragma unroll
       for (int ti = 0; ti < 4; ++ti) {
-        f32x4 yo = {0.f, 0.f, 0.f, 0.f}, yd = yo;
+        ev[ti] = *(const f32x4*)(&sm.ecs[vb][16 * ti + 4 * kq]);
+        xv[ti] = tr4(xt + trd + ti * (16 * PW * 2));
+      }
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-          const u32x2 lo = *(const u32x2*)(Ct + ti * 4096 + c_sw[m][0]);
-          const u32x2 hi = *(const u32x2*)(Ct + ti * 4096 + c_sw[m][1]);
-          typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-          const u32x4 w = {lo[0], lo[1], hi[0], hi[1]};
-          yo = mfma16(__builtin_bit_cast(bf16x8, w), sb[m], yo);
+      for (int ks = 0; ks < 2; ++ks) {
+        xq[ks][0] = tr4(xt + trx + ks * (32 * PW * 2));
+        xq[ks][1] = tr4(xt + trx + ks * (32 * PW * 2) + 4 * PW * 2);
+      }
+      quarter(3, cq[1], bq[1], xwf, dl);
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- y = exp(cs_t) Yoff + M x + D x  (Ydiag accumulates onto the scaled Yoff)
+      const bf16x8 xf[2] = {cat4(xq[0][0], xq[0][1]), cat4(xq[1][0], xq[1][1])};
+      if (!SDBG(a, 128)) {
+        const f32x2 dh2 = {Dh, Dh};
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) {
+          const unsigned x01 = __builtin_bit_cast(u32x2, xv[ti])[0], x23 = __builtin_bit_cast(u32x2, xv[ti])[1];
+          f32x2 y0 = {yo[ti][0], yo[ti][1]}, y1 = {yo[ti][2], yo[ti][3]};
+          y0 = __builtin_elementwise_fma(y0, f32x2{ev[ti][0], ev[ti][1]}, dh2 * f32x2{bf16_lo(x01), bf16_hi(x01)});
+          y1 = __builtin_elementwise_fma(y1, f32x2{ev[ti][2], ev[ti][3]}, dh2 * f32x2{bf16_lo(x23), bf16_hi(x23)});
+          yo[ti] = f32x4{y0[0], y0[1], y1[0], y1[1]};
         }
-        const int f0 = ti == 0 ? 0 : ti == 1 ? 1 : ti == 2 ? 2 : 4;
-        yd = mfma16(ld8(Mf + f0 * 1024 + lane * 16), xf[0], yd);
-        if (ti >= 2) yd = mfma16(ld8(Mf + (f0 + 1) * 1024 + lane * 16), xf[1], yd);
-        const f32x4 e = *(const f32x4*)(&sm.ecs[vb][16 * ti + 4 * kq]);
-        const bf16x4 xv = tr4(xt + trd + ti * (16 * PW * 2));
-        if (pvalid) {
-          bf16_t* yrow = sm.yt[c & 1] + (16 * ti + 4 * kq) * PW + pcol;
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            yrow[r * PW] = (bf16_t)(yd[r] + e[r] * yo[r] + Dh * (float)xv[r]);
+        for (int ti = 0; ti < 4; ++ti) {
+          const int f0 = ti == 0 ? 0 : ti == 1 ? 1 : ti == 2 ? 2 : 4;
+          yo[ti] = mfma16(mf[f0], xf[0], yo[ti]);
+          if (ti >= 2) yo[ti] = mfma16(mf[f0 + 1], xf[1], yo[ti]);
+        }
+        if (pvalid) {
+#pragma unroll
+          for (int ti = 0; ti < 4; ++ti) {
+            // two bf16 per v_cvt_pk; low / high halves go out as ds_write_b16 / _d16_hi
+            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+            const unsigned ya = lds_lane_addr(sm.yt[c & 1] + (16 * ti + 4 * kq) * PW + pcol);
+            const bf16x2 p01 = {(bf16_t)yo[ti][0], (bf16_t)yo[ti][1]}, p23 = {(bf16_t)yo[ti][2], (bf16_t)yo[ti][3]};
+            const unsigned w01 = __builtin_bit_cast(unsigned, p01), w23 = __builtin_bit_cast(unsigned, p23);
+            asm volatile("ds_write_b16 %0, %1\n\tds_write_b16_d16_hi %0, %1 offset:%3\n\t"
+                         "ds_write_b16 %0, %2 offset:%4\n\tds_write_b16_d16_hi %0, %2 offset:%5"
+                         :: "v"(ya), "v"(w01), "v"(w23), "n"(PW * 2), "n"(PW * 4), "n"(PW * 6) : "memory");
+          }
         }
       }
       SLICE_BARRIER();
@@ -269,7 +382,7 @@ __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
     if (a.final_state && pvalid) {
 #pragma unroll
       for (int i = 0; i < 8; ++i)
-        *(f32x4*)(a.final_state + (((int64_t)b * a.H + h) * a.P + p_base + pcol) * SN + 16 * i + 4 * kq) = xacc[i];
+        *(f32x4*)(a.final_state + (((int64_t)b * a.H + h) * a.P + p_base + pcol) * SN + 32 * (i >> 1) + 8 * kq + 4 * (i & 1)) = xacc[i];
     }
     SLICE_BARRIER();   // final (y of the last chunk is stored after it)
   } else if (wave == W_XIO) {
@@ -320,15 +433,15 @@ __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
     SLICE_BARRIER();   // P2
     SLICE_BARRIER();   // P3
     for (int c = 0; c < nchunks; ++c) {
-      if (c > 0) store_y(c - 1);
-      const bool issued = c + DXS < nchunks;
+      if (c > 0 && !SDBG(a, 4)) store_y(c - 1);
+      const bool issued = c + DXS < nchunks && !SDBG(a, 4);
       if (issued) {
         issue_x(c + DXS);
         issue_dt(c + DXS + 1);
       }
-      // x of chunk c+2 and dt of chunk c+3 (issued a step ago) must have landed: since then
-      // this wave issued NPI stores + NPI + 1 copies
-      if (issued && c > 0 && (c + 1) * SQ <= L) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPI + 1) : "memory");
+      // x of chunk c+2 and dt of chunk c+3 (issued two steps ago) must have landed: since
+      // then this wave issued 2 x (NPI stores + NPI + 1 copies) — two steps of flight time
+      if (issued && c > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (2 * NPI + 1)) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       SLICE_BARRIER();
     }
@@ -346,7 +459,7 @@ __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
     for (int k = 0; k < 4; ++k) {
       const int row = 16 * q + 4 * k + (lane >> 4);
       brow[k] = row;
-      cg_b[k] = (lane & 15) ^ (2 * (row & 3) + 8 * ((row >> 3) & 1));
+      cg_b[k] = (lane & 15) ^ (4 * (row & 3));
       cg_c[k] = (lane & 15) ^ (row & 15);
       off_b[k] = (unsigned)((row * a.bsl + cg_b[k] * 8) * 2);
       off_c[k] = (unsigned)((row * a.csl + cg_c[k] * 8) * 2);
@@ -376,7 +489,7 @@ __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
     SLICE_BARRIER();   // P2
     SLICE_BARRIER();   // P3
     for (int c = 0; c < nchunks; ++c) {
-      const bool issued = c + 2 < nchunks;
+      const bool issued = c + 2 < nchunks && !SDBG(a, 2);
       if (issued) {
         issue_bc(c + 2);
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // chunk c+1 landed, c+2 in flight
@@ -390,41 +503,72 @@ __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
     // ============================================================ decay mask M = CB .* L
     const int mi = mask_index(wave);
     const bf16_t* cbg = a.cb + (((int64_t)b * a.G + g) * nchunks) * CB_ELEMS + lane * 8;
-    bf16x8 cbv[3];
-    auto load_cb = [&](int c) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    auto load_cb = [&](int c, bf16x8 (&cbv)[3]) {
 #pragma unroll
       for (int ff = 0; ff < 3; ++ff) cbv[ff] = *(const bf16x8*)(cbg + (int64_t)c * CB_ELEMS + (3 * mi + ff) * 512);
     };
-    auto build = [&](int c) {
+    // M[t][s] = CB[t][s] * 2^(cs2_t - cs2_s) * dt_s for s <= t, else 0 (cs2 = cs * log2 e; the
+    // exponent is <= 0 wherever it is used, masked entries get exponent -inf -> factor 0)
+    auto build = [&](int c, const bf16x8 (&cbv)[3]) {
       const int vb = c % NV;
+      float cst[3];
+      f32x4 cs_s[2][2], dt_s[2][2];
+#pragma unroll
+      for (int ff = 0; ff < 3; ++ff) cst[ff] = sm.cs[vb][16 * frag_ti(3 * mi + ff) + lc];
+#pragma unroll
+      for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          cs_s[sp][hh] = *(const f32x4*)(&sm.cs[vb][32 * sp + 8 * kq + 4 * hh]);
+          dt_s[sp][hh] = *(const f32x4*)(&sm.dtv[vb][32 * sp + 8 * kq + 4 * hh]);
+        }
 #pragma unroll
       for (int ff = 0; ff < 3; ++ff) {
         const int f = 3 * mi + ff;
-        const int t = 16 * frag_ti(f) + lc, s0 = 32 * frag_sp(f) + 8 * kq;
-        const float cst = sm.cs[vb][t];
-        const f32x4 ca = *(const f32x4*)(&sm.cs[vb][s0]), cb2 = *(const f32x4*)(&sm.cs[vb][s0 + 4]);
-        const f32x4 da = *(const f32x4*)(&sm.dtv[vb][s0]), db = *(const f32x4*)(&sm.dtv[vb][s0 + 4]);
+        const int sp = frag_sp(f);
+        const int t = 16 * frag_ti(f) + lc, s0 = 32 * sp + 8 * kq;
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+        const u32x4 cw = __builtin_bit_cast(u32x4, cbv[ff]);
         bf16x8 o;
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-          const float css = jj < 4 ? ca[jj & 3] : cb2[jj & 3];
-          const float dts = jj < 4 ? da[jj & 3] : db[jj & 3];
-          const float e = __expf(fminf(cst - css, 0.f));
-          o[jj] = (s0 + jj <= t) ? (bf16_t)((float)cbv[ff][jj] * e * dts) : (bf16_t)0.f;
+        for (int jp = 0; jp < 4; ++jp) {
+          const int j0 = 2 * jp, j1 = 2 * jp + 1;
+          const float a0 = (s0 + j0 <= t) ? cst[ff] - cs_s[sp][j0 >> 2][j0 & 3] : -__builtin_inff();
+          const float a1 = (s0 + j1 <= t) ? cst[ff] - cs_s[sp][j1 >> 2][j1 & 3] : -__builtin_inff();
+          const f32x2 e = {__builtin_amdgcn_exp2f(a0), __builtin_amdgcn_exp2f(a1)};
+          const f32x2 cd = f32x2{bf16_lo(cw[jp]), bf16_hi(cw[jp])} *
+                           f32x2{dt_s[sp][j0 >> 2][j0 & 3], dt_s[sp][j1 >> 2][j1 & 3]};
+          const f32x2 v = cd * e;
+          o[j0] = (bf16_t)v[0];
+          o[j1] = (bf16_t)v[1];
         }
         *(bf16x8*)(sm.M[c & 1] + f * 512 + lane * 8) = o;
       }
     };
-    load_cb(0);
+    // CB fragments are fetched two steps ahead into two register sets (A: even chunks,
+    // B: odd chunks), so a fetch has two steps of flight time
+    bf16x8 cbA[3], cbB[3];
+    load_cb(0, cbA);
+    load_cb(min(1, nchunks - 1), cbB);
     SLICE_BARRIER();   // P1
     SLICE_BARRIER();   // P2 (chunks 0/1 prepared)
-    build(0);
-    if (nchunks > 1) load_cb(1);
+    build(0, cbA);
+    load_cb(min(2, nchunks - 1), cbA);
     SLICE_BARRIER();   // P3
-    for (int c = 0; c < nchunks; ++c) {
-      if (c + 1 < nchunks) build(c + 1);
-      if (c + 2 < nchunks) load_cb(c + 2);
+    for (int c = 0; c < nchunks; c += 2) {
+      if (c + 1 < nchunks && !SDBG(a, 8)) {
+        build(c + 1, cbB);
+        load_cb(min(c + 3, nchunks - 1), cbB);
+      }
       SLICE_BARRIER();
+      if (c + 1 < nchunks) {
+        if (c + 2 < nchunks && !SDBG(a, 8)) {
+          build(c + 2, cbA);
+          load_cb(min(c + 4, nchunks - 1), cbA);
+        }
+        SLICE_BARRIER();
+      }
     }
     SLICE_BARRIER();   // final
   } else if (scale_index(wave) >= 0) {
@@ -439,18 +583,30 @@ __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
       const int vb = c % NV;
       const unsigned char* src = reinterpret_cast<const unsigned char*>(sm.xr[c % NXS]);
       unsigned char* dst = reinterpret_cast<unsigned char*>(sm.xs[c & 1]);
-      for (int k = k0; k < k1; ++k) {
-        const int i = lane + 64 * k;
-        const float w = sm.wts[vb][i / NPC];
-        const uint4 v = *(const uint4*)(src + i * 16);
-        const unsigned u[4] = {v.x, v.y, v.z, v.w};
-        bf16x8 o;
+      float w[KA];
+      uint4 v[KA];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          o[2 * e] = (bf16_t)(bf16_lo(u[e]) * w);
-          o[2 * e + 1] = (bf16_t)(bf16_hi(u[e]) * w);
+      for (int kk = 0; kk < KA; ++kk) {
+        const int k = k0 + kk;
+        if (k < k1) {
+          const int i = lane + 64 * k;
+          w[kk] = sm.wts[vb][i / NPC];
+          v[kk] = *(const uint4*)(src + i * 16);
         }
-        *(bf16x8*)(dst + i * 16) = o;
+      }
+#pragma unroll
+      for (int kk = 0; kk < KA; ++kk) {
+        const int k = k0 + kk;
+        if (k < k1) {
+          const unsigned u[4] = {v[kk].x, v[kk].y, v[kk].z, v[kk].w};
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            o[2 * e] = (bf16_t)(bf16_lo(u[e]) * w[kk]);
+            o[2 * e + 1] = (bf16_t)(bf16_hi(u[e]) * w[kk]);
+          }
+          *(bf16x8*)(dst + (lane + 64 * k) * 16) = o;
+        }
       }
     };
     auto prep = [&](int c) {             // one wave: lane = token
@@ -465,11 +621,12 @@ __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
       }
       const float cs = wave_incl_scan_dpp(d * Ah);
       const float cl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs), 63));
-      sm.cs[vb][lane] = cs;
-      sm.ecs[vb][lane] = __expf(cs);
+      const float cs2 = cs * 1.4426950408889634f, cl2 = cl * 1.4426950408889634f;
+      sm.cs[vb][lane] = cs2;                                    // log2 domain (v_exp_f32 is 2^x)
+      sm.ecs[vb][lane] = __builtin_amdgcn_exp2f(cs2);
       sm.dtv[vb][lane] = d;
-      sm.wts[vb][lane] = __expf(cl - cs) * d;
-      if (lane == 0) sm.dl[vb][0] = __expf(cl);
+      sm.wts[vb][lane] = __builtin_amdgcn_exp2f(cl2 - cs2) * d;
+      if (lane == 0) sm.dl[vb][0] = __builtin_amdgcn_exp2f(cl2);
       decay_total += cl;
     };
     SLICE_BARRIER();   // P1
@@ -481,8 +638,8 @@ __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
     scale_x(0);
     SLICE_BARRIER();   // P3
     for (int c = 0; c < nchunks; ++c) {
-      if (c + 1 < nchunks) scale_x(c + 1);
-      if (xi == 1 && c + 2 < nchunks) prep(c + 2);
+      if (c + 1 < nchunks && !SDBG(a, 16)) scale_x(c + 1);
+      if (xi == 1 && c + 2 < nchunks && !SDBG(a, 16)) prep(c + 2);
       SLICE_BARRIER();
     }
     SLICE_BARRIER();   // final
@@ -495,6 +652,12 @@ __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
     for (int c = 0; c < nchunks; ++c) SLICE_BARRIER();
     SLICE_BARRIER();
   }
+#ifdef TV_SLICE_STAMP
+  if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) {
+    g_slice_stamps[wave] = stamp_wait;
+    g_slice_stamps[16 + wave] = clock64() - stamp_t0;
+  }
+#endif
 }
 
 bool pick_slices(int P, int* nslices, int* pw) {
@@ -522,6 +685,12 @@ hipError_t launch_slice(const SliceArgs& a, dim3 grid, hipStream_t st) {
 }
 
 }  // namespace
+
+#ifdef TV_SLICE_STAMP
+extern "C" int tv_ssd_slice_debug_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_slice_stamps), sizeof(g_slice_stamps));
+}
+#endif
 
 bool tv_ssd_slice_supported(int seqlen, int nheads, int headdim, int ngroups, int dstate,
                             int dtype, int64_t xsl, int64_t bsl, int64_t bsg, int64_t csl,
@@ -570,6 +739,7 @@ int tv_ssd_slice_launch(const void* x, const void* dt, const void* A, const void
   a.xsb = xsb; a.xsl = xsl; a.dsb = dsb; a.dsl = dsl; a.bsb = bsb; a.bsl = bsl; a.bsg = bsg;
   a.csb = csb; a.csl = csl; a.csg = csg; a.ysb = ysb; a.ysl = ysl;
   a.softplus = dt_softplus; a.group_map = group_map; a.dt_min = dt_min; a.dt_max = dt_max;
+  { const char* e = getenv("TV_MARCH_DBG"); a.dbg = e ? atoi(e) : 0; }
 
   CbArgs ca;
   ca.Bm = a.Bm; ca.Cm = a.Cm; ca.cb = (bf16_t*)workspace;
