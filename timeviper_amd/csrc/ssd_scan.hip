@@ -1,5 +1,6 @@
-// S3 dispatcher: tv_ssd_scan_fwd picks the MFMA chunk-march kernel (bf16/f16,
-// d_state 128, MFMA-tileable head_dim) or the generic fp32 recurrence kernel.
+// S3 dispatcher: tv_ssd_scan_fwd picks an MFMA march kernel (bf16, d_state 128,
+// MFMA-tileable head_dim: the slice march when a workspace is supplied, else the chunk
+// march) or the generic fp32 recurrence kernel.
 #include "common.hpp"
 
 int tv_ssd_generic_launch(const void* x, const void* dt, const void* A, const void* Bm,
@@ -43,7 +44,7 @@ int tv_ssd_slice_launch(const void* x, const void* dt, const void* A, const void
 
 // 0 auto, 1 generic recurrence, 2 chunk march (ssd_march.hip), 3 slice march (ssd_slice.hip)
 static int g_ssd_impl = 0;
-static const int kAutoImpl = 2;
+static const int kAutoImpl = 3;   // slice march; falls back to the chunk march / generic kernel
 
 extern "C" void tv_ssd_scan_set_impl(int impl) { g_ssd_impl = impl; }
 

@@ -25,6 +25,7 @@
 // Reference semantics: mamba_chunk_scan_combined call modeling_nano.py:639-653; arithmetic
 // :775-851.
 #include <stdlib.h>
+#include <type_traits>
 #include "ssd_common.hpp"
 
 namespace {
@@ -123,7 +124,7 @@ struct SliceArgs {
 
 template <int PW>
 struct __attribute__((aligned(16))) SliceSmem {
-  static constexpr int XSLOT = SQ * PW + 64;   // + finite guard (the last tile reads past PW)
+  static constexpr int XSLOT = SQ * PW + 16;   // + finite guard (the last tile reads <= 16 B past PW)
   bf16_t bt[NB][SQ * SN];     // B tiles [t][n], 16-byte chunk index ^ 4(t & 3) (ds_read_b64_tr)
   bf16_t ct[NB][SQ * SN];     // C tiles [t][n], chunks XOR-swizzled for row reads
   bf16_t xr[NXS][XSLOT];      // x tiles [t][PW]
@@ -131,12 +132,15 @@ struct __attribute__((aligned(16))) SliceSmem {
   bf16_t M[2][CB_ELEMS];      // decay-masked C.B^T fragments
   bf16_t yt[2][SQ * PW];      // y tiles [t][PW]
   unsigned dtr[NDT][SQ];      // raw dt of heads (h&~1, h|1)
-  unsigned pad_[SQ];
   float cs[NV][SQ];           // inclusive cumsum of dt*A inside the chunk, times log2(e)
   float ecs[NV][SQ];          // exp(cs)
   float dtv[NV][SQ];          // discretised dt
   float wts[NV][SQ];          // exp(cs_last - cs_t) * dt_t
   float dl[NV][4];            // exp(cs_last)
+  // off-diagonal 16x16 blocks of the decay mask are separable around the first token of
+  // their t-tile: 2^(cs2_t - cs2_s) dt_s = ut[t] * ws[ti][s],  both factors <= 1 resp. dt
+  float ut[2][SQ];            // 2^(cs2_t - cs2_{16 (t/16)})
+  float ws[2][96];            // t-tile 1: s < 16 at [0,16); tile 2: s < 32 at [16,48); tile 3: [48,96)
 };
 
 __device__ __forceinline__ unsigned lds_lane_addr(const void* p) {
@@ -155,7 +159,8 @@ constexpr int W_XIO = 3;                         // x / dt DMA + y stores
 // different SIMDs; SIMD 3 has no slice-wave)
 __device__ __forceinline__ int bc_index(int w) { return w == 4 ? 0 : w == 5 ? 1 : w == 6 ? 2 : w == 11 ? 3 : -1; }
 __device__ __forceinline__ int mask_index(int w) { return w == 7 ? 0 : w == 8 ? 1 : -1; }
-__device__ __forceinline__ int scale_index(int w) { return w == 9 ? 0 : w == 10 ? 1 : -1; }
+constexpr int W_PREP = 9;                        // dt -> softplus -> prefix sum, mask factors
+constexpr int W_SCALE = 10;                      // x~ pieces the four B/C waves do not take
 
 // -DTV_SLICE_STAMP: every wave of workgroup 0 sums the cycles it spends parked at the step
 // barrier (s_memtime); tv_ssd_slice_debug_stamps() returns {wait[16], total[16]}.
@@ -211,6 +216,21 @@ __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
   // barrier each.  At step c the slice-waves consume chunk c while the helpers produce
   // x~_{c+1}, M_{c+1}, the vectors of chunk c+2, issue B/C of chunk c+2, x of chunk c+4,
   // dt of chunk c+5 and store y_{c-1}.
+  // x~ = w_t x for one 1 KiB piece (64 lanes x 16 B) of chunk c: done by the B/C waves (one
+  // piece each, they have VALU and LDS slots to spare) and by W_SCALE
+  auto scale_piece = [&](int c, int k) {
+    const int i = lane + 64 * k;
+    const float w = sm.wts[c % NV][i / NPC];
+    const uint4 v = *(const uint4*)(reinterpret_cast<const unsigned char*>(sm.xr[c % NXS]) + i * 16);
+    const unsigned u[4] = {v.x, v.y, v.z, v.w};
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o[2 * e] = (bf16_t)(bf16_lo(u[e]) * w);
+      o[2 * e + 1] = (bf16_t)(bf16_hi(u[e]) * w);
+    }
+    *(bf16x8*)(reinterpret_cast<unsigned char*>(sm.xs[c & 1]) + i * 16) = o;
+  };
   if (wave < PT) {
     // ============================================================ slice-wave (16 columns)
     const int j = wave;
@@ -487,128 +507,150 @@ __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     SLICE_BARRIER();   // P1
     SLICE_BARRIER();   // P2
+    if (q < NPI) scale_piece(0, q);
     SLICE_BARRIER();   // P3
     for (int c = 0; c < nchunks; ++c) {
       const bool issued = c + 2 < nchunks && !SDBG(a, 2);
-      if (issued) {
-        issue_bc(c + 2);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // chunk c+1 landed, c+2 in flight
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
+      if (issued) issue_bc(c + 2);
+      if (q < NPI && c + 1 < nchunks && !SDBG(a, 16)) scale_piece(c + 1, q);
+      if (issued) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // chunk c+1 landed, c+2 in flight
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       SLICE_BARRIER();
     }
     SLICE_BARRIER();   // final
   } else if (mask_index(wave) >= 0) {
     // ============================================================ decay mask M = CB .* L
-    const int mi = mask_index(wave);
-    const bf16_t* cbg = a.cb + (((int64_t)b * a.G + g) * nchunks) * CB_ELEMS + lane * 8;
-    typedef __attribute__((ext_vector_type(2))) float f32x2;
-    auto load_cb = [&](int c, bf16x8 (&cbv)[3]) {
+    // M[t][s] = CB[t][s] 2^(cs2_t - cs2_s) dt_s for s <= t (cs2 = cs log2 e), else 0, built
+    // in five wave-wide units of 16x16 blocks so that every lane of an instruction does the
+    // same kind of work:
+    //   unit 0 / 1: diagonal blocks (0,0)+(1,1) / (2,2)+(3,3): one v_exp per element
+    //     (exponent <= 0 where s <= t, -inf -> factor 0 above the diagonal);
+    //   units 2, 3, 4: off-diagonal blocks {(2,0),(2,1)}, {(3,0),(3,1)}, {(1,0),(3,2)}:
+    //     ut[t] * ws[ti][s];
+    //   the fragment halves above the diagonal are never written (LDS was zeroed).
+    // Mask wave 0 takes units 0, 2, 3; mask wave 1 units 1, 4.
+    auto run_mask = [&](auto MI) {
+      constexpr int mi = decltype(MI)::value;
+      constexpr int NS = mi == 0 ? 2 : 1;           // separable units of this wave
+      const bf16_t* cbg = a.cb + (((int64_t)b * a.G + g) * nchunks) * CB_ELEMS;
+      typedef __attribute__((ext_vector_type(2))) float f32x2;
+      typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+      const int hi = kq >> 1;
+      // element offset of this lane's 8 values inside the chunk's CB / M image, its t, first s
+      const int d_off = mi == 0 ? hi * 512 + lane * 8 : (3 + 2 * hi) * 512 + lane * 8;
+      const int d_t = 32 * mi + 16 * hi + lc, d_s0 = 32 * mi + 8 * kq;
+      int s_off[NS], s_t[NS], s_w[NS];
+      if (mi == 0) {
+        s_off[0] = 2 * 512 + lane * 8; s_t[0] = 32 + lc; s_w[0] = 16 + 8 * kq;            // frag (2,0)
+        s_off[NS - 1] = 4 * 512 + lane * 8; s_t[NS - 1] = 48 + lc; s_w[NS - 1] = 48 + 8 * kq;   // frag (3,0)
+      } else {
+        s_off[0] = hi ? 5 * 512 + (lane - 32) * 8 : 512 + lane * 8;                        // (1,0) | (3,2)
+        s_t[0] = hi ? 48 + lc : 16 + lc;
+        s_w[0] = hi ? 48 + 16 + 8 * kq : 8 * kq;
+      }
+      auto load_cb = [&](int c, bf16x8 (&cbv)[1 + NS]) {
+        cbv[0] = *(const bf16x8*)(cbg + (int64_t)c * CB_ELEMS + d_off);
 #pragma unroll
-      for (int ff = 0; ff < 3; ++ff) cbv[ff] = *(const bf16x8*)(cbg + (int64_t)c * CB_ELEMS + (3 * mi + ff) * 512);
-    };
-    // M[t][s] = CB[t][s] * 2^(cs2_t - cs2_s) * dt_s for s <= t, else 0 (cs2 = cs * log2 e; the
-    // exponent is <= 0 wherever it is used, masked entries get exponent -inf -> factor 0)
-    auto build = [&](int c, const bf16x8 (&cbv)[3]) {
-      const int vb = c % NV;
-      float cst[3];
-      f32x4 cs_s[2][2], dt_s[2][2];
-#pragma unroll
-      for (int ff = 0; ff < 3; ++ff) cst[ff] = sm.cs[vb][16 * frag_ti(3 * mi + ff) + lc];
-#pragma unroll
-      for (int sp = 0; sp < 2; ++sp)
+        for (int u = 0; u < NS; ++u) cbv[1 + u] = *(const bf16x8*)(cbg + (int64_t)c * CB_ELEMS + s_off[u]);
+      };
+      auto build = [&](int c, const bf16x8 (&cbv)[1 + NS]) {
+        const int vb = c % NV, pb = c & 1;
+        bf16_t* Mo = sm.M[pb];
+        // all LDS reads first
+        float utv[NS];
+        f32x4 cs_s[2], dt_s[2], wv[NS][2];
+        const float cst = sm.cs[vb][d_t];
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
-          cs_s[sp][hh] = *(const f32x4*)(&sm.cs[vb][32 * sp + 8 * kq + 4 * hh]);
-          dt_s[sp][hh] = *(const f32x4*)(&sm.dtv[vb][32 * sp + 8 * kq + 4 * hh]);
+          cs_s[hh] = *(const f32x4*)(&sm.cs[vb][d_s0 + 4 * hh]);
+          dt_s[hh] = *(const f32x4*)(&sm.dtv[vb][d_s0 + 4 * hh]);
         }
 #pragma unroll
-      for (int ff = 0; ff < 3; ++ff) {
-        const int f = 3 * mi + ff;
-        const int sp = frag_sp(f);
-        const int t = 16 * frag_ti(f) + lc, s0 = 32 * sp + 8 * kq;
-        typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-        const u32x4 cw = __builtin_bit_cast(u32x4, cbv[ff]);
-        bf16x8 o;
+        for (int u = 0; u < NS; ++u) {
+          utv[u] = sm.ut[pb][s_t[u]];
 #pragma unroll
-        for (int jp = 0; jp < 4; ++jp) {
-          const int j0 = 2 * jp, j1 = 2 * jp + 1;
-          const float a0 = (s0 + j0 <= t) ? cst[ff] - cs_s[sp][j0 >> 2][j0 & 3] : -__builtin_inff();
-          const float a1 = (s0 + j1 <= t) ? cst[ff] - cs_s[sp][j1 >> 2][j1 & 3] : -__builtin_inff();
-          const f32x2 e = {__builtin_amdgcn_exp2f(a0), __builtin_amdgcn_exp2f(a1)};
-          const f32x2 cd = f32x2{bf16_lo(cw[jp]), bf16_hi(cw[jp])} *
-                           f32x2{dt_s[sp][j0 >> 2][j0 & 3], dt_s[sp][j1 >> 2][j1 & 3]};
-          const f32x2 v = cd * e;
-          o[j0] = (bf16_t)v[0];
-          o[j1] = (bf16_t)v[1];
+          for (int hh = 0; hh < 2; ++hh) wv[u][hh] = *(const f32x4*)(&sm.ws[pb][s_w[u] + 4 * hh]);
         }
-        *(bf16x8*)(sm.M[c & 1] + f * 512 + lane * 8) = o;
-      }
-    };
-    // CB fragments are fetched two steps ahead into two register sets (A: even chunks,
-    // B: odd chunks), so a fetch has two steps of flight time
-    bf16x8 cbA[3], cbB[3];
-    load_cb(0, cbA);
-    load_cb(min(1, nchunks - 1), cbB);
-    SLICE_BARRIER();   // P1
-    SLICE_BARRIER();   // P2 (chunks 0/1 prepared)
-    build(0, cbA);
-    load_cb(min(2, nchunks - 1), cbA);
-    SLICE_BARRIER();   // P3
-    for (int c = 0; c < nchunks; c += 2) {
-      if (c + 1 < nchunks && !SDBG(a, 8)) {
-        build(c + 1, cbB);
-        load_cb(min(c + 3, nchunks - 1), cbB);
-      }
-      SLICE_BARRIER();
-      if (c + 1 < nchunks) {
-        if (c + 2 < nchunks && !SDBG(a, 8)) {
-          build(c + 2, cbA);
-          load_cb(min(c + 4, nchunks - 1), cbA);
+        {   // diagonal unit
+          const u32x4 cw = __builtin_bit_cast(u32x4, cbv[0]);
+          bf16x8 o;
+#pragma unroll
+          for (int jp = 0; jp < 4; ++jp) {
+            const int j0 = 2 * jp, j1 = 2 * jp + 1;
+            const float a0 = (d_s0 + j0 <= d_t) ? cst - cs_s[j0 >> 2][j0 & 3] : -__builtin_inff();
+            const float a1 = (d_s0 + j1 <= d_t) ? cst - cs_s[j1 >> 2][j1 & 3] : -__builtin_inff();
+            const f32x2 e = {__builtin_amdgcn_exp2f(a0), __builtin_amdgcn_exp2f(a1)};
+            const f32x2 v = f32x2{bf16_lo(cw[jp]), bf16_hi(cw[jp])} *
+                            f32x2{dt_s[j0 >> 2][j0 & 3], dt_s[j1 >> 2][j1 & 3]} * e;
+            o[j0] = (bf16_t)v[0];
+            o[j1] = (bf16_t)v[1];
+          }
+          *(bf16x8*)(Mo + d_off) = o;
+        }
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {          // separable units
+          const u32x4 cw = __builtin_bit_cast(u32x4, cbv[1 + u]);
+          const f32x2 u2 = {utv[u], utv[u]};
+          bf16x8 o;
+#pragma unroll
+          for (int jp = 0; jp < 4; ++jp) {
+            const int j0 = 2 * jp, j1 = 2 * jp + 1;
+            const f32x2 v = f32x2{bf16_lo(cw[jp]), bf16_hi(cw[jp])} *
+                            (u2 * f32x2{wv[u][j0 >> 2][j0 & 3], wv[u][j1 >> 2][j1 & 3]});
+            o[j0] = (bf16_t)v[0];
+            o[j1] = (bf16_t)v[1];
+          }
+          *(bf16x8*)(Mo + s_off[u]) = o;
+        }
+      };
+      // CB fragments are fetched two steps ahead into two register sets (A: even chunks,
+      // B: odd chunks), so a fetch has two steps of flight time
+      bf16x8 cbA[1 + NS], cbB[1 + NS];
+      load_cb(0, cbA);
+      load_cb(min(1, nchunks - 1), cbB);
+      SLICE_BARRIER();   // P1
+      SLICE_BARRIER();   // P2 (chunks 0/1 prepared)
+      build(0, cbA);
+      load_cb(min(2, nchunks - 1), cbA);
+      SLICE_BARRIER();   // P3
+      for (int c = 0; c < nchunks; c += 2) {
+        if (c + 1 < nchunks && !SDBG(a, 8)) {
+          build(c + 1, cbB);
+          load_cb(min(c + 3, nchunks - 1), cbB);
         }
         SLICE_BARRIER();
+        if (c + 1 < nchunks) {
+          if (c + 2 < nchunks && !SDBG(a, 8)) {
+            build(c + 2, cbA);
+            load_cb(min(c + 4, nchunks - 1), cbA);
+          }
+          SLICE_BARRIER();
+        }
       }
+      SLICE_BARRIER();   // final
+    };
+    if (mask_index(wave) == 0) run_mask(std::integral_constant<int, 0>{});
+    else run_mask(std::integral_constant<int, 1>{});
+  } else if (wave == W_SCALE) {
+    // ============================================================ remaining x~ pieces
+    SLICE_BARRIER();   // P1
+    SLICE_BARRIER();   // P2
+#pragma unroll
+    for (int k = 4; k < NPI; ++k) scale_piece(0, k);
+    SLICE_BARRIER();   // P3
+    for (int c = 0; c < nchunks; ++c) {
+      if (c + 1 < nchunks && !SDBG(a, 16)) {
+#pragma unroll
+        for (int k = 4; k < NPI; ++k) scale_piece(c + 1, k);
+      }
+      SLICE_BARRIER();
     }
     SLICE_BARRIER();   // final
-  } else if (scale_index(wave) >= 0) {
-    // ============================================================ x~ tiles, dt / cumsum prep
-    const int xi = scale_index(wave);
-    constexpr int KA = (NPI + 1) / 2;
-    const int k0 = xi == 0 ? 0 : KA, k1 = xi == 0 ? KA : NPI;
+  } else if (wave == W_PREP) {
+    // ============================================================ dt / cumsum prep
     const float Ah = a.A[h];
     const float bias = a.dt_bias ? a.dt_bias[h] : 0.f;
     float decay_total = 0.f;
-    auto scale_x = [&](int c) {
-      const int vb = c % NV;
-      const unsigned char* src = reinterpret_cast<const unsigned char*>(sm.xr[c % NXS]);
-      unsigned char* dst = reinterpret_cast<unsigned char*>(sm.xs[c & 1]);
-      float w[KA];
-      uint4 v[KA];
-#pragma unroll
-      for (int kk = 0; kk < KA; ++kk) {
-        const int k = k0 + kk;
-        if (k < k1) {
-          const int i = lane + 64 * k;
-          w[kk] = sm.wts[vb][i / NPC];
-          v[kk] = *(const uint4*)(src + i * 16);
-        }
-      }
-#pragma unroll
-      for (int kk = 0; kk < KA; ++kk) {
-        const int k = k0 + kk;
-        if (k < k1) {
-          const unsigned u[4] = {v[kk].x, v[kk].y, v[kk].z, v[kk].w};
-          bf16x8 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            o[2 * e] = (bf16_t)(bf16_lo(u[e]) * w[kk]);
-            o[2 * e + 1] = (bf16_t)(bf16_hi(u[e]) * w[kk]);
-          }
-          *(bf16x8*)(dst + (lane + 64 * k) * 16) = o;
-        }
-      }
-    };
     auto prep = [&](int c) {             // one wave: lane = token
       const int vb = c % NV;
       const int t = c * SQ + lane;
@@ -627,23 +669,29 @@ __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
       sm.dtv[vb][lane] = d;
       sm.wts[vb][lane] = __builtin_amdgcn_exp2f(cl2 - cs2) * d;
       if (lane == 0) sm.dl[vb][0] = __builtin_amdgcn_exp2f(cl2);
+      // separable factors of the off-diagonal mask blocks (pivot = first token of a t-tile)
+      const float p1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs2), 16));
+      const float p2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs2), 32));
+      const float p3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs2), 48));
+      const float p0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs2), 0));
+      const float pv = lane < 16 ? p0 : lane < 32 ? p1 : lane < 48 ? p2 : p3;
+      sm.ut[c & 1][lane] = __builtin_amdgcn_exp2f(fminf(cs2 - pv, 0.f));
+      if (lane < 16) sm.ws[c & 1][lane] = __builtin_amdgcn_exp2f(fminf(p1 - cs2, 0.f)) * d;
+      if (lane < 32) sm.ws[c & 1][16 + lane] = __builtin_amdgcn_exp2f(fminf(p2 - cs2, 0.f)) * d;
+      if (lane < 48) sm.ws[c & 1][48 + lane] = __builtin_amdgcn_exp2f(fminf(p3 - cs2, 0.f)) * d;
       decay_total += cl;
     };
     SLICE_BARRIER();   // P1
-    if (xi == 1) {
-      prep(0);
-      if (nchunks > 1) prep(1);
-    }
+    prep(0);
+    if (nchunks > 1) prep(1);
     SLICE_BARRIER();   // P2
-    scale_x(0);
     SLICE_BARRIER();   // P3
     for (int c = 0; c < nchunks; ++c) {
-      if (c + 1 < nchunks && !SDBG(a, 16)) scale_x(c + 1);
-      if (xi == 1 && c + 2 < nchunks && !SDBG(a, 16)) prep(c + 2);
+      if (c + 2 < nchunks && !SDBG(a, 16)) prep(c + 2);
       SLICE_BARRIER();
     }
     SLICE_BARRIER();   // final
-    if (xi == 1 && a.total_decay && slice == 0 && lane == 0) a.total_decay[(int64_t)b * a.H + h] = decay_total;
+    if (a.total_decay && slice == 0 && lane == 0) a.total_decay[(int64_t)b * a.H + h] = decay_total;
   } else {
     // idle waves (slice-wave slots of narrower slices)
     SLICE_BARRIER();

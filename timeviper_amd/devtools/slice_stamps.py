@@ -9,8 +9,8 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 from timeviper_amd import _capi, kernels as K  # noqa: E402
 
-ROLE = {0: "slice0", 1: "slice1", 2: "slice2", 3: "xio", 4: "bc0", 5: "bc1", 6: "bc2", 11: "bc3",
-        7: "mask0", 8: "mask1", 9: "scale0", 10: "scale1+prep"}
+ROLE = {0: "slice0", 1: "slice1", 2: "slice2", 3: "xio", 4: "bc0+sc", 5: "bc1+sc", 6: "bc2+sc", 11: "bc3+sc",
+        7: "mask0", 8: "mask1", 9: "prep", 10: "scale4"}
 
 
 def main():
