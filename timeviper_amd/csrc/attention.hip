@@ -182,42 +182,56 @@ __global__ __launch_bounds__(NW * 64) void flash_fwd_kernel(AttnArgs a) {
           sacc[t] = Frag<T>::mfma(kf, qf[ks], sacc[t]);
         }
       }
-      // ---- mask, scale to log2 domain, running max ----
+      // ---- mask, running max on the raw scores (the scale is positive, so it commutes with
+      // max), then p = 2^(s*scale - m) as one FMA + v_exp per score; packed fp32 math ----
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
       const bool need_mask = (kbase + FA_KB > a.Lk) || (a.causal && kbase + FA_KB - 1 > q0 + shift);
+      if (need_mask) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int key = kbase + t * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+            const bool ok = key < a.Lk && (!a.causal || key <= qrow + shift);
+            sacc[t][i] = ok ? sacc[t][i] : -INFINITY;
+          }
+      }
       float tmax = -INFINITY;
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          float s = sacc[t][i] * a.scale_log2;
-          if (need_mask) {
-            const int key = kbase + t * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-            const bool ok = key < a.Lk && (!a.causal || key <= qrow + shift);
-            s = ok ? s : -INFINITY;
-          }
-          sacc[t][i] = s;
-          tmax = fmaxf(tmax, s);
-        }
+        for (int i = 0; i < 16; i += 2) tmax = fmaxf(fmaxf(tmax, sacc[t][i]), sacc[t][i + 1]);
       tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-      const float m_new = fmaxf(m_run, tmax);
+      const float m_new = fmaxf(m_run, tmax * a.scale_log2);
       // rows with nothing visible yet keep m=-inf: use 0 as the exponent base
       const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);  // m_run=-inf -> 0
-      float psum = 0.f;
+      const f32x2 sc2 = {a.scale_log2, a.scale_log2}, nm2 = {-m_use, -m_use};
+      f32x2 ps2 = {0.f, 0.f};
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const float p = __builtin_amdgcn_exp2f(sacc[t][i] - m_use);
-          sacc[t][i] = p;
-          psum += p;
+        for (int i = 0; i < 16; i += 2) {
+          const f32x2 e = __builtin_elementwise_fma(f32x2{sacc[t][i], sacc[t][i + 1]}, sc2, nm2);
+          const f32x2 pp = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+          sacc[t][i] = pp[0];
+          sacc[t][i + 1] = pp[1];
+          ps2 += pp;
         }
-      l_run = l_run * alpha + psum;
+      l_run = l_run * alpha + (ps2[0] + ps2[1]);
+      // the accumulators only need rescaling when some row's maximum moved (wave-uniform test)
+      if (__builtin_amdgcn_ballot_w64(m_new > m_run)) {
+        const f32x2 al2 = {alpha, alpha};
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+          for (int i = 0; i < 16; i += 2) {
+            const f32x2 v = f32x2{oacc[dt][i], oacc[dt][i + 1]} * al2;
+            oacc[dt][i] = v[0];
+            oacc[dt][i + 1] = v[1];
+          }
+      }
       m_run = m_new;
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) oacc[dt][i] *= alpha;
 
       // ---- O^T += V^T . P^T over 4 k-steps of 16 keys ----
 #pragma unroll
@@ -304,8 +318,8 @@ extern "C" int tv_flash_attn_fwd(const void* q, const void* k, const void* v, vo
                                  int causal, int dtype, void* stream) {
   TV_CHECK_ARG(q && k && v && o, "flash_attn: null pointer");
   TV_CHECK_ARG(batch > 0 && seqlen_q >= 0 && seqlen_k >= 0 && nheads_q > 0 && nheads_kv > 0 &&
-                   nheads_q % nheads_kv == 0 && headdim > 0,
-               "flash_attn: bad sizes");
+                   nheads_q % nheads_kv == 0 && headdim > 0 && softmax_scale > 0.f,
+               "flash_attn: bad sizes (or non-positive softmax scale)");
   if (dtype != TV_BF16 && dtype != TV_F16) TV_UNSUPPORTED("flash_attn: dtype must be bf16/f16");
   if (headdim % 8) TV_UNSUPPORTED("flash_attn: headdim %d not a multiple of 8", headdim);
   const int64_t strides[] = {q_stride_b, q_stride_l, q_stride_h, k_stride_b, k_stride_l,
