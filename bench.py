@@ -150,9 +150,17 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # TV_BENCH_FORCE_SP=1 (dev): run the sequence-sharded runner and its RCCL collectives even
+    # with one rank, so the N>1 code path can be exercised on a 1-GPU box
+    sharded = world > 1 or os.environ.get("TV_BENCH_FORCE_SP") == "1"
+    if sharded:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from timeviper_amd import kernels as K
     from timeviper_amd.model import build_synthetic_timeviper
@@ -169,7 +177,7 @@ def main():
     ids = torch.cat([torch.randint(3, 1000, (20,), device=dev, generator=g),
                      torch.full((T,), tok, device=dev),
                      torch.randint(3, 1000, (80,), device=dev, generator=g)])[None]
-    if world > 1:
+    if sharded:
         from timeviper_amd.distributed import SequenceParallelTimeViper
         runner = SequenceParallelTimeViper(vlm, rank, world)
         lo, hi = runner.frame_range(T)
@@ -180,7 +188,7 @@ def main():
         step = lambda: vlm(input_ids=ids, pixel_values_videos=pix).logits
 
     def barrier():
-        if world > 1:
+        if sharded:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -197,7 +205,7 @@ def main():
         st.on = False
     assert torch.isfinite(out.float()).all(), "non-finite logits"
     t = torch.tensor([dt_s], device=dev, dtype=torch.float64)
-    if world > 1:
+    if sharded:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     dt_s = float(t.item())
 
@@ -221,7 +229,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if sharded:
         torch.distributed.destroy_process_group()
 
 
