@@ -67,9 +67,17 @@ class ScanTimer:
         ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.rec)
         tokens = sum(n for _, _, n in self.rec)
         gbs = tokens * bytes_per_token / (ms * 1e-3) / 1e9
-        return {"bound": "hbm", "kernel": "ssd_scan (tv_ssd_scan_fwd)", "achieved": round(gbs, 1),
+        # HBM bytes actually moved per algorithmic byte: rocprofv3 PMC passes (FETCH_SIZE x2,
+        # WRITE_SIZE) on this op, committed under profiles/ (PMC cannot be collected from here)
+        traffic, src = None, None
+        tf = Path(__file__).resolve().parent / "profiles" / "r01_ssd_scan_traffic.json"
+        if tf.exists():
+            ratio = json.loads(tf.read_text())["hbm_over_algorithmic"]
+            traffic, src = round(gbs * ratio, 1), f"profiles/{tf.name}: HBM bytes = {ratio:.3f} x algorithmic"
+        return {"bound": "hbm", "kernel": "ssd_scan (tv_ssd_scan_fwd: ssd_cb_kernel + ssd_slice_kernel)",
+                "achieved": round(gbs, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                "traffic": None, "launches": len(self.rec),
+                "traffic": traffic, "traffic_source": src, "launches": len(self.rec),
                 "avg_launch_us": round(ms * 1e3 / len(self.rec), 1),
                 "bytes_per_token": bytes_per_token}
 
