@@ -137,28 +137,55 @@ __global__ __launch_bounds__(NORM_THREADS) void layernorm_kernel(
   }
 }
 
-// exact (erf) GELU, elementwise, 16 bytes per lane, grid-stride
+// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, the size of fp32 erff's own
+// rounding): branch-free, 2 transcendental + ~12 plain VALU ops per element, so the
+// kernel is bound by HBM and not by libm's piecewise erff (~45 ops with divergent paths).
+// gelu(x) = 0.5 x (1 + erf(x / sqrt 2)), the reference's nn.GELU() formula.
+__device__ __forceinline__ float gelu_erf(float x) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.f));
+  float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+  p = __builtin_fmaf(p, t, 1.421413741f);
+  p = __builtin_fmaf(p, t, -0.284496736f);
+  p = __builtin_fmaf(p, t, 0.254829592f);
+  p *= t;
+  const float e = __builtin_amdgcn_exp2f(z * z * -1.4426950408889634f);
+  const float erf_abs = __builtin_fmaf(-p, e, 1.f);
+  const float hx = 0.5f * x;
+  return __builtin_fmaf(hx, copysignf(erf_abs, x), hx);
+}
+
+// exact-formula (erf) GELU, elementwise, 16 bytes per lane, grid-stride
 template <typename T>
 __global__ __launch_bounds__(256) void gelu_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                    int64_t nvec, int64_t n) {
   constexpr int V = Vec16<T>::N;
+  constexpr int U = 4;   // 16-byte loads in flight per lane before the first use
   typedef typename Vec16<T>::type vec_t;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + (U - 1) * stride < nvec; i += U * stride) {
+    vec_t v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = *(const vec_t*)(x + (i + u * stride) * V);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      vec_t o;
+#pragma unroll
+      for (int j = 0; j < V; ++j) o[j] = from_f32<T>(gelu_erf(to_f32(v[u][j])));
+      *(vec_t*)(y + (i + u * stride) * V) = o;
+    }
+  }
+  for (; i < nvec; i += stride) {
     const vec_t v = *(const vec_t*)(x + i * V);
     vec_t o;
 #pragma unroll
-    for (int j = 0; j < V; ++j) {
-      const float f = to_f32(v[j]);
-      o[j] = from_f32<T>(0.5f * f * (1.f + erff(f * 0.70710678118654752f)));
-    }
+    for (int j = 0; j < V; ++j) o[j] = from_f32<T>(gelu_erf(to_f32(v[j])));
     *(vec_t*)(y + i * V) = o;
   }
   if (blockIdx.x == 0) {   // ragged tail (< one vector)
-    const int64_t i = nvec * V + threadIdx.x;
-    if (i < n) {
-      const float f = to_f32(x[i]);
-      y[i] = from_f32<T>(0.5f * f * (1.f + erff(f * 0.70710678118654752f)));
-    }
+    const int64_t k = nvec * V + threadIdx.x;
+    if (k < n) y[k] = from_f32<T>(gelu_erf(to_f32(x[k])));
   }
 }
 
@@ -352,7 +379,7 @@ extern "C" int tv_gelu_fwd(const void* x, void* y, int64_t n, int dtype, void* s
   const int vec = dtype == TV_F32 ? 4 : 8;
   if (!aligned16(x) || !aligned16(y)) TV_UNSUPPORTED("gelu: pointers must be 16-byte aligned");
   const int64_t nvec = n / vec;
-  const unsigned grid = (unsigned)((nvec + 255) / 256 < 16384 ? (nvec + 255) / 256 + (nvec == 0) : 16384);
+  const unsigned grid = (unsigned)((nvec + 255) / 256 < 8192 ? (nvec + 255) / 256 + (nvec == 0) : 8192);
   hipStream_t s = (hipStream_t)stream;
   switch (dtype) {
     case TV_F32: gelu_kernel<float><<<grid, 256, 0, s>>>((const float*)x, (float*)y, nvec, n); break;

@@ -95,6 +95,16 @@ def main():
         ms = timeit(lambda: K.flash_attn_func(qv[:, :, 0], qv[:, :, 1], qv[:, :, 2], causal=False), iters=5)
         fl = 4 * 256 * 16 * 729 * 729 * 72
         print(f"attn ViT 256x729 d72 {ms:9.2f} ms  {fl/ms/1e9:8.1f} TFLOP/s")
+    if "gelu" in ops:
+        hx = rn(256 * 729, 4304)
+        ms = timeit(lambda: K.gelu(hx, inplace=True))
+        by = hx.numel() * 2 * 2
+        print(f"gelu 186624x4304 {ms*1e3:9.1f} us  {by/ms/1e6:8.1f} GB/s  ({by/ms/1e6/8000:.1%} of 8 TB/s)")
+        xl, dl_ = rn(256 * 729, 1152), rn(256 * 729, 1152)
+        wl, bl = rn(1152), rn(1152)
+        ms = timeit(lambda: K.layer_norm(xl, wl, bl, 1e-6, residual=dl_, return_sum=True))
+        by = xl.numel() * 2 * 4
+        print(f"layernorm+residual 186624x1152 {ms*1e3:9.1f} us  {by/ms/1e6:8.1f} GB/s  ({by/ms/1e6/8000:.1%} of 8 TB/s)")
     if "patch" in ops:
         pix = rn(256, 3, 384, 384)
         wp, bp, pos = rn(1152, 3, 14, 14), rn(1152), rn(729, 1152)
