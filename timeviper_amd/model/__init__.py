@@ -44,12 +44,17 @@ def build_synthetic_timeviper(llm_config: Optional[NemotronHConfig] = None,
                               vision_backbone_id: str = "siglip-vit-so400m-384px",
                               pdrop_type: Optional[str] = None, merge_module: str = "no_merge",
                               device="cuda", dtype=torch.bfloat16, seed: int = 0,
-                              vit_depth: Optional[int] = None, image_size: Optional[int] = None):
+                              vit_depth: Optional[int] = None, image_size: Optional[int] = None,
+                              vision_config=None):
     """Random-init TimeViper (there are no checkpoints offline): weights N(0, 0.02),
     A_log = log U[1,16], dt_bias = softplus^-1(U[1e-3,1e-1]), D = 1."""
     torch.manual_seed(seed)
     with torch.device("meta"):
-        vb = TimmViTBackbone(vision_backbone_id, depth_override=vit_depth, default_image_size=image_size)
+        if get_vision_backbone_config(vision_backbone_id)["type"] == "internvideo2":
+            vb = InternVideo2ViTBackbone(vision_backbone_id, default_image_size=image_size or 224,
+                                         vision_config=vision_config)
+        else:
+            vb = TimmViTBackbone(vision_backbone_id, depth_override=vit_depth, default_image_size=image_size)
         llm = GenericLLMBackbone("nanov2-9b", config=llm_config, merge_module=merge_module,
                                  use_pdrop=pdrop_type is not None, pdrop_type=pdrop_type)
         vlm = HybridTimeViperVLM("timeviper-synthetic", vb, llm, arch_specifier="tome_mlp-16")
@@ -67,7 +72,7 @@ def build_synthetic_timeviper(llm_config: Optional[NemotronHConfig] = None,
                 p.copy_(dt + torch.log(-torch.expm1(-dt)))
             elif name.endswith(".D") or "norm" in name.split(".")[-2] and name.endswith("weight"):
                 p.fill_(1.0)
-            elif name.endswith("gamma"):
+            elif name.endswith("gamma") or name.endswith(("ls1.weight", "ls2.weight")):
                 p.fill_(1.0)
             elif name.endswith("alpha"):
                 p.fill_(0.5)
