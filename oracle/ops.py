@@ -119,6 +119,8 @@ def causal_conv1d_ref(x_blc, weight, bias=None, activation="silu", halo=None):
     weight (C,K).  `halo` (B,K-1,C) replaces the zero left padding."""
     Bsz, L, Cc = x_blc.shape
     K = weight.shape[-1]
+    if L == 0:
+        return x_blc.float()
     xt = x_blc.transpose(1, 2).float()
     left = torch.zeros(Bsz, Cc, K - 1) if halo is None else halo.transpose(1, 2).float()
     y = F.conv1d(torch.cat([left, xt], dim=-1), weight.float().reshape(Cc, 1, K),

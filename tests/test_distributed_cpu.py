@@ -5,6 +5,7 @@ must reproduce the single-process forward.  Kernels are replaced by oracle-backe
 import os
 import socket
 
+import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
@@ -106,3 +107,61 @@ def test_chain_states_and_split():
     inc2 = chain_states(S, d, 2)
     assert torch.allclose(inc2, torch.exp(d[1])[..., None, None] * S[0] + S[1])
     assert torch.equal(chain_states(S, d, 0), torch.zeros_like(S[0]))
+
+
+def ragged_worker(rank, world, port, lens, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    try:
+        from timeviper_amd.distributed import SequenceParallelTimeViper
+        vlm = build("no_merge")
+        bb = vlm.llm_backbone.llm.backbone
+        g = torch.Generator().manual_seed(3)
+        L = sum(lens)
+        hidden = torch.randn(1, L, 64, generator=g)
+        lo = sum(lens[:rank])
+        with cpu_kernels(), torch.no_grad():
+            runner = SequenceParallelTimeViper(vlm, rank, world)
+            outs = []
+            for blk in (bb.layers[0], bb.layers[3]):          # a Mamba and an attention layer
+                normed = blk.norm(hidden)
+                mine = normed[:, lo:lo + lens[rank]]
+                part = runner._mamba(blk.mixer, mine) if blk.block_type == "mamba" \
+                    else runner._attention(blk.mixer, mine)
+                full = blk.mixer(normed)
+                full = full[0] if isinstance(full, tuple) else full
+                outs.append((part.numpy(), full[:, lo:lo + lens[rank]].numpy()))
+            q.put((rank, outs))
+        dist.barrier()
+    except BaseException:
+        import traceback
+        traceback.print_exc()
+        os._exit(1)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ragged_and_empty_shards():
+    """Shards shorter than the conv halo (1 token) and empty shards (0 tokens) — what a
+    top-k pdrop stage can leave on a rank — still reproduce the unsharded mixers."""
+    lens = [5, 1, 0, 6]
+    world = len(lens)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=ragged_worker, args=(r, world, port, lens, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        got = dict(q.get(timeout=240) for _ in range(world))
+    finally:
+        for p in procs:
+            p.join(60)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs), "worker failed (see its traceback above)"
+    for r in range(world):
+        for part, ref in got[r]:
+            assert part.shape == ref.shape
+            assert np.allclose(part, ref, rtol=1e-4, atol=1e-5), (r, np.abs(part - ref).max())

@@ -473,3 +473,32 @@ def test_layernorm_and_gelu(K, dtype):
     for n in (1, 7, 279 * 17):                       # ragged sizes (InternVideo2 toy MLP width 279)
         r = (torch.randn(n, generator=g) * 2).to(dtype)
         close(K.gelu(r.to(DEV)), torch.nn.functional.gelu(r.float()), *TOL[dtype])
+
+
+def test_zero_length_inputs(K):
+    """A rank of the sharded runner can be left with no tokens: every operator must accept
+    L = 0 (and a one-token shard with a conv halo)."""
+    H, P, G, N = 8, 40, 2, 128
+    conv_dim = H * P + 2 * G * N
+    e = lambda *s: torch.empty(*s, device=DEV, dtype=torch.bfloat16)
+    w, b = torch.randn(conv_dim, 4, device=DEV).bfloat16(), torch.randn(conv_dim, device=DEV).bfloat16()
+    x, Bm, Cm = K.causal_conv1d_xbc(e(1, 0, conv_dim), w, b, H * P, G, N)
+    assert x.shape == (1, 0, H * P) and Bm.shape == (1, 0, G, N) and Cm.shape == (1, 0, G, N)
+    A = -torch.rand(H, device=DEV) - 1
+    init = torch.randn(1, H, P, N, device=DEV)
+    y, fin, dec = K.mamba_chunk_scan_combined(e(1, 0, H, P), e(1, 0, H), A, Bm, Cm, chunk_size=64,
+                                              D=torch.ones(H, device=DEV), dt_softplus=True,
+                                              initial_states=init, return_final_states=True,
+                                              return_total_decay=True)
+    assert y.shape == (1, 0, H, P) and torch.equal(fin, init) and float(dec.abs().max()) == 0.0
+    assert K.rms_norm(e(1, 0, 64), torch.ones(64, device=DEV), 1e-5).shape == (1, 0, 64)
+    assert K.rmsnorm_fn(e(0, 64), torch.ones(64, device=DEV).bfloat16(), None, e(0, 64), 1e-5, 32,
+                        norm_before_gate=False).shape == (0, 64)
+    o = K.flash_attn_func(e(1, 0, 4, 64), torch.randn(1, 9, 2, 64, device=DEV).bfloat16(),
+                          torch.randn(1, 9, 2, 64, device=DEV).bfloat16(), causal=True)
+    assert o.shape == (1, 0, 4, 64)
+    # one token + halo == the last row of the same conv over 4 rows
+    xs = torch.randn(1, 4, conv_dim, device=DEV).bfloat16()
+    full = K.causal_conv1d_xbc(xs, w, b, H * P, G, N)[0]
+    one = K.causal_conv1d_xbc(xs[:, 3:], w, b, H * P, G, N, halo=xs[:, :3].contiguous())[0]
+    assert torch.equal(one, full[:, 3:])

@@ -316,7 +316,7 @@ extern "C" int tv_flash_attn_fwd(const void* q, const void* k, const void* v, vo
                                  int64_t v_stride_l, int64_t v_stride_h, int64_t o_stride_b,
                                  int64_t o_stride_l, int64_t o_stride_h, float softmax_scale,
                                  int causal, int dtype, void* stream) {
-  TV_CHECK_ARG(q && k && v && o, "flash_attn: null pointer");
+  TV_CHECK_ARG((seqlen_q == 0 || (q && o)) && (seqlen_q == 0 || seqlen_k == 0 || (k && v)), "flash_attn: null pointer");
   TV_CHECK_ARG(batch > 0 && seqlen_q >= 0 && seqlen_k >= 0 && nheads_q > 0 && nheads_kv > 0 &&
                    nheads_q % nheads_kv == 0 && headdim > 0 && softmax_scale > 0.f,
                "flash_attn: bad sizes (or non-positive softmax scale)");

@@ -225,7 +225,7 @@ extern "C" int tv_causal_conv1d_fwd(const void* x, const void* weight, const voi
                                     int channels, int kernel, int64_t x_stride_b,
                                     int64_t x_stride_l, int64_t y_stride_b, int64_t y_stride_l,
                                     int dtype, int silu, void* stream) {
-  TV_CHECK_ARG(x && weight && y, "conv1d: null pointer");
+  TV_CHECK_ARG(weight && (seqlen == 0 || (x && y)), "conv1d: null pointer");   // empty tensors have no storage
   TV_CHECK_ARG(batch > 0 && seqlen >= 0 && channels > 0, "conv1d: bad sizes");
   if (kernel < 2 || kernel > 4) TV_UNSUPPORTED("conv1d: kernel width %d not in [2,4]", kernel);
   if (seqlen == 0) return TV_OK;
@@ -253,7 +253,7 @@ extern "C" int tv_causal_conv1d_xbc_fwd(const void* x, const void* weight, const
                                         int batch, int seqlen, int d_inner, int ngroups,
                                         int dstate, int kernel, int64_t x_stride_b,
                                         int64_t x_stride_l, int dtype, int silu, void* stream) {
-  TV_CHECK_ARG(x && weight && y_x && y_b && y_c, "conv1d_xbc: null pointer");
+  TV_CHECK_ARG(weight && (seqlen == 0 || (x && y_x && y_b && y_c)), "conv1d_xbc: null pointer");
   TV_CHECK_ARG(batch > 0 && seqlen >= 0 && d_inner > 0 && ngroups > 0 && dstate > 0,
                "conv1d_xbc: bad sizes");
   if (kernel < 2 || kernel > 4) TV_UNSUPPORTED("conv1d_xbc: kernel width %d not in [2,4]", kernel);

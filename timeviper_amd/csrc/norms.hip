@@ -290,7 +290,7 @@ extern "C" int tv_rmsnorm_fwd(const void* x, const void* delta, const void* weig
                               void* sum_out, void* y, int64_t rows, int dim, int64_t x_stride,
                               int64_t delta_stride, int64_t sum_stride, int64_t y_stride,
                               float eps, int dtype, int wdtype, void* stream) {
-  TV_CHECK_ARG(x && weight && y, "rmsnorm: null pointer");
+  TV_CHECK_ARG(weight && (rows == 0 || (x && y)), "rmsnorm: null pointer");   // empty tensors have no storage
   TV_CHECK_ARG(rows >= 0 && dim > 0, "rmsnorm: bad sizes");
   if (rows == 0) return TV_OK;
   if (wdtype != TV_F32 && wdtype != dtype) TV_UNSUPPORTED("rmsnorm: wdtype must be f32 or dtype");
@@ -319,7 +319,7 @@ extern "C" int tv_rmsnorm_gated_fwd(const void* x, const void* z, const void* we
                                     int64_t rows, int dim, int group_size, int64_t x_stride,
                                     int64_t z_stride, int64_t y_stride, float eps, int dtype,
                                     int wdtype, void* stream) {
-  TV_CHECK_ARG(x && weight && y, "rmsnorm_gated: null pointer");
+  TV_CHECK_ARG(weight && (rows == 0 || (x && y)), "rmsnorm_gated: null pointer");
   TV_CHECK_ARG(rows >= 0 && dim > 0 && group_size > 0 && dim % group_size == 0,
                "rmsnorm_gated: bad sizes (dim %d, group %d)", dim, group_size);
   if (rows == 0) return TV_OK;
@@ -349,7 +349,7 @@ extern "C" int tv_layernorm_fwd(const void* x, const void* delta, const void* we
                                 const void* bias, void* sum_out, void* y, int64_t rows, int dim,
                                 int64_t x_stride, int64_t delta_stride, int64_t sum_stride,
                                 int64_t y_stride, float eps, int dtype, void* stream) {
-  TV_CHECK_ARG(x && weight && y, "layernorm: null pointer");
+  TV_CHECK_ARG(weight && (rows == 0 || (x && y)), "layernorm: null pointer");
   TV_CHECK_ARG(rows >= 0 && dim > 0, "layernorm: bad sizes");
   if (rows == 0) return TV_OK;
   const int vec = dtype == TV_F32 ? 4 : 8;
@@ -373,7 +373,7 @@ extern "C" int tv_layernorm_fwd(const void* x, const void* delta, const void* we
 }
 
 extern "C" int tv_gelu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream) {
-  TV_CHECK_ARG(x && y, "gelu: null pointer");
+  TV_CHECK_ARG(n == 0 || (x && y), "gelu: null pointer");
   TV_CHECK_ARG(n >= 0, "gelu: bad size");
   if (n == 0) return TV_OK;
   const int vec = dtype == TV_F32 ? 4 : 8;

@@ -161,7 +161,7 @@ extern "C" int tv_patch_embed_strided_fwd(const void* pixels, const void* weight
                                           int dout, int frames_per_group, int64_t group_stride,
                                           int64_t frame_stride, int64_t chan_stride, int dtype,
                                           void* stream) {
-  TV_CHECK_ARG(pixels && weight && out, "patch_embed: null pointer");
+  TV_CHECK_ARG(weight && (frames == 0 || (pixels && out)), "patch_embed: null pointer");
   TV_CHECK_ARG(frames >= 0 && cin > 0 && height > 0 && width > 0 && patch > 0 && dout > 0 &&
                    frames_per_group > 0,
                "patch_embed: bad sizes");

@@ -65,7 +65,7 @@ extern "C" int tv_ssd_scan_fwd(const void* x, const void* dt, const void* A, con
                                int64_t y_stride_l, int dtype, int dt_softplus,
                                float dt_min, float dt_max, int group_map, void* workspace,
                                size_t workspace_bytes, void* stream) {
-  TV_CHECK_ARG(x && dt && A && Bm && Cm && y, "ssd_scan: null pointer");
+  TV_CHECK_ARG(A && (seqlen == 0 || (x && dt && Bm && Cm && y)), "ssd_scan: null pointer");   // empty tensors have no storage
   TV_CHECK_ARG(batch > 0 && seqlen >= 0 && nheads > 0 && headdim > 0 && ngroups > 0 &&
                    dstate > 0 && nheads % ngroups == 0,
                "ssd_scan: bad sizes (B %d L %d H %d P %d G %d N %d)", batch, seqlen, nheads,

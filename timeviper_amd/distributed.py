@@ -102,11 +102,33 @@ class SequenceParallelTimeViper:
         d_in, gts = mixer.intermediate_size, mixer.n_groups * mixer.ssm_state_size
         gate, xBC, dt = proj.split([d_in, mixer.conv_dim, mixer.num_heads], dim=-1)
         Kw = mixer.conv_kernel_size
-        # halo: the K-1 pre-conv rows that precede this shard
-        tail = xBC[:, -(Kw - 1):].contiguous()
+        # halo: the K-1 pre-conv rows that precede this shard.  Every rank contributes its last
+        # K-1 rows (front-padded with zeros when its shard is shorter) and their count, so a
+        # shard shorter than K-1 — or empty — still hands the right rows to its successors.
+        n_tail = min(L, Kw - 1)
+        tail = xBC.new_zeros((Bsz, Kw - 1, xBC.shape[-1]))
+        if n_tail:
+            tail[:, Kw - 1 - n_tail:] = xBC[:, L - n_tail:]
+        cnt = torch.tensor([n_tail], device=xBC.device, dtype=torch.int64)
         tails = [torch.empty_like(tail) for _ in range(self.world)]
+        cnts = [torch.zeros_like(cnt) for _ in range(self.world)]
         dist.all_gather(tails, tail, group=self.group)
-        halo = tails[self.rank - 1] if self.rank > 0 else None
+        dist.all_gather(cnts, cnt, group=self.group)
+        halo = None
+        if self.rank > 0:
+            rows, need = [], Kw - 1
+            for j in range(self.rank - 1, -1, -1):
+                take = min(int(cnts[j]), need)
+                if take:
+                    rows.insert(0, tails[j][:, Kw - 1 - take:])
+                    need -= take
+                if need == 0:
+                    break
+            if need < Kw - 1:
+                halo = torch.cat(rows, dim=1)
+                if need:        # sequence start reached: zeros in front, like the unsharded conv
+                    halo = torch.cat([halo.new_zeros((Bsz, need, halo.shape[-1])), halo], dim=1)
+                halo = halo.contiguous()
         x, Bm, Cm = K.causal_conv1d_xbc(xBC, mixer.conv1d.weight.squeeze(1), mixer.conv1d.bias,
                                         d_in, mixer.n_groups, mixer.ssm_state_size,
                                         activation=mixer.activation, halo=halo)
