@@ -173,7 +173,10 @@ __device__ unsigned long long g_slice_stamps[32];
     __builtin_amdgcn_s_barrier();                         \
     stamp_wait += clock64() - ta__;                       \
   } while (0)
+#define PSTAMP(slot) do { const unsigned long long n__ = clock64(); ph_acc[slot] += n__ - ph_last; ph_last = n__; } while (0)
+__device__ unsigned long long g_slice_phases[8];
 #else
+#define PSTAMP(slot) do {} while (0)
 #define SLICE_BARRIER()                                   \
   do {                                                    \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
@@ -203,6 +206,7 @@ __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
 #ifdef TV_SLICE_STAMP
   unsigned long long stamp_wait = 0;
   const unsigned long long stamp_t0 = clock64();
+  unsigned long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_last = stamp_t0;
 #endif
   {   // zero LDS once: guards / pad columns must hold finite values
     bf16x8 z = {};
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
   // 0/1 prepared, P3: x~_0 and M_0 built); then every role runs nchunks steps with one
   // barrier each.  At step c the slice-waves consume chunk c while the helpers produce
   // x~_{c+1}, M_{c+1}, the vectors of chunk c+2, issue B/C of chunk c+2, x of chunk c+4,
-  // dt of chunk c+5 and store y_{c-1}.
+  // dt of chunk c+5 and store y_{c-2} (the slice-waves write y_{c-1} to LDS at the start of step c).
   // x~ = w_t x for one 1 KiB piece (64 lanes x 16 B) of chunk c: done by the B/C waves (one
   // piece each, they have VALU and LDS slots to spare) and by W_SCALE
   auto scale_piece = [&](int c, int k) {
@@ -257,6 +261,17 @@ __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
     // transposing reads of x / x~ (B operand: k = token) and of x in accumulator layout
     const int trx = ((8 * kq + q4) * PW + 4 * p4) * 2 + j * 32;
     const int trd = ((4 * kq + q4) * PW + 4 * p4) * 2 + j * 32;
+    unsigned ypk[4][2] = {};
+    auto write_y = [&](int c) {     // y tile of chunk c: ds_write_b16 / _d16_hi of the packed halves
+      if (!pvalid) return;
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti) {
+        const unsigned ya = lds_lane_addr(sm.yt[c & 1] + (16 * ti + 4 * kq) * PW + pcol);
+        asm volatile("ds_write_b16 %0, %1\n\tds_write_b16_d16_hi %0, %1 offset:%3\n\t"
+                     "ds_write_b16 %0, %2 offset:%4\n\tds_write_b16_d16_hi %0, %2 offset:%5"
+                     :: "v"(ya), "v"(ypk[ti][0]), "v"(ypk[ti][1]), "n"(PW * 2), "n"(PW * 4), "n"(PW * 6) : "memory");
+      }
+    };
     SLICE_BARRIER();   // P1
     SLICE_BARRIER();   // P2
     SLICE_BARRIER();   // P3
@@ -323,6 +338,7 @@ __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
       };
       bf16x8 cq[2][4];
       bf16x4 bq[2][2][4];
+      PSTAMP(7);
       // ---- first reads
       read_cq(0, cq[0]);
       bf16x4 xq[2][2], xwq[2][2];
@@ -333,20 +349,25 @@ __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
       }
       const float dl = sm.dl[vb][0];
       read_b2(0, bq[0]);
+      if (c > 0) write_y(c - 1);        // previous chunk's results, under the reads just issued
       __builtin_amdgcn_sched_barrier(0);
+      PSTAMP(0);
       read_cq(1, cq[1]);
       read_b2(2, bq[1]);
       const bf16x8 xwf[2] = {cat4(xwq[0][0], xwq[0][1]), cat4(xwq[1][0], xwq[1][1])};
       quarter(0, cq[0], bq[0], xwf, dl);
       __builtin_amdgcn_sched_barrier(0);
+      PSTAMP(1);
       read_cq(2, cq[0]);
       read_b2(4, bq[0]);
       quarter(1, cq[1], bq[1], xwf, dl);
       __builtin_amdgcn_sched_barrier(0);
+      PSTAMP(2);
       read_cq(3, cq[1]);
       read_b2(6, bq[1]);
       quarter(2, cq[0], bq[0], xwf, dl);
       __builtin_amdgcn_sched_barrier(0);
+      PSTAMP(3);
       // epilogue operands in flight under the last quarter
       bf16x8 mf[NFRAG];
 #pragma unroll
@@ -365,6 +386,7 @@ __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
       }
       quarter(3, cq[1], bq[1], xwf, dl);
       __builtin_amdgcn_sched_barrier(0);
+      PSTAMP(4);
       // ---- y = exp(cs_t) Yoff + M x + D x  (Ydiag accumulates onto the scaled Yoff)
       const bf16x8 xf[2] = {cat4(xq[0][0], xq[0][1]), cat4(xq[1][0], xq[1][1])};
       if (!SDBG(a, 128)) {
@@ -383,22 +405,24 @@ __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
           yo[ti] = mfma16(mf[f0], xf[0], yo[ti]);
           if (ti >= 2) yo[ti] = mfma16(mf[f0 + 1], xf[1], yo[ti]);
         }
-        if (pvalid) {
+        // packed bf16 results stay in registers across the barrier; they are written to the y
+        // tile at the start of the next step, beside that step's first fragment reads
 #pragma unroll
-          for (int ti = 0; ti < 4; ++ti) {
-            // two bf16 per v_cvt_pk; low / high halves go out as ds_write_b16 / _d16_hi
-            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-            const unsigned ya = lds_lane_addr(sm.yt[c & 1] + (16 * ti + 4 * kq) * PW + pcol);
-            const bf16x2 p01 = {(bf16_t)yo[ti][0], (bf16_t)yo[ti][1]}, p23 = {(bf16_t)yo[ti][2], (bf16_t)yo[ti][3]};
-            const unsigned w01 = __builtin_bit_cast(unsigned, p01), w23 = __builtin_bit_cast(unsigned, p23);
-            asm volatile("ds_write_b16 %0, %1\n\tds_write_b16_d16_hi %0, %1 offset:%3\n\t"
-                         "ds_write_b16 %0, %2 offset:%4\n\tds_write_b16_d16_hi %0, %2 offset:%5"
-                         :: "v"(ya), "v"(w01), "v"(w23), "n"(PW * 2), "n"(PW * 4), "n"(PW * 6) : "memory");
-          }
+        for (int ti = 0; ti < 4; ++ti) {
+          typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+          const bf16x2 p01 = {(bf16_t)yo[ti][0], (bf16_t)yo[ti][1]}, p23 = {(bf16_t)yo[ti][2], (bf16_t)yo[ti][3]};
+          ypk[ti][0] = __builtin_bit_cast(unsigned, p01);
+          ypk[ti][1] = __builtin_bit_cast(unsigned, p23);
         }
       }
+      PSTAMP(5);
       SLICE_BARRIER();
     }
+#ifdef TV_SLICE_STAMP
+    if (blockIdx.x == 0 && blockIdx.y == 0 && wave == 0 && lane == 0)
+      for (int i = 0; i < 8; ++i) g_slice_phases[i] = ph_acc[i];
+#endif
+    write_y(nchunks - 1);
     if (a.final_state && pvalid) {
 #pragma unroll
       for (int i = 0; i < 8; ++i)
@@ -453,7 +477,7 @@ __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
     SLICE_BARRIER();   // P2
     SLICE_BARRIER();   // P3
     for (int c = 0; c < nchunks; ++c) {
-      if (c > 0 && !SDBG(a, 4)) store_y(c - 1);
+      if (c > 1 && !SDBG(a, 4)) store_y(c - 2);   // written by the slice-waves at the start of step c-1
       const bool issued = c + DXS < nchunks && !SDBG(a, 4);
       if (issued) {
         issue_x(c + DXS);
@@ -461,11 +485,12 @@ __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
       }
       // x of chunk c+2 and dt of chunk c+3 (issued two steps ago) must have landed: since
       // then this wave issued 2 x (NPI stores + NPI + 1 copies) — two steps of flight time
-      if (issued && c > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (2 * NPI + 1)) : "memory");
+      if (issued && c > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (2 * NPI + 1)) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       SLICE_BARRIER();
     }
-    SLICE_BARRIER();   // final: the last chunk's y tile is complete
+    if (nchunks > 1) store_y(nchunks - 2);
+    SLICE_BARRIER();   // final: the slice-waves have flushed the last chunk's y tile
     store_y(nchunks - 1);
   } else if (bc_index(wave) >= 0) {
     // ============================================================ B / C DMA
@@ -736,7 +761,9 @@ hipError_t launch_slice(const SliceArgs& a, dim3 grid, hipStream_t st) {
 
 #ifdef TV_SLICE_STAMP
 extern "C" int tv_ssd_slice_debug_stamps(unsigned long long* out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_slice_stamps), sizeof(g_slice_stamps));
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_slice_stamps), sizeof(g_slice_stamps));
+  if (e == hipSuccess) e = hipMemcpyFromSymbol(out + 32, HIP_SYMBOL(g_slice_phases), sizeof(g_slice_phases));
+  return (int)e;
 }
 #endif
 

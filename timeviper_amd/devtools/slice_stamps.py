@@ -26,7 +26,7 @@ def main():
     for _ in range(2):
         K.mamba_chunk_scan_combined(x, dt, A, Bm, Cm, chunk_size=64, D=D, dt_bias=bias, dt_softplus=True)
     torch.cuda.synchronize()
-    out = (ctypes.c_ulonglong * 32)()
+    out = (ctypes.c_ulonglong * 40)()
     fn = _capi.lib()._lib.tv_ssd_slice_debug_stamps if hasattr(_capi.lib(), "_lib") else None
     if fn is None:
         fn = ctypes.CDLL(str(Path(_capi.__file__).parent / "lib" / "libtimeviper_hip.so")).tv_ssd_slice_debug_stamps
@@ -37,6 +37,10 @@ def main():
         wait, total = out[w], out[16 + w]
         print(f"wave {w:2d} {ROLE.get(w, '?'):12s} total {total/steps:8.0f} ticks/step   busy {(total-wait)/steps:8.0f}   "
               f"parked {wait/total:6.1%}")
+
+
+    names = ["first reads", "quarter 0", "quarter 1", "quarter 2", "quarter 3", "Ydiag + epilogue", "-", "barrier + loop"]
+    print("slice-wave 0 phases (cycles/step): " + "  ".join(f"{n} {out[32 + i] / steps:.0f}" for i, n in enumerate(names) if n != "-"))
 
 
 if __name__ == "__main__":
