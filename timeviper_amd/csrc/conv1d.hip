@@ -121,8 +121,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv1d_xbc_kernel(
 #pragma unroll
     for (int i = 0; i < V; ++i) win[j][i] = have ? to_f32(v[i]) : 0.f;
   }
-  for (int t = t0; t < t1; ++t) {
-    vec_t v = *(const vec_t*)(xb + (int64_t)t * xsl);
+  auto step = [&](int t, const vec_t& v) {
     vec_t ov;
 #pragma unroll
     for (int i = 0; i < V; ++i) {
@@ -130,13 +129,24 @@ __global__ __launch_bounds__(CONV_THREADS) void conv1d_xbc_kernel(
       float acc = bs[i];
 #pragma unroll
       for (int j = 0; j < K; ++j) acc = fmaf(wk[j][i], win[j][i], acc);
-      if (silu) acc = silu_f(acc);
+      if (silu) acc *= __builtin_amdgcn_rcpf(1.f + __expf(-acc));   // x * sigmoid(x)
       ov[i] = from_f32<T>(acc);
 #pragma unroll
       for (int j = 0; j < K - 1; ++j) win[j][i] = win[j + 1][i];
     }
     *(vec_t*)(yb + (int64_t)t * ysl) = ov;
+  };
+  // four rows of loads in flight ahead of the arithmetic
+  constexpr int U = 4;
+  int t = t0;
+  for (; t + U <= t1; t += U) {
+    vec_t v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = *(const vec_t*)(xb + (int64_t)(t + u) * xsl);
+#pragma unroll
+    for (int u = 0; u < U; ++u) step(t + u, v[u]);
   }
+  for (; t < t1; ++t) step(t, *(const vec_t*)(xb + (int64_t)t * xsl));
 }
 
 template <typename T, int K>

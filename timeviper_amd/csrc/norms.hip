@@ -15,6 +15,24 @@ template <typename T>
 __device__ __forceinline__ float wload(const void* w, int wf32, int i) {
   return wf32 ? ((const float*)w)[i] : to_f32(((const T*)w)[i]);
 }
+// the V weights of one 16-byte activation vector, as floats (fp32 weights: V*4 bytes = two or
+// one 16-byte loads; activation-dtype weights: one)
+template <typename T>
+__device__ __forceinline__ void wload_vec(const void* w, int wf32, int i0, float (&out)[Vec16<T>::N]) {
+  constexpr int V = Vec16<T>::N;
+  if (wf32) {
+#pragma unroll
+    for (int q = 0; q < V / 4; ++q) {
+      const f32x4 v = *(const f32x4*)((const float*)w + i0 + 4 * q);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) out[4 * q + i] = v[i];
+    }
+  } else {
+    const typename Vec16<T>::type v = *(const typename Vec16<T>::type*)((const T*)w + i0);
+#pragma unroll
+    for (int i = 0; i < V; ++i) out[i] = to_f32(v[i]);
+  }
+}
 
 template <typename T>
 __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_kernel(
@@ -66,9 +84,10 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_kernel(
     const int iv = threadIdx.x + k * NORM_THREADS;
     if (iv < nv) {
       vec_t o;
+      float wv[V];
+      wload_vec<T>(w, wf32, iv * V, wv);
 #pragma unroll
-      for (int i = 0; i < V; ++i)
-        o[i] = from_f32<T>(wload<T>(w, wf32, iv * V + i) * (vals[k][i] * rstd));
+      for (int i = 0; i < V; ++i) o[i] = from_f32<T>(wv[i] * (vals[k][i] * rstd));
       *(vec_t*)(y + row * ys + (int64_t)iv * V) = o;
     }
   }
@@ -206,23 +225,32 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_gated_kernel(
   const int nv = gsz / V;
   const T* xr = x + row * xs + (int64_t)g * gsz;
   const T* zr = z ? z + row * zs + (int64_t)g * gsz : nullptr;
+  // every load of the (row, group) is issued before the first use
+  vec_t xv[NORM_MAXV], zv[NORM_MAXV];
+#pragma unroll
+  for (int k = 0; k < NORM_MAXV; ++k) {
+    const int iv = lane + k * 64;
+    if (iv < nv) {
+      xv[k] = *(const vec_t*)(xr + (int64_t)iv * V);
+      if (zr) zv[k] = *(const vec_t*)(zr + (int64_t)iv * V);
+    }
+  }
   float vals[NORM_MAXV][V];
   float ssq = 0.f;
 #pragma unroll
   for (int k = 0; k < NORM_MAXV; ++k) {
     const int iv = lane + k * 64;
     if (iv < nv) {
-      vec_t v = *(const vec_t*)(xr + (int64_t)iv * V);
-      if (zr) {
-        vec_t zv = *(const vec_t*)(zr + (int64_t)iv * V);
 #pragma unroll
-        for (int i = 0; i < V; ++i) vals[k][i] = to_f32(v[i]) * silu_f(to_f32(zv[i]));
-      } else {
-#pragma unroll
-        for (int i = 0; i < V; ++i) vals[k][i] = to_f32(v[i]);
+      for (int i = 0; i < V; ++i) {
+        float v = to_f32(xv[k][i]);
+        if (zr) {   // x * silu(z), sigmoid through the hardware reciprocal
+          const float g = to_f32(zv[k][i]);
+          v *= g * __builtin_amdgcn_rcpf(1.f + __expf(-g));
+        }
+        vals[k][i] = v;
+        ssq = fmaf(v, v, ssq);
       }
-#pragma unroll
-      for (int i = 0; i < V; ++i) ssq = fmaf(vals[k][i], vals[k][i], ssq);
     }
   }
   ssq = wave_sum(ssq);
@@ -233,9 +261,10 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_gated_kernel(
     const int iv = lane + k * 64;
     if (iv < nv) {
       vec_t o;
+      float wv[V];
+      wload_vec<T>(w, wf32, g * gsz + iv * V, wv);
 #pragma unroll
-      for (int i = 0; i < V; ++i)
-        o[i] = from_f32<T>(wload<T>(w, wf32, g * gsz + iv * V + i) * (vals[k][i] * rstd));
+      for (int i = 0; i < V; ++i) o[i] = from_f32<T>(wv[i] * (vals[k][i] * rstd));
       *(vec_t*)(yr + (int64_t)iv * V) = o;
     }
   }
@@ -295,7 +324,7 @@ extern "C" int tv_rmsnorm_fwd(const void* x, const void* delta, const void* weig
   if (rows == 0) return TV_OK;
   if (wdtype != TV_F32 && wdtype != dtype) TV_UNSUPPORTED("rmsnorm: wdtype must be f32 or dtype");
   const int vec = dtype == TV_F32 ? 4 : 8;
-  if (!aligned16(x) || !aligned16(y) || (delta && !aligned16(delta)) ||
+  if (!aligned16(x) || !aligned16(y) || !aligned16(weight) || (delta && !aligned16(delta)) ||
       (sum_out && !aligned16(sum_out)) || x_stride % vec || y_stride % vec ||
       (delta && delta_stride % vec) || (sum_out && sum_stride % vec))
     TV_UNSUPPORTED("rmsnorm: pointers/strides must be 16-byte aligned");
@@ -326,7 +355,7 @@ extern "C" int tv_rmsnorm_gated_fwd(const void* x, const void* z, const void* we
   if (wdtype != TV_F32 && wdtype != dtype)
     TV_UNSUPPORTED("rmsnorm_gated: wdtype must be f32 or dtype");
   const int vec = dtype == TV_F32 ? 4 : 8;
-  if (!aligned16(x) || !aligned16(y) || (z && !aligned16(z)) || x_stride % vec ||
+  if (!aligned16(x) || !aligned16(y) || !aligned16(weight) || (z && !aligned16(z)) || x_stride % vec ||
       y_stride % vec || (z && z_stride % vec))
     TV_UNSUPPORTED("rmsnorm_gated: pointers/strides must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
