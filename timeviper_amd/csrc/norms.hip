@@ -156,6 +156,73 @@ __global__ __launch_bounds__(NORM_THREADS) void layernorm_kernel(
   }
 }
 
+// Rows of up to 64 * NORM_MAXV vectors (ViT widths): one WAVE per row — no LDS, no block
+// barrier, four rows in flight per workgroup, every load issued before the first use.
+template <typename T>
+__global__ __launch_bounds__(NORM_THREADS) void layernorm_wave_kernel(
+    const T* __restrict__ x, const T* __restrict__ delta, const T* __restrict__ w,
+    const T* __restrict__ bias, T* __restrict__ sum_out, T* __restrict__ y, int64_t rows, int D,
+    int64_t xs, int64_t ds, int64_t ss, int64_t ys, float eps) {
+  constexpr int V = Vec16<T>::N;
+  typedef typename Vec16<T>::type vec_t;
+  const int64_t row = (int64_t)blockIdx.x * (NORM_THREADS / 64) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const int nv = D / V;
+  const T* xr = x + row * xs;
+  const T* dr = delta ? delta + row * ds : nullptr;
+  vec_t xv[NORM_MAXV], dv[NORM_MAXV];
+#pragma unroll
+  for (int k = 0; k < NORM_MAXV; ++k) {
+    const int iv = lane + k * 64;
+    if (iv < nv) {
+      xv[k] = *(const vec_t*)(xr + (int64_t)iv * V);
+      if (dr) dv[k] = *(const vec_t*)(dr + (int64_t)iv * V);
+    }
+  }
+  float vals[NORM_MAXV][V];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < NORM_MAXV; ++k) {
+    const int iv = lane + k * 64;
+    if (iv < nv) {
+      if (dr) {
+        vec_t sv;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          sv[i] = from_f32<T>(to_f32(xv[k][i]) + to_f32(dv[k][i]));
+          vals[k][i] = to_f32(sv[i]);
+        }
+        if (sum_out) *(vec_t*)(sum_out + row * ss + (int64_t)iv * V) = sv;
+      } else {
+#pragma unroll
+        for (int i = 0; i < V; ++i) vals[k][i] = to_f32(xv[k][i]);
+      }
+#pragma unroll
+      for (int i = 0; i < V; ++i) { s1 += vals[k][i]; s2 = fmaf(vals[k][i], vals[k][i], s2); }
+    }
+  }
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  const float mean = s1 / (float)D;
+  const float var = fmaxf(s2 / (float)D - mean * mean, 0.f);
+  const float rstd = rsqrtf(var + eps);
+#pragma unroll
+  for (int k = 0; k < NORM_MAXV; ++k) {
+    const int iv = lane + k * 64;
+    if (iv < nv) {
+      const vec_t wv = *(const vec_t*)(w + (int64_t)iv * V);
+      vec_t bv = {};
+      if (bias) bv = *(const vec_t*)(bias + (int64_t)iv * V);
+      vec_t o;
+#pragma unroll
+      for (int i = 0; i < V; ++i)
+        o[i] = from_f32<T>((vals[k][i] - mean) * rstd * to_f32(wv[i]) + to_f32(bv[i]));
+      *(vec_t*)(y + row * ys + (int64_t)iv * V) = o;
+    }
+  }
+}
+
 // erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, the size of fp32 erff's own
 // rounding): branch-free, 2 transcendental + ~12 plain VALU ops per element, so the
 // kernel is bound by HBM and not by libm's piecewise erff (~45 ops with divergent paths).
@@ -308,8 +375,15 @@ int launch_ln(const void* x, const void* delta, const void* w, const void* b, vo
   if (D % V || D / V > NORM_THREADS * NORM_MAXV)
     TV_UNSUPPORTED("layernorm: dim %d not a multiple of %d or larger than %d", D, V,
                    V * NORM_THREADS * NORM_MAXV);
-  layernorm_kernel<T><<<dim3((unsigned)rows), NORM_THREADS, 0, s>>>(
-      (const T*)x, (const T*)delta, (const T*)w, (const T*)b, (T*)sum_out, (T*)y, D, xs, ds, ss, ys, eps);
+  if (D / V <= 64 * NORM_MAXV) {
+    const int64_t nblk = (rows + NORM_THREADS / 64 - 1) / (NORM_THREADS / 64);
+    layernorm_wave_kernel<T><<<dim3((unsigned)nblk), NORM_THREADS, 0, s>>>(
+        (const T*)x, (const T*)delta, (const T*)w, (const T*)b, (T*)sum_out, (T*)y, rows, D, xs, ds, ss,
+        ys, eps);
+  } else {
+    layernorm_kernel<T><<<dim3((unsigned)rows), NORM_THREADS, 0, s>>>(
+        (const T*)x, (const T*)delta, (const T*)w, (const T*)b, (T*)sum_out, (T*)y, D, xs, ds, ss, ys, eps);
+  }
   TV_LAUNCH_CHECK();
 }
 
