@@ -67,37 +67,58 @@ __global__ __launch_bounds__(PE_THREADS) void patch_embed_kernel(PeArgs a) {
   const T* pix = (const T*)a.pix;
   const T* wgt = (const T*)a.w;
 
-  for (int row0 = 0; row0 < rows_total; row0 += PE_RPS) {
-    __syncthreads();
-    // stage patches: (m, row) pairs, `p` elements each, padded to 16
-    for (int i = tid; i < PE_TM * PE_RPS; i += PE_THREADS) {
-      const int ml = i % PE_TM, rl = i / PE_TM;
-      const int64_t m = m0 + ml;
-      const int row = row0 + rl;
-      T* dst = sP + ml * PE_STR + rl * 16;
-      if (m < a.M && row < rows_total) {
-        const int64_t f = m / npatch;
-        const int pi = (int)(m % npatch);
-        const int py = pi / a.gw, px = pi % a.gw;
-        const int c = row / a.p, dy = row % a.p;
-        const T* src = pix + (f / a.fpg) * a.group_stride + (f % a.fpg) * a.frame_stride +
-                       (int64_t)c * a.chan_stride + (int64_t)(py * a.p + dy) * a.W + px * a.p;
-        for (int dx = 0; dx < 16; ++dx) dst[dx] = dx < a.p ? src[dx] : from_f32<T>(0.f);
+  // Staging.  A thread always stages the same patch (ml = tid % 128) and the same output
+  // channel (nl = tid % 128): their base pointers are resolved once.  With an even patch size
+  // (14, 16) and even image width every patch row starts 4-byte aligned, so a row is p/2 dword
+  // loads and two 16-byte LDS writes instead of 16 scalar loads, selects and 2-byte writes.
+  constexpr int PE_IT = PE_TM * PE_RPS / PE_THREADS;     // (row) items per thread and k-step
+  static_assert(PE_TM == PE_TN && PE_THREADS % PE_TM == 0, "staging map");
+  const int sl = tid % PE_TM, srl0 = tid / PE_TM;        // item j: row row0 + srl0 + j * (256/128)
+  const int64_t sm_ = m0 + sl;
+  const bool m_ok = sm_ < a.M;
+  const T* pbase = pix;
+  if (m_ok) {
+    const int64_t f = sm_ / npatch;
+    const int pi = (int)(sm_ % npatch);
+    pbase = pix + (f / a.fpg) * a.group_stride + (f % a.fpg) * a.frame_stride +
+            (int64_t)(pi / a.gw) * a.p * a.W + (pi % a.gw) * a.p;
+  }
+  const int sn = n0 + sl;
+  const bool n_ok = sn < a.dout;
+  const T* wbase = wgt + (int64_t)(n_ok ? sn : 0) * kw;
+  const bool vec_ok = (a.p % 2 == 0) && (a.W % 2 == 0) && ((a.chan_stride | a.frame_stride | a.group_stride) % 2 == 0) &&
+                      (((uintptr_t)pix | (uintptr_t)wgt) % 4 == 0);
+  auto stage_row = [&](const T* src, bool ok, T* dst) {
+    unsigned u[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (ok) {
+      if (vec_ok) {
+        const unsigned* s32 = reinterpret_cast<const unsigned*>(src);
+#pragma unroll
+        for (int d = 0; d < 8; ++d)
+          if (2 * d < a.p) u[d] = s32[d];
       } else {
-        for (int dx = 0; dx < 16; ++dx) dst[dx] = from_f32<T>(0.f);
+        for (int dx = 0; dx < a.p; ++dx) {
+          const unsigned v = __builtin_bit_cast(unsigned short, src[dx]);
+          u[dx >> 1] |= v << (16 * (dx & 1));
+        }
       }
     }
-    for (int i = tid; i < PE_TN * PE_RPS; i += PE_THREADS) {
-      const int nl = i % PE_TN, rl = i / PE_TN;
-      const int n = n0 + nl;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    *(u32x4*)dst = u32x4{u[0], u[1], u[2], u[3]};
+    *(u32x4*)(dst + 8) = u32x4{u[4], u[5], u[6], u[7]};
+  };
+
+  for (int row0 = 0; row0 < rows_total; row0 += PE_RPS) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PE_IT; ++j) {
+      const int rl = srl0 + j * (PE_THREADS / PE_TM);
       const int row = row0 + rl;
-      T* dst = sW + nl * PE_STR + rl * 16;
-      if (n < a.dout && row < rows_total) {
-        const T* src = wgt + (int64_t)n * kw + (int64_t)row * a.p;
-        for (int dx = 0; dx < 16; ++dx) dst[dx] = dx < a.p ? src[dx] : from_f32<T>(0.f);
-      } else {
-        for (int dx = 0; dx < 16; ++dx) dst[dx] = from_f32<T>(0.f);
-      }
+      const int c = row / a.p, dy = row - c * a.p;
+      const bool row_ok = row < rows_total;
+      stage_row(pbase + (int64_t)c * a.chan_stride + (int64_t)dy * a.W, m_ok && row_ok,
+                sP + sl * PE_STR + rl * 16);
+      stage_row(wbase + (int64_t)row * a.p, n_ok && row_ok, sW + sl * PE_STR + rl * 16);
     }
     __syncthreads();
 #pragma unroll
