@@ -3,8 +3,8 @@
 // Structure (wave64, v_mfma_f32_32x32x16): a workgroup of 8 waves owns 256 query
 // rows of one (batch, q-head) (4 waves / 128 rows for short queries); each wave keeps
 // its 32 query rows as MFMA B fragments in registers for the whole kernel.  K/V tiles
-// of 64 keys are double-buffered row-major in LDS and shared by the waves; the next
-// tile's global loads are in flight while the current one is multiplied.  The score tile is computed
+// of 64 keys arrive by LDS-DMA into a 3-stage ring shared by the waves, two tiles ahead
+// of the math (counted vmcnt, one barrier per tile).  The score tile is computed
 // TRANSPOSED, S^T = K . Q^T, so every lane owns one query column: the softmax
 // row statistics are per-lane scalars (one cross-half shuffle per tile), and the
 // P^T accumulator registers are, after a bf16 pack, directly the B operand of
@@ -16,7 +16,7 @@
 // causal, no positional encoding, scale 1/sqrt(d)), SDPA (:1300-1307,
 // cross_attention.py:310-317 non-causal), flash_attn_varlen_qkvpacked_func
 // (flash_attention_class.py:59-66).
-#include "common.hpp"
+#include "ssd_common.hpp"
 
 namespace {
 
@@ -58,29 +58,28 @@ struct AttnArgs {
 };
 
 // KS = ceil(D/16) k-steps of QK^T, DT = ceil(D/32) d-tiles of PV, NW waves per workgroup.
-// K/V tiles are double-buffered in LDS: the global loads of tile j+1 are issued before the
-// math of tile j and land in registers while it runs; they are written to the other buffer
-// after it, so there is ONE barrier per tile and HBM/L2 latency hides under the MFMAs.
+// K/V tiles of 64 keys go global -> LDS by LDS-DMA (global_load_lds_dwordx4, 16 bytes per
+// lane, no VGPR round trip: staging through registers cost a third of the kernel) into a
+// ring of 3 stages, two tiles ahead of the math, with counted vmcnt waits and one barrier
+// per tile.  LDS rows are 256 bytes (128 elements); the 16-byte chunks of a row are
+// XOR-swizzled on the DMA source address so that the row reads of K (ds_read_b128, chunk ^
+// row%16) and the transposing reads of V (ds_read_b64_tr_b16, chunk ^ 4(row%4)) are bank
+// conflict free.  Chunks past head_dim are never written and stay zero from the start.
 template <typename T, int KS, int DT, int NW>
 __global__ __launch_bounds__(NW * 64) void flash_fwd_kernel(AttnArgs a) {
   typedef typename Frag<T>::v8 v8;
   typedef typename Frag<T>::v4 v4;
-  constexpr int THREADS = NW * 64;
   constexpr int QB = NW * FA_QW;     // query rows per workgroup
-  constexpr int DKP = KS * 16;       // padded K row (elements)
-  constexpr int DVP = DT * 32;       // padded V row
-  constexpr int KSTR = DKP + 8;      // +16 B: conflict-free ds_read_b128 across rows
-  // V row stride == 16 or 48 dwords (mod 64): the 4 rows of a tr-read block land
-  // on disjoint bank quarters
-  constexpr int VSTR = (DVP % 64 == 32) ? DVP : DVP + 32;
-  constexpr int KCH = DKP / 8, VCH = DVP / 8;           // 16-byte chunks per row
-  constexpr int NKR = (FA_KB * KCH + THREADS - 1) / THREADS;
-  constexpr int NVR = (FA_KB * VCH + THREADS - 1) / THREADS;
-  __shared__ __attribute__((aligned(16))) T sK[2][FA_KB * KSTR];
-  __shared__ __attribute__((aligned(16))) T sV[2][FA_KB * VSTR];
+  constexpr int ROWB = 256;          // LDS bytes per key row
+  constexpr int TILEB = FA_KB * ROWB;
+  constexpr int NS = 3;              // ring stages
+  constexpr int PPW = 32 / NW;       // 1 KiB DMA pieces per wave and tile (16 K + 16 V pieces)
+  extern __shared__ __attribute__((aligned(16))) unsigned char fa_smem[];
+  unsigned char* const sK = fa_smem;
+  unsigned char* const sV = fa_smem + NS * TILEB;
 
   const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int r = lane & 31, hh = lane >> 5;
   // causal: launch the heaviest (last) query blocks first
   const int qblk = a.causal ? (gridDim.x - 1 - blockIdx.x) : blockIdx.x;
@@ -94,6 +93,11 @@ __global__ __launch_bounds__(NW * 64) void flash_fwd_kernel(AttnArgs a) {
   const T* qp = (const T*)a.q + (int64_t)b * a.qsb + (int64_t)h * a.qsh;
   const T* kp = (const T*)a.k + (int64_t)b * a.ksb + (int64_t)hk * a.ksh;
   const T* vp = (const T*)a.v + (int64_t)b * a.vsb + (int64_t)hk * a.vsh;
+
+  {   // zero LDS once: pad chunks (columns >= head_dim) are read but never written
+    const v8 z = {};
+    for (int i = tid; i < 2 * NS * TILEB / 16; i += NW * 64) reinterpret_cast<v8*>(fa_smem)[i] = z;
+  }
 
   // Q^T fragments (B operand): lane (r,hh) holds Q[qrow][16ks + 8hh + j]
   v8 qf[KS];
@@ -117,70 +121,87 @@ __global__ __launch_bounds__(NW * 64) void flash_fwd_kernel(AttnArgs a) {
   if (k_end < 0) k_end = 0;
   const int ntiles = (k_end + FA_KB - 1) / FA_KB;
 
-  // ---- staging: global -> registers (issue) ... registers -> LDS (commit) ----
-  v8 rk[NKR], rv[NVR];
-  auto stage_issue = [&](int kt) {
+  // ---- DMA pieces of this wave: piece id pc = wave + NW*i; pc < 16 -> K rows 4pc..4pc+3,
+  // else V rows 4(pc-16)..; lane l carries row 4(pc%16) + l/16, LDS slot l%16 ----
+  int p_row[PPW];
+  unsigned p_off[PPW];            // byte offset from the tile's first key (full tiles)
+  int p_chunk[PPW];               // source 16-byte chunk of the row (>= D/8: nothing to copy)
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int pc = wave + NW * i;
+    const bool isK = pc < 16;
+    const int row = 4 * (pc & 15) + (lane >> 4);
+    const int c = (lane & 15) ^ (isK ? (row & 15) : 4 * (row & 3));
+    p_row[i] = row;
+    p_chunk[i] = c;
+    p_off[i] = (unsigned)(((int64_t)row * (isK ? a.ksl : a.vsl) + c * 8) * (int)sizeof(T));
+  }
+  const int dchunks = D / 8;
+  auto issue_tile = [&](int kt) {
     const int kbase = kt * FA_KB;
+    const int stage = kt % NS;
+    const void* kb = ssdk::uniform_ptr(kp + (int64_t)kbase * a.ksl);
+    const void* vb = ssdk::uniform_ptr(vp + (int64_t)kbase * a.vsl);
+    const int left = a.Lk - kbase;          // rows of this tile that exist
 #pragma unroll
-    for (int i = 0; i < NKR; ++i) {
-      const int idx = tid + i * THREADS;
-      const int row = idx / KCH, c = idx % KCH;
-      const int key = kbase + row;
-      v8 z = {};
-      rk[i] = (idx < FA_KB * KCH && key < a.Lk && c * 8 < D)
-                  ? *(const v8*)(kp + (int64_t)key * a.ksl + c * 8) : z;
-    }
-#pragma unroll
-    for (int i = 0; i < NVR; ++i) {
-      const int idx = tid + i * THREADS;
-      const int row = idx / VCH, c = idx % VCH;
-      const int key = kbase + row;
-      v8 z = {};
-      rv[i] = (idx < FA_KB * VCH && key < a.Lk && c * 8 < D)
-                  ? *(const v8*)(vp + (int64_t)key * a.vsl + c * 8) : z;
-    }
-  };
-  auto stage_commit = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < NKR; ++i) {
-      const int idx = tid + i * THREADS;
-      if (idx < FA_KB * KCH) *(v8*)(sK[buf] + (idx / KCH) * KSTR + (idx % KCH) * 8) = rk[i];
-    }
-#pragma unroll
-    for (int i = 0; i < NVR; ++i) {
-      const int idx = tid + i * THREADS;
-      if (idx < FA_KB * VCH) *(v8*)(sV[buf] + (idx / VCH) * VSTR + (idx % VCH) * 8) = rv[i];
+    for (int i = 0; i < PPW; ++i) {
+      const int pc = wave + NW * i;
+      const bool isK = pc < 16;            // wave-uniform
+      unsigned off = p_off[i];
+      if (left < FA_KB) {                  // last tile: rows past the end repeat the last key (masked later)
+        const int rr = min(p_row[i], left - 1);
+        off = (unsigned)(((int64_t)rr * (isK ? a.ksl : a.vsl) + p_chunk[i] * 8) * (int)sizeof(T));
+      }
+      const unsigned dst = ssdk::lds_addr_of((isK ? sK : sV) + stage * TILEB + (pc & 15) * 1024);
+      if (p_chunk[i] < dchunks) ssdk::glds16(isK ? kb : vb, off, dst);     // EXEC masks the pad chunks
     }
   };
 
-  if (ntiles > 0) {
-    stage_issue(0);
-    stage_commit(0);
+  // fragment read offsets inside a stage
+  int k_rd[KS];                   // K row fragment: row t*32 + r, chunk (2ks + hh) ^ (r % 16)
+  const int kz = (hh ^ (r & 15)) << 4;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) k_rd[ks] = r * ROWB + ((32 * ks) ^ kz);
+  const int q4 = (lane & 15) >> 2, p4 = lane & 3;
+  int v_rd[DT];                   // V^T fragment: row 16s + 4hh + q4 (+8), chunk (4dt + cc) ^ 4 q4
+  {
+    const int cc = 2 * ((lane >> 4) & 1) + (p4 >> 1);
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+      v_rd[dt] = (4 * hh + q4) * ROWB + ((4 * (dt ^ q4) + cc) << 4) + (p4 & 1) * 8;
   }
-  __syncthreads();
+
+  __syncthreads();                 // LDS zeroed before the first copy lands
+  if (ntiles > 0) issue_tile(0);
+  if (ntiles > 1) issue_tile(1);
+  if (ntiles > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
 
   for (int kt = 0; kt < ntiles; ++kt) {
     const int kbase = kt * FA_KB;
-    const int buf = kt & 1;
-    const bool more = kt + 1 < ntiles;
-    if (more) stage_issue(kt + 1);
-    const T* cK = sK[buf];
-    const T* cV = sV[buf];
+    const bool ahead = kt + 2 < ntiles;
+    if (ahead) issue_tile(kt + 2);
+    const unsigned char* cK = sK + (kt % NS) * TILEB;
+    const unsigned char* cV = sV + (kt % NS) * TILEB;
 
     // wave-uniform skip of tiles entirely above this wave's causal diagonal
     const int wave_q_last = q0 + FA_QW - 1;
     if (!(a.causal && kbase > wave_q_last + shift)) {
-      // ---- S^T = K . Q^T  (2 key sub-tiles of 32) ----
+      // ---- S^T = K . Q^T  (2 key sub-tiles of 32); all K fragment reads ahead of the MFMAs ----
       f32x16 sacc[2];
+      v8 kf[2][KS];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) kf[t][ks] = *(const v8*)(cK + t * (32 * ROWB) + k_rd[ks]);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) sacc[t][i] = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          const v8 kf = *(const v8*)(cK + (t * 32 + r) * KSTR + ks * 16 + hh * 8);
-          sacc[t] = Frag<T>::mfma(kf, qf[ks], sacc[t]);
-        }
+        for (int ks = 0; ks < KS; ++ks) sacc[t] = Frag<T>::mfma(kf[t][ks], qf[ks], sacc[t]);
       }
       // ---- mask, running max on the raw scores (the scale is positive, so it commutes with
       // max), then p = 2^(s*scale - m) as one FMA + v_exp per score; packed fp32 math ----
@@ -233,31 +254,42 @@ __global__ __launch_bounds__(NW * 64) void flash_fwd_kernel(AttnArgs a) {
       }
       m_run = m_new;
 
-      // ---- O^T += V^T . P^T over 4 k-steps of 16 keys ----
+      // ---- O^T += V^T . P^T over 4 k-steps of 16 keys; the V^T fragments of k-step s+1 are in
+      // flight while k-step s multiplies ----
+      {
+        auto read_v = [&](int s_, v4 (&lo)[DT], v4 (&hi)[DT]) {
+          // element j of this lane is key row 16s + 8(j>>2) + 4hh + (j&3) of the tile
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int t = s >> 1, rb = (s & 1) * 8;
-        v8 pf;
+          for (int dt = 0; dt < DT; ++dt) {
+            lo[dt] = Frag<T>::tr_read((const T*)(cV + s_ * (16 * ROWB) + v_rd[dt]));
+            hi[dt] = Frag<T>::tr_read((const T*)(cV + s_ * (16 * ROWB) + 8 * ROWB + v_rd[dt]));
+          }
+        };
+        v4 vlo[2][DT], vhi[2][DT];
+        read_v(0, vlo[0], vhi[0]);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pf[j] = from_f32<T>(sacc[t][rb + j]);
-        // element j of this lane is key row 16s + 8(j>>2) + 4hh + (j&3) of the tile
-        const int key0 = s * 16 + 4 * hh;
-        const int q4 = (lane & 15) >> 2, p4 = lane & 3;
-        const int cb = 16 * ((lane >> 4) & 1);
+        for (int s_ = 0; s_ < 4; ++s_) {
+          if (s_ < 3) read_v(s_ + 1, vlo[(s_ + 1) & 1], vhi[(s_ + 1) & 1]);
+          const int t = s_ >> 1, rb = (s_ & 1) * 8;
+          v8 pf;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-          const T* base = cV + (key0 + q4) * VSTR + dt * 32 + cb + 4 * p4;
-          const v4 lo = Frag<T>::tr_read(base);
-          const v4 hi = Frag<T>::tr_read(base + 8 * VSTR);
-          v8 vf;
+          for (int j = 0; j < 8; ++j) pf[j] = from_f32<T>(sacc[t][rb + j]);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi[j]; }
-          oacc[dt] = Frag<T>::mfma(vf, pf, oacc[dt]);
+          for (int dt = 0; dt < DT; ++dt) {
+            v8 vf;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { vf[j] = vlo[s_ & 1][dt][j]; vf[4 + j] = vhi[s_ & 1][dt][j]; }
+            oacc[dt] = Frag<T>::mfma(vf, pf, oacc[dt]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
-    if (more) stage_commit(buf ^ 1);
-    __syncthreads();
+    // tile kt+1 (issued an iteration ago) must have landed; this iteration's copies stay in flight
+    if (ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
   }
 
   // ---- epilogue: normalise and store O[q][d] ----
@@ -286,12 +318,26 @@ __global__ __launch_bounds__(NW * 64) void flash_fwd_kernel(AttnArgs a) {
 
 template <typename T, int KS, int DT>
 int launch_fa_d(const AttnArgs& a, int B, hipStream_t st) {
+  constexpr int lds = 2 * 3 * FA_KB * 256;     // K and V rings: 3 stages x 64 rows x 256 B
+  hipError_t e;
   if (a.Lq > 128) {
-    dim3 grid((a.Lq + 255) / 256, a.Hq, B);
-    flash_fwd_kernel<T, KS, DT, 8><<<grid, 512, 0, st>>>(a);
+    e = hipFuncSetAttribute((const void*)flash_fwd_kernel<T, KS, DT, 8>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess) {
+      dim3 grid((a.Lq + 255) / 256, a.Hq, B);
+      flash_fwd_kernel<T, KS, DT, 8><<<grid, 512, lds, st>>>(a);
+    }
   } else {
-    dim3 grid((a.Lq + 127) / 128, a.Hq, B);
-    flash_fwd_kernel<T, KS, DT, 4><<<grid, 256, 0, st>>>(a);
+    e = hipFuncSetAttribute((const void*)flash_fwd_kernel<T, KS, DT, 4>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess) {
+      dim3 grid((a.Lq + 127) / 128, a.Hq, B);
+      flash_fwd_kernel<T, KS, DT, 4><<<grid, 256, lds, st>>>(a);
+    }
+  }
+  if (e != hipSuccess) {
+    tv_set_error("flash_attn: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    return TV_ERR_LAUNCH;
   }
   TV_LAUNCH_CHECK();
 }
@@ -330,6 +376,9 @@ extern "C" int tv_flash_attn_fwd(const void* q, const void* k, const void* v, vo
     TV_UNSUPPORTED("flash_attn: o strides must be multiples of 4 elements");
   if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15))
     TV_UNSUPPORTED("flash_attn: q/k/v must be 16-byte aligned");
+  // the K/V copies address a 64-key tile with 32-bit byte offsets from its first key
+  if (64 * k_stride_l * 2 >= (1ll << 31) || 64 * v_stride_l * 2 >= (1ll << 31))
+    TV_UNSUPPORTED("flash_attn: k/v row stride too large");
   if (seqlen_q == 0) return TV_OK;
   AttnArgs a;
   a.q = q; a.k = k; a.v = v; a.o = o; a.lse = (float*)lse;
