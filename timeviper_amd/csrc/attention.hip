@@ -64,7 +64,7 @@ struct AttnArgs {
 // per tile.  LDS rows are 256 bytes (128 elements); the 16-byte chunks of a row are
 // XOR-swizzled on the DMA source address so that the row reads of K (ds_read_b128, chunk ^
 // row%16) and the transposing reads of V (ds_read_b64_tr_b16, chunk ^ 4(row%4)) are bank
-// conflict free.  Chunks past head_dim are never written and stay zero from the start.
+// conflict free.  Chunks past head_dim are never copied (the K ones QK^T reads are zeroed once).
 template <typename T, int KS, int DT, int NW>
 __global__ __launch_bounds__(NW * 64) void flash_fwd_kernel(AttnArgs a) {
   typedef typename Frag<T>::v8 v8;
@@ -94,9 +94,16 @@ __global__ __launch_bounds__(NW * 64) void flash_fwd_kernel(AttnArgs a) {
   const T* kp = (const T*)a.k + (int64_t)b * a.ksb + (int64_t)hk * a.ksh;
   const T* vp = (const T*)a.v + (int64_t)b * a.vsb + (int64_t)hk * a.vsh;
 
-  {   // zero LDS once: pad chunks (columns >= head_dim) are read but never written
+  // K chunks between head_dim and the padded 16*KS columns are read by QK^T (against zero Q
+  // columns) but never copied: zero them once so that stale LDS bits cannot be NaN/Inf.  (V
+  // chunks past head_dim only feed output rows that are never stored.)
+  if (D < 16 * KS) {
     const v8 z = {};
-    for (int i = tid; i < 2 * NS * TILEB / 16; i += NW * 64) reinterpret_cast<v8*>(fa_smem)[i] = z;
+    const int c0 = D / 8, nc = 2 * KS - c0;
+    for (int i = tid; i < NS * FA_KB * nc; i += NW * 64) {
+      const int row = (i / nc) % FA_KB, st = i / (nc * FA_KB), c = c0 + i % nc;
+      *reinterpret_cast<v8*>(sK + st * TILEB + row * ROWB + ((c ^ (row & 15)) << 4)) = z;
+    }
   }
 
   // Q^T fragments (B operand): lane (r,hh) holds Q[qrow][16ks + 8hh + j]
@@ -137,24 +144,25 @@ __global__ __launch_bounds__(NW * 64) void flash_fwd_kernel(AttnArgs a) {
     p_off[i] = (unsigned)(((int64_t)row * (isK ? a.ksl : a.vsl) + c * 8) * (int)sizeof(T));
   }
   const int dchunks = D / 8;
-  auto issue_tile = [&](int kt) {
+  auto issue_piece = [&](int kt, int i) {          // piece i (0..PPW-1) of tile kt
     const int kbase = kt * FA_KB;
     const int stage = kt % NS;
-    const void* kb = ssdk::uniform_ptr(kp + (int64_t)kbase * a.ksl);
-    const void* vb = ssdk::uniform_ptr(vp + (int64_t)kbase * a.vsl);
+    const int pc = wave + NW * i;
+    const bool isK = pc < 16;            // wave-uniform
+    const void* tb = ssdk::uniform_ptr(isK ? (const void*)(kp + (int64_t)kbase * a.ksl)
+                                           : (const void*)(vp + (int64_t)kbase * a.vsl));
     const int left = a.Lk - kbase;          // rows of this tile that exist
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-      const int pc = wave + NW * i;
-      const bool isK = pc < 16;            // wave-uniform
-      unsigned off = p_off[i];
-      if (left < FA_KB) {                  // last tile: rows past the end repeat the last key (masked later)
-        const int rr = min(p_row[i], left - 1);
-        off = (unsigned)(((int64_t)rr * (isK ? a.ksl : a.vsl) + p_chunk[i] * 8) * (int)sizeof(T));
-      }
-      const unsigned dst = ssdk::lds_addr_of((isK ? sK : sV) + stage * TILEB + (pc & 15) * 1024);
-      if (p_chunk[i] < dchunks) ssdk::glds16(isK ? kb : vb, off, dst);     // EXEC masks the pad chunks
+    unsigned off = p_off[i];
+    if (left < FA_KB) {                  // last tile: rows past the end repeat the last key (masked later)
+      const int rr = min(p_row[i], left - 1);
+      off = (unsigned)(((int64_t)rr * (isK ? a.ksl : a.vsl) + p_chunk[i] * 8) * (int)sizeof(T));
     }
+    const unsigned dst = ssdk::lds_addr_of((isK ? sK : sV) + stage * TILEB + (pc & 15) * 1024);
+    if (p_chunk[i] < dchunks) ssdk::glds16(tb, off, dst);     // EXEC masks the pad chunks
+  };
+  auto issue_tile = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) issue_piece(kt, i);
   };
 
   // fragment read offsets inside a stage
@@ -181,14 +189,16 @@ __global__ __launch_bounds__(NW * 64) void flash_fwd_kernel(AttnArgs a) {
   for (int kt = 0; kt < ntiles; ++kt) {
     const int kbase = kt * FA_KB;
     const bool ahead = kt + 2 < ntiles;
-    if (ahead) issue_tile(kt + 2);
     const unsigned char* cK = sK + (kt % NS) * TILEB;
     const unsigned char* cV = sV + (kt % NS) * TILEB;
 
     // wave-uniform skip of tiles entirely above this wave's causal diagonal
     const int wave_q_last = q0 + FA_QW - 1;
-    if (!(a.causal && kbase > wave_q_last + shift)) {
-      // ---- S^T = K . Q^T  (2 key sub-tiles of 32); all K fragment reads ahead of the MFMAs ----
+    const bool active = !(a.causal && kbase > wave_q_last + shift);
+    if (!active && ahead) issue_tile(kt + 2);
+    if (active) {
+      // ---- S^T = K . Q^T  (2 key sub-tiles of 32); all K fragment reads ahead of the MFMAs;
+      // the copies of tile kt+2 are issued between the MFMAs, whose pipe time hides them ----
       f32x16 sacc[2];
       v8 kf[2][KS];
 #pragma unroll
@@ -201,7 +211,17 @@ __global__ __launch_bounds__(NW * 64) void flash_fwd_kernel(AttnArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) sacc[t][i] = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) sacc[t] = Frag<T>::mfma(kf[t][ks], qf[ks], sacc[t]);
+        for (int ks = 0; ks < KS; ++ks) {
+          sacc[t] = Frag<T>::mfma(kf[t][ks], qf[ks], sacc[t]);
+          // PPW pieces spread over the 2*KS MFMAs
+          constexpr int every = (2 * KS) / PPW > 0 ? (2 * KS) / PPW : 1;
+          const int idx = t * KS + ks;
+          if (ahead && idx % every == 0 && idx / every < PPW) issue_piece(kt + 2, idx / every);
+        }
+      }
+      if (ahead) {      // pieces that did not fit the spacing (PPW > 2*KS)
+#pragma unroll
+        for (int i = (2 * KS) / ((2 * KS) / PPW > 0 ? (2 * KS) / PPW : 1); i < PPW; ++i) issue_piece(kt + 2, i);
       }
       // ---- mask, running max on the raw scores (the scale is positive, so it commutes with
       // max), then p = 2^(s*scale - m) as one FMA + v_exp per score; packed fp32 math ----
