@@ -136,6 +136,9 @@ int tv_rmsnorm_gated_fwd(const void* x, const void* z, const void* weight,
  * chunk-invariant up to rounding) and is not part of the ABI.
  * total_decay (B,H) fp32, optional: sum_t dt_t*A_h over the sequence, the
  * per-head log-decay a sequence-sharded caller needs to chain shard states.
+ * workspace: tv_ssd_scan_workspace_bytes() bytes of device memory (may be 0 /
+ * NULL: the workspace-free kernels are used then); nothing persists in it
+ * between calls.  seqlen == 0 is valid (the state passes through).
  * --------------------------------------------------------------------- */
 size_t tv_ssd_scan_workspace_bytes(int batch, int seqlen, int nheads,
                                    int headdim, int ngroups, int dstate,
@@ -155,7 +158,12 @@ int tv_ssd_scan_fwd(const void* x, const void* dt, const void* A,
                     void* stream);
 
 /* Force a particular implementation (testing/benchmarking):
- * 0 = auto, 1 = generic fp32 recurrence kernel, 2 = MFMA chunk-march kernel. */
+ * 0 = auto (the slice march where it applies and a workspace is given, else the
+ *     chunk march, else the generic kernel),
+ * 1 = generic fp32 recurrence kernel (any dtype / shape),
+ * 2 = MFMA chunk-march kernel (bf16, d_state 128; needs no workspace),
+ * 3 = MFMA slice-march kernel (bf16, d_state 128; C.B^T pre-pass into `workspace`,
+ *     tv_ssd_scan_workspace_bytes() bytes, 16-byte aligned). */
 void tv_ssd_scan_set_impl(int impl);
 
 /* Single-token decode step, replaces selective_state_update (:528-539) with
