@@ -67,27 +67,40 @@ __global__ __launch_bounds__(192) void ssd_cb_kernel(CbArgs a) {
   const int rmax = a.L - 1 - t0;   // rows past the sequence end repeat the last row (finite)
   const bf16_t* Bg = a.Bm + (int64_t)b * a.bsb + (int64_t)g * a.bsg + (int64_t)t0 * a.bsl;
   const bf16_t* Cg = a.Cm + (int64_t)b * a.csb + (int64_t)g * a.csg + (int64_t)t0 * a.csl;
+  // wave 0: fragments (2,0) (2,1); wave 1: (3,0) (3,1) — one C t-tile against both s-pairs;
+  // wave 2: (0,0) (1,0) — two C t-tiles against s-pair 0.  Every operand row is loaded once
+  // per wave (20 / 20 / 16 loads of 16 bytes per lane).
+  bf16x8 cf[2][4], b0[2][4], b1[2][4];
+  const int nct = wave == 2 ? 2 : 1, nsp = wave == 2 ? 1 : 2;
+  const int ti0 = wave == 0 ? 2 : wave == 1 ? 3 : 0;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    if (u < nct) {
+      const bf16_t* cp = Cg + (int64_t)min(16 * (ti0 + u) + lc, rmax) * a.csl + 8 * kq;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) cf[u][ks] = *(const bf16x8*)(cp + 32 * ks);
+    }
+    if (u < nsp) {
+      const int s_lo = 32 * u + 8 * (lc >> 2) + (lc & 3);
+      const bf16_t* bp0 = Bg + (int64_t)min(s_lo, rmax) * a.bsl + 8 * kq;
+      const bf16_t* bp1 = Bg + (int64_t)min(s_lo + 4, rmax) * a.bsl + 8 * kq;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        b0[u][ks] = *(const bf16x8*)(bp0 + 32 * ks);
+        b1[u][ks] = *(const bf16x8*)(bp1 + 32 * ks);
+      }
+    }
+  }
 #pragma unroll
   for (int ff = 0; ff < 2; ++ff) {
-    const int f = 2 * wave + ff;
-    const int ti = frag_ti(f), sp = frag_sp(f);
-    const int tr = min(16 * ti + lc, rmax);
-    const int s_lo = 32 * sp + 8 * (lc >> 2) + (lc & 3);
-    const bf16_t* cp = Cg + (int64_t)tr * a.csl + 8 * kq;
-    const bf16_t* bp0 = Bg + (int64_t)min(s_lo, rmax) * a.bsl + 8 * kq;
-    const bf16_t* bp1 = Bg + (int64_t)min(s_lo + 4, rmax) * a.bsl + 8 * kq;
+    // fragment index in the (0,0) (1,0) (2,0) (2,1) (3,0) (3,1) order
+    const int f = wave == 0 ? 2 + ff : wave == 1 ? 4 + ff : ff;
+    const int ci = wave == 2 ? ff : 0, si = wave == 2 ? 0 : ff;
     f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0;
-    bf16x8 cf[4], b0[4], b1[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      cf[ks] = *(const bf16x8*)(cp + 32 * ks);
-      b0[ks] = *(const bf16x8*)(bp0 + 32 * ks);
-      b1[ks] = *(const bf16x8*)(bp1 + 32 * ks);
-    }
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      d0 = mfma16(b0[ks], cf[ks], d0);
-      d1 = mfma16(b1[ks], cf[ks], d1);
+      d0 = mfma16(b0[si][ks], cf[ci][ks], d0);
+      d1 = mfma16(b1[si][ks], cf[ci][ks], d1);
     }
     bf16x8 o;
 #pragma unroll
