@@ -223,6 +223,23 @@ int tv_gather_rows(const void* src, const int64_t* index, void* dst,
                    int64_t n_rows, int dim, int64_t src_stride,
                    int64_t dst_stride, int dtype, void* stream);
 
+/* ------------------------------------------------------------------------
+ * V3  ToMe projector: ONE round of bipartite soft matching + size-weighted merge,
+ * all frames at once.  Replaces bipartite_soft_matching + merge_wavg
+ * (timeviper/model/projector/tome.py:14-83) as called per round by
+ * ToMe16_mlp_hd64.merge_tokens (:118-152).
+ *   x (frames, tokens, dim) contiguous; size_in (frames, tokens) in x's dtype or
+ *   NULL (all ones); r even tokens per frame are merged into their best odd match.
+ *   x_out (frames, tokens - r, dim) = [kept evens, descending score | odds],
+ *   size_out (frames, tokens - r).  metric = mean over `heads` head slices.
+ *   workspace: tv_tome_workspace_bytes() bytes, 16-byte aligned.
+ * --------------------------------------------------------------------- */
+size_t tv_tome_workspace_bytes(int frames, int tokens, int dim, int heads);
+int tv_tome_merge_round(const void* x, const void* size_in, void* x_out,
+                        void* size_out, int frames, int tokens, int dim,
+                        int heads, int r, int dtype, void* workspace,
+                        size_t workspace_bytes, void* stream);
+
 /* uniform keep indices, reference :1946-1953: torch.linspace(0, n-1, keep,
  * dtype=long) with CPU (double-step, symmetric halves) semantics; out int64
  * (keep) on the device.  Bit-exact with the CPU reference for any n<2^31.  */

@@ -502,3 +502,42 @@ def test_zero_length_inputs(K):
     full = K.causal_conv1d_xbc(xs, w, b, H * P, G, N)[0]
     one = K.causal_conv1d_xbc(xs[:, 3:], w, b, H * P, G, N, halo=xs[:, :3].contiguous())[0]
     assert torch.equal(one, full[:, 3:])
+
+
+# ---------------------------------------------------------------- ToMe (V3)
+def test_tome_hip_matches_reference_golden(K):
+    """csrc/tome.hip, fp32, against the reference's own ToMe output (tests/golden/tome.npz:
+    729 -> 16 tokens in 6 rounds, and 4-frame clips of 100 tokens)."""
+    from timeviper_amd.model.projector.tome import ToMe16_mlp_hd64
+    g = load_golden("tome")
+    proj = ToMe16_mlp_hd64(64, 48, num_compressed_tokens=16)
+    proj.load_state_dict(golden_state_dict(g), strict=True)
+    proj = proj.to(DEV).eval()
+    x = torch.from_numpy(g["x"]).to(DEV)
+    with torch.no_grad():
+        merged = proj.merge_tokens(x, 16, "raw")
+        y = proj(x, compress=True, local_num_frames=1)
+        y2 = proj(torch.from_numpy(g["x2"]).to(DEV), compress=True, local_num_frames=4)
+    close(merged, g["merged"], 1e-4, 1e-5, "merged tokens")
+    close(y, g["y"], 1e-4, 1e-5, "projector output")
+    close(y2, g["y2"], 1e-4, 1e-5, "4-frame clips")
+
+
+@pytest.mark.parametrize("dtype,F_,T,C,heads", [(torch.bfloat16, 5, 729, 1152, 16), (torch.float32, 3, 257, 128, 16),
+                                                (torch.bfloat16, 2, 1024, 1408, 16), (torch.float32, 4, 7, 64, 16)])
+def test_tome_round_vs_torch_restatement(K, dtype, F_, T, C, heads):
+    """one round against the step-by-step torch restatement of tome.py:14-83 (fp64 on the CPU);
+    sizes carried from a previous round; r up to half the tokens"""
+    from timeviper_amd.model.projector.tome import bipartite_soft_matching, merge_wavg
+    g = torch.Generator().manual_seed(T + C)
+    x = torch.randn(F_, T, C, generator=g).to(dtype)
+    size = torch.randint(1, 5, (F_, T, 1), generator=g).to(dtype)
+    for r, sz in ((T // 2, None), (max(1, T // 5), size)):
+        xd = x.double()
+        metric = xd.reshape(F_, T, heads, C // heads).mean(2)
+        merge, _ = bipartite_soft_matching(metric, r)
+        x_ref, s_ref = merge_wavg(merge, xd, None if sz is None else sz.double())
+        xo, so = K.tome_merge_round(x.to(DEV), None if sz is None else sz.to(DEV), r, heads)
+        assert xo.shape == x_ref.shape and so.shape == s_ref.shape
+        assert torch.equal(so.float().cpu(), s_ref.float()), "merged sizes differ (different matching)"
+        close(xo, x_ref.float(), *TOL[dtype], f"r={r}")

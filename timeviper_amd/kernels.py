@@ -432,6 +432,24 @@ def attn_rank_scores(q_row: torch.Tensor, k: torch.Tensor, n_keys: int, vis_star
 
 
 # ---------------------------------------------------------------- patch embed
+def tome_merge_round(x, size, r: int, heads: int = 16):
+    """One ToMe round for every frame (tome.py:14-83): x (F, T, C), size (F, T, 1) or None ->
+    (x' (F, T-r, C), size' (F, T-r, 1)); rows = [kept even tokens, descending match score |
+    odd tokens with their merged partners], size-weighted average."""
+    _gpu(x, size)
+    F_, T, Cc = x.shape
+    x = x.contiguous()
+    sz = None if size is None else size.reshape(F_, T).to(x.dtype).contiguous()
+    xo = torch.empty((F_, T - r, Cc), dtype=x.dtype, device=x.device)
+    so = torch.empty((F_, T - r, 1), dtype=x.dtype, device=x.device)
+    lib = _capi.lib()
+    ws_bytes = lib.tv_tome_workspace_bytes(F_, T, Cc, heads)
+    ws = torch.empty(max(int(ws_bytes), 16), dtype=torch.uint8, device=x.device)
+    check(lib.tv_tome_merge_round(_p(x), _p(sz), _p(xo), _p(so), F_, T, Cc, heads, int(r), _dt(x),
+                                  _p(ws), int(ws_bytes), _stream()), "tv_tome_merge_round")
+    return xo, so
+
+
 def patch_embed(pixels, weight, bias=None, pos=None, patch: Optional[int] = None):
     """pixels (F, C, H, W) -> (F, gh*gw, Dout); weight is the Conv2d weight
     (Dout, C, p, p) (or Conv3d (Dout, C, 1, p, p)); pos (gh*gw, Dout) optional."""

@@ -1,13 +1,14 @@
 """ToMe token merging 729 -> 16 tokens/frame + MLP (reference
-timeviper/model/projector/tome.py:14-231).  SURVEY.md §8f "next" row 1: the
-matching runs as batched torch ops on the GPU for now (12 launches x 6 rounds per
-clip); arithmetic follows the reference step by step so that merged tokens agree
-with it whenever `argsort` has no ties."""
+timeviper/model/projector/tome.py:14-231).  On the GPU every round is one call of the HIP
+operator `kernels.tome_merge_round` (metric, bipartite matching, sort, size-weighted merge:
+csrc/tome.hip); the torch functions below restate the reference step by step and are what
+the CPU tests check against the reference golden vectors."""
 from typing import Callable, Dict, Tuple, Union
 
 import torch
 import torch.nn as nn
 
+from ... import kernels as K
 from .mlp import _interleave
 
 
@@ -95,9 +96,12 @@ class ToMe16_mlp_hd64(nn.Module):
         b, p, c = x.shape
         head = self.num_attention_heads
         for r in merge_schedule(p, target_num_token):
-            metric = x.reshape(b, p, head, c // head).mean(2)
-            merge, _ = bipartite_soft_matching(metric, r)
-            x, size = merge_wavg(merge, x, size)
+            if x.is_cuda:       # HIP kernels: metric, matching, sort and weighted merge of a round
+                x, size = K.tome_merge_round(x, size, min(r, p // 2), head)
+            else:               # host-side restatement (CPU tests against the reference golden)
+                metric = x.reshape(b, p, head, c // head).mean(2)
+                merge, _ = bipartite_soft_matching(metric, r)
+                x, size = merge_wavg(merge, x, size)
             p = x.shape[1]
         if token_order in ("ascending", "descending"):
             idx = size.squeeze(-1).argsort(dim=1, descending=token_order == "descending")
