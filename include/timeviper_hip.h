@@ -224,6 +224,22 @@ int tv_gather_rows(const void* src, const int64_t* index, void* dst,
                    int64_t dst_stride, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Qwen2 backbone ("next" row, BASELINE config 5).
+ * tv_rope_fwd: rotary embedding in place on x (rows, heads, headdim) with element
+ *   strides (x_stride_l, x_stride_h); cos / sin (rows, headdim) contiguous in x's
+ *   dtype (the tables Qwen2RotaryEmbedding returns, modeling_qwen2.py:362-385):
+ *   x' = x*cos + rotate_half(x)*sin  (apply_rotary_pos_emb :89-113, called :211-214).
+ * tv_silu_mul_fwd: y = silu(gate) * up  (Qwen2MLP.forward :78-80), row strides in
+ *   elements (gate and up may be the two halves of one fused projection).
+ * --------------------------------------------------------------------- */
+int tv_rope_fwd(void* x, const void* cos, const void* sin, int64_t rows,
+                int heads, int headdim, int64_t x_stride_l, int64_t x_stride_h,
+                int dtype, void* stream);
+int tv_silu_mul_fwd(const void* gate, const void* up, void* y, int64_t rows,
+                    int dim, int64_t gate_stride, int64_t up_stride,
+                    int64_t y_stride, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------
  * V3  ToMe projector: ONE round of bipartite soft matching + size-weighted merge,
  * all frames at once.  Replaces bipartite_soft_matching + merge_wavg
  * (timeviper/model/projector/tome.py:14-83) as called per round by

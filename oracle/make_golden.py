@@ -345,3 +345,77 @@ def make_internvideo2_golden():
 
 if __name__ == "__main__" and os.environ.get("GOLDEN_ONLY") in (None, "internvideo2"):
     make_internvideo2_golden()
+
+
+@torch.no_grad()
+def make_qwen2_golden():
+    """G12: the reference's Qwen2ForCausalLM (llm_repo/qwen2/modeling_qwen2.py) at toy width, fp32,
+    eager attention: plain, pdrop without merge, pdrop + TransV CrossAttention."""
+    sys.path.insert(0, REF)
+    for name, path in [("timeviper", f"{REF}/timeviper"), ("timeviper.model", f"{REF}/timeviper/model"),
+                       ("timeviper.model.llm", f"{REF}/timeviper/model/llm"),
+                       ("timeviper.model.llm.llm_repo", f"{REF}/timeviper/model/llm/llm_repo"),
+                       ("timeviper.model.llm.llm_repo.qwen2", f"{REF}/timeviper/model/llm/llm_repo/qwen2")]:
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__path__ = [path]
+            sys.modules[name] = m
+    # The reference targets transformers 4.56; the 5.x in this image no longer registers the
+    # "default" rotary initialiser its Qwen2RotaryEmbedding looks up (:354).  Restated from the
+    # published 4.56 `_compute_default_rope_parameters`: inv_freq = base^(-2i/d), scaling 1.
+    import transformers.modeling_rope_utils as ru
+
+    def default_rope(config, device=None, seq_len=None, **kw):
+        d = getattr(config, "head_dim", None) or config.hidden_size // config.num_attention_heads
+        base = getattr(config, "rope_theta", None) or config.rope_parameters["rope_theta"]
+        inv = 1.0 / (base ** (torch.arange(0, d, 2, dtype=torch.int64).to(device=device, dtype=torch.float) / d))
+        return inv, 1.0
+    ru.ROPE_INIT_FUNCTIONS.setdefault("default", default_rope)
+    q = importlib.import_module("timeviper.model.llm.llm_repo.qwen2.modeling_qwen2")
+    # every parameter is overwritten below: skip the 5.x weight-init pass, which expects rotary
+    # modules of its own vintage
+    q.Qwen2PreTrainedModel._init_weights = lambda self, module: None
+    # 5.x renamed create_causal_mask's `input_embeds` argument
+    _ccm = q.create_causal_mask
+
+    def create_causal_mask(**kw):
+        if "input_embeds" in kw:
+            kw["inputs_embeds"] = kw.pop("input_embeds")
+        kw.pop("cache_position", None)            # dropped from the 5.x signature
+        return _ccm(**kw)
+    q.create_causal_mask = create_causal_mask
+    # "uni" stages only: the reference's Qwen2 "attn" ranking cannot run — its mask row is taken
+    # from a (1,1,L,L) tensor (:560-569) and broadcasts the scores to 4-D, after which the vision
+    # slice (:651-653) is empty and torch.cat (:692) raises.  (The nano file keeps the mask 2-D.)
+    pd = "uni_1_0.75-uni_3_0.5-uni_4_0.25"
+    for tag, kw in [("plain", {}), ("pdrop_nomerge", dict(use_pdrop=True, pdrop_type=pd)),
+                    ("pdrop_transv", dict(use_pdrop=True, pdrop_type=pd, merge_module="CrossAttention"))]:
+        cfg = q.Qwen2Config(vocab_size=64, hidden_size=64, intermediate_size=96, num_hidden_layers=6,
+                            num_attention_heads=4, num_key_value_heads=2, max_position_embeddings=512,
+                            rope_theta=10000.0, rms_norm_eps=1e-6, pad_token_id=None, **kw)
+        cfg._attn_implementation = "eager"
+        torch.manual_seed(31)
+        model = q.Qwen2ForCausalLM(cfg).eval().float()
+        g = torch.Generator().manual_seed(32)
+        for n, p in model.named_parameters():
+            if n.endswith("alpha"):
+                p.fill_(0.7)
+            elif "norm" in n:
+                p.copy_(torch.rand(p.shape, generator=g) + 0.5)
+            elif n.endswith("bias"):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+            else:
+                p.copy_(torch.randn(p.shape, generator=g) * (0.4 if ("q_proj" in n or "k_proj" in n) else 0.08))
+        ids = torch.randint(0, 64, (1, 43), generator=g)
+        args = {}
+        if kw:
+            model.set_pdrop_args(**model.model.pdrop_args)
+            args["train_pdrop_args"] = {"first_vision_token_positions": [3], "num_vision_tokens": [24],
+                                        "text_prompt_lens": [19]}
+        out = model(input_ids=ids, use_cache=False, **args)
+        npz(f"qwen2_{tag}", ids=ids, logits=out.logits,
+            **{"w." + k: v for k, v in model.state_dict().items()})
+
+
+if __name__ == "__main__" and os.environ.get("GOLDEN_ONLY") in (None, "qwen2"):
+    make_qwen2_golden()

@@ -205,15 +205,15 @@ def uniform_keep_indices_ref(n_tokens: int, keep: int) -> torch.Tensor:
 
 
 def attn_rank_scores_ref(hidden, q_w, k_w, num_heads, num_kv_heads, head_dim, query_row,
-                         vis_start, n_vis):
+                         vis_start, n_vis, q_b=None, k_b=None):
     """pdrop "attn" importance (:1822-1857, :1914-1939) for batch 1 / eval:
     q,k = q_proj/k_proj of the UN-NORMED hidden states; one query row; causal row of
     the mask; softmax in fp32 cast back to the activation dtype; mean over heads;
     vision span.  hidden (L, Dm).  Never builds the (L,L) mask (only row
     `query_row` of it is used by the reference)."""
     dt = hidden.dtype
-    q = (hidden[query_row:query_row + 1] @ q_w.t()).view(1, num_heads, head_dim).transpose(0, 1)
-    k = (hidden @ k_w.t()).view(-1, num_kv_heads, head_dim).transpose(0, 1)
+    q = F.linear(hidden[query_row:query_row + 1], q_w, q_b).view(1, num_heads, head_dim).transpose(0, 1)
+    k = F.linear(hidden, k_w, k_b).view(-1, num_kv_heads, head_dim).transpose(0, 1)
     k = k.repeat_interleave(num_heads // num_kv_heads, dim=0)           # repeat_kv :1845
     w = torch.matmul(q, k.transpose(1, 2)) / math.sqrt(head_dim)         # (H,1,L) :1923-1927
     mask_row = torch.zeros(hidden.shape[0], dtype=dt)

@@ -84,6 +84,16 @@ def _patch_video(pix, w, b=None, pos=None):
     return y.to(pix.dtype)
 
 
+def _rope_(q, k, cos, sin):
+    def rot(x):
+        h = x.shape[-1] // 2
+        return torch.cat((-x[..., h:], x[..., :h]), dim=-1)
+    c, s_ = cos[:, :, None, :].to(q.dtype), sin[:, :, None, :].to(q.dtype)
+    q.copy_(q * c + rot(q) * s_)
+    k.copy_(k * c + rot(k) * s_)
+    return q, k
+
+
 def _dropped(keep_sorted, start, n):
     allidx = torch.arange(start, start + n)
     return allidx[~torch.isin(allidx, keep_sorted)]
@@ -104,6 +114,8 @@ def cpu_kernels():
         "patch_embed": lambda pix, w, b=None, pos=None, patch=None:
             R.patch_embed_ref(pix, w, b, pos).to(pix.dtype),
         "patch_embed_video": _patch_video,
+        "apply_rotary_pos_emb_": _rope_,
+        "silu_mul": lambda g, u: torch.nn.functional.silu(g) * u,
     }
     saved = {k: getattr(K, k) for k in patches}
     for k, v in patches.items():

@@ -106,3 +106,50 @@ def test_internvideo2_mirror_matches_reference(case, is_video):
     with cpu_kernels():
         out = tower(torch.from_numpy(g[case]), is_video=is_video)
     np.testing.assert_allclose(out.numpy(), g[case + "_out"], rtol=1e-4, atol=3e-5)
+
+
+@pytest.mark.parametrize("tag,extra", [("plain", {}), ("pdrop_nomerge", dict(use_pdrop=True)),
+                                       ("pdrop_transv", dict(use_pdrop=True, merge_module="CrossAttention"))])
+def test_qwen2_mirror_matches_reference(tag, extra):
+    """Qwen2 mirror: reference state dict loads strict; forward (operators replaced by their CPU
+    restatements) reproduces the reference logits, including pdrop + TransV."""
+    from cpu_kernel_shim import cpu_kernels
+    from timeviper_amd.model.llm.qwen2 import Qwen2Config, Qwen2ForCausalLM
+    g = load_golden(f"qwen2_{tag}")
+    pd = "uni_1_0.75-uni_3_0.5-uni_4_0.25"
+    cfg = Qwen2Config(vocab_size=64, hidden_size=64, intermediate_size=96, num_hidden_layers=6,
+                      num_attention_heads=4, num_key_value_heads=2, rope_theta=10000.0,
+                      pdrop_type=pd if extra else None, **extra)
+    model = Qwen2ForCausalLM(cfg).eval()
+    model.load_state_dict(golden_state_dict(g), strict=True)
+    args = {"train_pdrop_args": {"first_vision_token_positions": [3], "num_vision_tokens": [24],
+                                 "text_prompt_lens": [19]}} if extra else {}
+    with cpu_kernels(), torch.no_grad():
+        out = model(input_ids=torch.from_numpy(g["ids"]).long(), use_cache=False, **args)
+    np.testing.assert_allclose(out.logits.numpy(), g["logits"], rtol=1e-4, atol=8e-5)
+
+
+def test_llm_factory_families():
+    """llm_registry.py:64-97: both families resolve by id; a config of the wrong family or an
+    unknown id is an error, not a silent default."""
+    from timeviper_amd.model.llm.llm_factory import GenericLLMBackbone, get_llm_config, llm_family_of
+    from timeviper_amd.model.llm.nano import NemotronHConfig
+    from timeviper_amd.model.llm.qwen2 import Qwen2Config, Qwen2ForCausalLM
+    assert llm_family_of("nanov2-9b") == "nano" and llm_family_of("qwen2.5-7b-instruct") == "qwen2"
+    c = get_llm_config("qwen2.5-7b-instruct")
+    assert (c.hidden_size, c.num_hidden_layers, c.num_key_value_heads, c.head_dim) == (3584, 28, 4, 128)
+    with pytest.raises(ValueError):
+        llm_family_of("llama-9000")
+    with pytest.raises(ValueError):
+        get_llm_config("qwen2.5-3b-instruct")
+    small = Qwen2Config(vocab_size=64, hidden_size=32, intermediate_size=48, num_hidden_layers=2,
+                        num_attention_heads=2, num_key_value_heads=1)
+    bb = GenericLLMBackbone("qwen2.5-3b-instruct", config=small, use_pdrop=True, pdrop_type="uni_1_0.5")
+    assert bb.llm_family == "qwen2" and isinstance(bb.llm, Qwen2ForCausalLM) and bb.embed_dim == 32
+    assert bb.llm.backbone.pdrop_layers == [1]
+    assert bb.llm.new_cache().get_seq_length() == 0
+    with pytest.raises(TypeError):
+        GenericLLMBackbone("nanov2-9b", config=small)
+    with pytest.raises(TypeError):
+        GenericLLMBackbone("qwen2-7b", config=NemotronHConfig(vocab_size=64, hidden_size=32, num_hidden_layers=2,
+                                                              hybrid_override_pattern="M*"))

@@ -541,3 +541,33 @@ def test_tome_round_vs_torch_restatement(K, dtype, F_, T, C, heads):
         assert xo.shape == x_ref.shape and so.shape == s_ref.shape
         assert torch.equal(so.float().cpu(), s_ref.float()), "merged sizes differ (different matching)"
         close(xo, x_ref.float(), *TOL[dtype], f"r={r}")
+
+
+# ---------------------------------------------------------------- Qwen2 operators
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_rope_and_silu_mul(K, dtype):
+    g = torch.Generator().manual_seed(17)
+    B, L, Hq, Hkv, D = 1, 77, 6, 2, 128
+    qkv = torch.randn(B, L, (Hq + 2 * Hkv) * D, generator=g).to(dtype)        # q, k are column slices
+    pos = torch.arange(5, 5 + L)[None]
+    inv = 1.0 / (10000.0 ** (torch.arange(0, D, 2).float() / D))
+    emb = torch.cat([pos[:, :, None].float() * inv] * 2, dim=-1)
+    cos, sin = emb.cos().to(dtype), emb.sin().to(dtype)
+
+    def rot(x):
+        return torch.cat((-x[..., D // 2:], x[..., :D // 2]), dim=-1)
+    q = qkv[..., :Hq * D].view(B, L, Hq, D)
+    k = qkv[..., Hq * D:(Hq + Hkv) * D].view(B, L, Hkv, D)
+    q_ref = q.float() * cos.float()[:, :, None] + rot(q.float()) * sin.float()[:, :, None]
+    k_ref = k.float() * cos.float()[:, :, None] + rot(k.float()) * sin.float()[:, :, None]
+    d = qkv.to(DEV)
+    qd = d[..., :Hq * D].view(B, L, Hq, D)
+    kd = d[..., Hq * D:(Hq + Hkv) * D].view(B, L, Hkv, D)
+    K.apply_rotary_pos_emb_(qd, kd, cos.to(DEV), sin.to(DEV))
+    close(qd, q_ref, *TOL[dtype], "rope q")
+    close(kd, k_ref, *TOL[dtype], "rope k")
+    assert torch.equal(d[..., (Hq + Hkv) * D:].cpu(), qkv[..., (Hq + Hkv) * D:]), "v must be untouched"
+    gu = torch.randn(33, 2 * 18944 // 8, generator=g).to(dtype)
+    gate, up = gu[:, :gu.shape[1] // 2], gu[:, gu.shape[1] // 2:]
+    y = K.silu_mul(gate.to(DEV), up.to(DEV))
+    close(y, torch.nn.functional.silu(gate.float()) * up.float(), *TOL[dtype], "silu_mul")

@@ -189,3 +189,22 @@ def test_internvideo2_tower_matches_reference(case, is_video):
     out = ov.internvideo2_tower_ref(golden_state_dict(g), T(g[case]), int(g["num_heads"]),
                                     is_video=is_video)
     close(out, g[case + "_out"], 1e-4, 2e-5)
+
+
+QWEN_TOY = dict(num_hidden_layers=6, num_attention_heads=4, num_key_value_heads=2, head_dim=16,
+                rope_theta=10000.0, rms_norm_eps=1e-6)
+QWEN_PD = "uni_1_0.75-uni_3_0.5-uni_4_0.25"
+QWEN_ARGS = {"first_vision_token_positions": [3], "num_vision_tokens": [24], "text_prompt_lens": [19]}
+
+
+@pytest.mark.parametrize("tag,extra", [("plain", {}), ("pdrop_nomerge", dict(pdrop_type=QWEN_PD)),
+                                       ("pdrop_transv", dict(pdrop_type=QWEN_PD, merge_module="CrossAttention"))])
+def test_qwen2_matches_reference(tag, extra):
+    """G12: Qwen2ForCausalLM of the reference (eager, fp32): rotary attention, SwiGLU, uniform pdrop
+    stages with re-started positions, TransV merge with biased q/k/v."""
+    from oracle import qwen2 as oq
+    g = load_golden(f"qwen2_{tag}")
+    cfg = {**QWEN_TOY, **extra}
+    logits = oq.causal_lm_ref(golden_state_dict(g), cfg, input_ids=T(g["ids"]).long(),
+                              pdrop_args=QWEN_ARGS if extra else None)
+    close(logits, g["logits"], 1e-4, 6e-5)

@@ -39,6 +39,8 @@ SIGNATURES = {
     "tv_gather_rows": (_i, [_p, _p, _p, _l, _i, _l, _l, _i, _p]),
     "tv_uniform_keep_indices": (_i, [_p, _l, _l, _l, _p]),
     "tv_dropped_indices": (_i, [_p, _l, _l, _l, _p, _p]),
+    "tv_rope_fwd": (_i, [_p, _p, _p, _l, _i, _i, _l, _l, _i, _p]),
+    "tv_silu_mul_fwd": (_i, [_p, _p, _p, _l, _i, _l, _l, _l, _i, _p]),
     "tv_tome_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i]),
     "tv_tome_merge_round": (_i, [_p] * 4 + [_i] * 6 + [_p, C.c_size_t, _p]),
     "tv_patch_embed_fwd": (_i, [_p] * 5 + [_i] * 7 + [_p]),

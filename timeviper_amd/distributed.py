@@ -72,6 +72,9 @@ class SequenceParallelTimeViper:
     def __init__(self, vlm, rank: int, world: int, group=None):
         self.vlm, self.rank, self.world, self.group = vlm, rank, world, group
         self.llm = vlm.llm_backbone.llm
+        if vlm.llm_backbone.llm_family != "nano":
+            raise NotImplementedError("sequence parallelism is built for the hybrid Mamba-2 backbone only "
+                                      f"(got family `{vlm.llm_backbone.llm_family}`)")
         self.bb = self.llm.backbone
         self.cfg = self.llm.config
 

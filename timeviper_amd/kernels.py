@@ -432,6 +432,30 @@ def attn_rank_scores(q_row: torch.Tensor, k: torch.Tensor, n_keys: int, vis_star
 
 
 # ---------------------------------------------------------------- patch embed
+def apply_rotary_pos_emb_(q, k, cos, sin):
+    """In-place rotary embedding of q (B, L, Hq, D) and k (B, L, Hkv, D) (views with a
+    contiguous head dim) with cos / sin (B, L, D): modeling_qwen2.py:89-113."""
+    _gpu(q, k, cos, sin)
+    B, L, _, D = q.shape
+    cs = cos.to(q.dtype).reshape(B * L, D).contiguous()
+    sn = sin.to(q.dtype).reshape(B * L, D).contiguous()
+    for t in (q, k):
+        assert t.stride(-1) == 1 and (B == 1 or t.stride(0) == L * t.stride(1))
+        check(_capi.lib().tv_rope_fwd(_p(t), _p(cs), _p(sn), B * L, t.shape[2], D, t.stride(1),
+                                      t.stride(2), _dt(t), _stream()), "tv_rope_fwd")
+    return q, k
+
+
+def silu_mul(gate, up):
+    """silu(gate) * up over the last dim (Qwen2MLP, modeling_qwen2.py:78-80)."""
+    _gpu(gate, up)
+    g2, u2 = _rows2d(gate), _rows2d(up)
+    y = torch.empty(g2.shape, dtype=gate.dtype, device=gate.device)
+    check(_capi.lib().tv_silu_mul_fwd(_p(g2), _p(u2), _p(y), g2.shape[0], g2.shape[1], g2.stride(0),
+                                      u2.stride(0), y.stride(0), _dt(gate), _stream()), "tv_silu_mul_fwd")
+    return y.view(gate.shape)
+
+
 def tome_merge_round(x, size, r: int, heads: int = 16):
     """One ToMe round for every frame (tome.py:14-83): x (F, T, C), size (F, T, 1) or None ->
     (x' (F, T-r, C), size' (F, T-r, 1)); rows = [kept even tokens, descending match score |

@@ -40,12 +40,12 @@ def get_vlm(model_id: str, vision_backbone: VisionBackbone, llm_backbone: Generi
                               arch_specifier=arch_specifier, visual_token_order=visual_token_order, **kw)
 
 
-def build_synthetic_timeviper(llm_config: Optional[NemotronHConfig] = None,
+def build_synthetic_timeviper(llm_config=None,
                               vision_backbone_id: str = "siglip-vit-so400m-384px",
                               pdrop_type: Optional[str] = None, merge_module: str = "no_merge",
                               device="cuda", dtype=torch.bfloat16, seed: int = 0,
                               vit_depth: Optional[int] = None, image_size: Optional[int] = None,
-                              vision_config=None):
+                              vision_config=None, llm_backbone_id: str = "nanov2-9b"):
     """Random-init TimeViper (there are no checkpoints offline): weights N(0, 0.02),
     A_log = log U[1,16], dt_bias = softplus^-1(U[1e-3,1e-1]), D = 1."""
     torch.manual_seed(seed)
@@ -55,7 +55,7 @@ def build_synthetic_timeviper(llm_config: Optional[NemotronHConfig] = None,
                                          vision_config=vision_config)
         else:
             vb = TimmViTBackbone(vision_backbone_id, depth_override=vit_depth, default_image_size=image_size)
-        llm = GenericLLMBackbone("nanov2-9b", config=llm_config, merge_module=merge_module,
+        llm = GenericLLMBackbone(llm_backbone_id, config=llm_config, merge_module=merge_module,
                                  use_pdrop=pdrop_type is not None, pdrop_type=pdrop_type)
         vlm = HybridTimeViperVLM("timeviper-synthetic", vb, llm, arch_specifier="tome_mlp-16")
     vlm = vlm.to_empty(device=device)

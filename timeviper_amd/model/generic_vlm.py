@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 
 from .llm import GenericLLMBackbone
-from .llm.nano import CausalLMOutputWithPast, HybridMambaAttentionDynamicCache
+from .llm.nano import CausalLMOutputWithPast
 from .projector import MLPProjector, MultiMLPProjector, MultiToMe16_mlp_hd64, ToMe16_mlp_hd64
 from .vit import VisionBackbone
 
@@ -239,7 +239,7 @@ class GenericTimeViperVLM(nn.Module):
         if do_sample:
             raise NotImplementedError("only greedy decoding is on the evaluation path")
         llm = self.llm_backbone.llm
-        cache = HybridMambaAttentionDynamicCache(llm.config, 1, dtype=self.dtype, device=self.device)
+        cache = llm.new_cache(1, dtype=self.dtype, device=self.device)
         out = self.forward(input_ids=input_ids, pixel_values=pixel_values,
                            pixel_values_videos=pixel_values_videos, past_key_values=cache,
                            use_cache=True, cache_position=torch.zeros(1, dtype=torch.long))

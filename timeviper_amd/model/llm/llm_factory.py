@@ -11,19 +11,40 @@ import torch
 import torch.nn as nn
 
 from .nano import NemotronHConfig, NemotronHForCausalLM
+from .qwen2 import Qwen2Config, Qwen2ForCausalLM
 
 MODEL_REGISTRY = {
     # llm_registry.py:64-97 — ids the reference accepts for the nano family
     "nanov2-9b": "nvidia/NVIDIA-Nemotron-Nano-9B-v2",
     "nanov2-9b-base": "nvidia/NVIDIA-Nemotron-Nano-9B-v2-Base",
 }
+QWEN2_REGISTRY = {
+    # llm_registry.py:65-77.  Only the 7B geometries have a config preset here (public
+    # config.json values); the other ids need an explicit `config=`.
+    "qwen2-7b": "Qwen/Qwen2-7B", "qwen2-7b-instruct": "Qwen/Qwen2-7B-Instruct",
+    "qwen2-1.5b": "Qwen/Qwen2-1.5B", "qwen2-1.5b-instruct": "Qwen/Qwen2-1.5B-Instruct",
+    "qwen2.5-7b-instruct": "Qwen/Qwen2.5-7B-Instruct", "qwen2.5-7b-base": "Qwen/Qwen2.5-7B-Base",
+    "qwen2.5-3b-instruct": "Qwen/Qwen2.5-3B-Instruct", "qwen2.5-3b-base": "Qwen/Qwen2.5-3B-Base",
+}
+_QWEN2_7B = ("qwen2-7b", "qwen2-7b-instruct", "qwen2.5-7b-instruct", "qwen2.5-7b-base")
 DEFAULT_TOKEN = "<image>"
 
 
-def get_llm_config(llm_backbone_id: str, **over) -> NemotronHConfig:
+def llm_family_of(llm_backbone_id: str) -> str:
     if llm_backbone_id in MODEL_REGISTRY:
-        return NemotronHConfig.nemotron_nano_9b_v2(**over)
+        return "nano"
+    if llm_backbone_id in QWEN2_REGISTRY:
+        return "qwen2"
     raise ValueError(f"LLM backbone `{llm_backbone_id}` is not supported!")
+
+
+def get_llm_config(llm_backbone_id: str, **over):
+    family = llm_family_of(llm_backbone_id)
+    if family == "nano":
+        return NemotronHConfig.nemotron_nano_9b_v2(**over)
+    if llm_backbone_id in _QWEN2_7B:
+        return Qwen2Config.qwen2_5_7b(**over)
+    raise ValueError(f"no built-in geometry for `{llm_backbone_id}`; pass config=Qwen2Config(...)")
 
 
 class SyntheticTokenizer:
@@ -43,13 +64,13 @@ class SyntheticTokenizer:
 
 
 class GenericLLMBackbone(nn.Module):
-    def __init__(self, llm_backbone_id: str, config: Optional[NemotronHConfig] = None,
+    def __init__(self, llm_backbone_id: str, config=None,
                  tokenizer=None, llm_max_length: Optional[int] = None, inference_mode: bool = True,
                  attn_implementation: str = "flash_attention_2", merge_module: str = "no_merge",
                  use_pdrop: bool = False, pdrop_type: Optional[str] = None) -> None:
         super().__init__()
         self.identifier = llm_backbone_id
-        self.llm_family = "nano"
+        self.llm_family = llm_family_of(llm_backbone_id)
         self.llm_max_length = llm_max_length
         self.inference_mode = inference_mode
         if config is None:
@@ -58,7 +79,10 @@ class GenericLLMBackbone(nn.Module):
         else:
             config.merge_module, config.use_pdrop, config.pdrop_type = merge_module, use_pdrop, pdrop_type
         config._attn_implementation = attn_implementation
-        self.llm = NemotronHForCausalLM(config)
+        want = NemotronHConfig if self.llm_family == "nano" else Qwen2Config
+        if not isinstance(config, want):
+            raise TypeError(f"`{llm_backbone_id}` needs a {want.__name__}, got {type(config).__name__}")
+        self.llm = NemotronHForCausalLM(config) if self.llm_family == "nano" else Qwen2ForCausalLM(config)
         self.tokenizer = tokenizer or SyntheticTokenizer(config.vocab_size)
         self.terminators = [self.tokenizer.eos_token_id]
 
