@@ -419,3 +419,35 @@ def make_qwen2_golden():
 
 if __name__ == "__main__" and os.environ.get("GOLDEN_ONLY") in (None, "qwen2"):
     make_qwen2_golden()
+
+
+@torch.no_grad()
+def make_multi_projector_golden():
+    """G13: the two-encoder projectors of the reference (projector/tome.py:180-231,
+    projector/mlp.py:37-68) on dict inputs keyed by backbone id: an image encoder (frame-wise ToMe)
+    beside a 4-frame-tube video encoder (local_num_frames=4) — the reshape + token interleave of
+    BASELINE config 4 — and the unequal-token-count case (concatenation)."""
+    import_reference()
+    tome = importlib.import_module("timeviper.model.projector.tome")
+    mlp = importlib.import_module("timeviper.model.projector.mlp")
+    torch.manual_seed(9)
+    keys = {"dinov2-vit-l": 48, "internvideo2-1b-16-224px": 64}
+    proj = tome.MultiToMe16_mlp_hd64(keys, 40, mlp_type="tome_mlp", num_compressed_tokens=16).eval()
+    T = 8
+    feats = {"dinov2-vit-l": torch.randn(T, 100, 48), "internvideo2-1b-16-224px": torch.randn(T // 4, 4 * 100, 64)}
+    y_video = proj(feats, compress=True, local_num_frames={"dinov2-vit-l": 1, "internvideo2-1b-16-224px": 4})
+    imgs = {"dinov2-vit-l": torch.randn(3, 100, 48), "internvideo2-1b-16-224px": torch.randn(3, 100, 64)}
+    y_image = proj(imgs, compress=True, local_num_frames={"dinov2-vit-l": 1, "internvideo2-1b-16-224px": 1})
+    mproj = mlp.MultiMLPProjector({"a": 48, "b": 64}, 40).eval()
+    same = {"a": torch.randn(2, 9, 48), "b": torch.randn(2, 9, 64)}
+    diff = {"a": torch.randn(2, 9, 48), "b": torch.randn(2, 5, 64)}
+    npz("multi_projector", v_dino=feats["dinov2-vit-l"], v_iv2=feats["internvideo2-1b-16-224px"], y_video=y_video,
+        i_dino=imgs["dinov2-vit-l"], i_iv2=imgs["internvideo2-1b-16-224px"], y_image=y_image,
+        m_same_a=same["a"], m_same_b=same["b"], m_same_y=mproj(same),
+        m_diff_a=diff["a"], m_diff_b=diff["b"], m_diff_y=mproj(diff),
+        **{"w." + k: v for k, v in proj.state_dict().items()},
+        **{"mw." + k: v for k, v in mproj.state_dict().items()})
+
+
+if __name__ == "__main__" and os.environ.get("GOLDEN_ONLY") in (None, "multi_projector"):
+    make_multi_projector_golden()

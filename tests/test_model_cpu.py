@@ -153,3 +153,51 @@ def test_llm_factory_families():
     with pytest.raises(TypeError):
         GenericLLMBackbone("qwen2-7b", config=NemotronHConfig(vocab_size=64, hidden_size=32, num_hidden_layers=2,
                                                               hybrid_override_pattern="M*"))
+
+
+def test_multi_projectors_match_reference():
+    """Two-encoder projectors on dict inputs (projector/tome.py:180-231, mlp.py:37-68): frame-wise
+    ToMe beside 4-frame-tube ToMe with the reshape + token interleave, and the concatenation case."""
+    from timeviper_amd.model.projector import MultiMLPProjector, MultiToMe16_mlp_hd64
+    g = load_golden("multi_projector")
+    t = lambda k: torch.from_numpy(g[k])
+    keys = {"dinov2-vit-l": 48, "internvideo2-1b-16-224px": 64}
+    proj = MultiToMe16_mlp_hd64(keys, 40, mlp_type="tome_mlp", num_compressed_tokens=16).eval()
+    proj.load_state_dict(golden_state_dict(g), strict=True)
+    with torch.no_grad():
+        yv = proj({"dinov2-vit-l": t("v_dino"), "internvideo2-1b-16-224px": t("v_iv2")}, compress=True,
+                  local_num_frames={"dinov2-vit-l": 1, "internvideo2-1b-16-224px": 4})
+        yi = proj({"dinov2-vit-l": t("i_dino"), "internvideo2-1b-16-224px": t("i_iv2")}, compress=True,
+                  local_num_frames={"dinov2-vit-l": 1, "internvideo2-1b-16-224px": 1})
+    assert yv.shape == g["y_video"].shape == (8, 32, 40)
+    assert torch.allclose(yv, t("y_video"), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(yi, t("y_image"), rtol=1e-5, atol=1e-6)
+    mp = MultiMLPProjector({"a": 48, "b": 64}, 40).eval()
+    mp.load_state_dict(golden_state_dict(g, prefix="mw."), strict=True)
+    with torch.no_grad():
+        assert torch.allclose(mp({"a": t("m_same_a"), "b": t("m_same_b")}), t("m_same_y"), rtol=1e-5, atol=1e-6)
+        assert torch.allclose(mp({"a": t("m_diff_a"), "b": t("m_diff_b")}), t("m_diff_y"), rtol=1e-5, atol=1e-6)
+
+
+def test_multivit_registry_and_contract():
+    """registry.py:74-99 ('+' ids, named variant) and the attributes generic_vlm.py:180-186,:415
+    read from a multi-encoder backbone."""
+    from timeviper_amd.model.vit import MultiViTBackbone, get_vision_backbone_config
+    from timeviper_amd.model.vit.internvideo2 import InternVideo2VisionConfig
+    c = get_vision_backbone_config("dinov2-vit-l+internvideo2-1b-16-224px")
+    assert c["type"] == "multi" and c["default_image_size"] == 224
+    assert c["backbones"] == ["dinov2-vit-l", "internvideo2-1b-16-224px"]
+    c = get_vision_backbone_config("dinosiglip-vit-so-384px")
+    assert c["backbones"] == ["dinov2-vit-l", "siglip-vit-so400m-384px"] and c["default_image_size"] == 384
+    with pytest.raises(ValueError):
+        get_vision_backbone_config("dinov2-vit-l+nope")
+    vcfg = InternVideo2VisionConfig(num_frames=4, hidden_size=64, num_hidden_layers=3,
+                                    num_attention_heads=2, image_size=28, patch_size=14)
+    with torch.device("meta"):
+        vb = MultiViTBackbone("dinov2-vit-l+internvideo2-1b-16-224px", member_kwargs={
+            "dinov2-vit-l": dict(depth_override=2, default_image_size=28),
+            "internvideo2-1b-16-224px": dict(default_image_size=28, vision_config=vcfg)})
+    assert vb.get_identifier == "multivit"
+    assert vb.backbone_ids == ["dinov2-vit-l", "internvideo2-1b-16-224px"]
+    assert list(vb.backbones.keys()) == ["dinov2_vit_l", "internvideo2_1b_16_224px"]
+    assert vb.backbones["dinov2_vit_l"].embed_dim == 1024 and vb.backbones["internvideo2_1b_16_224px"].embed_dim == 64

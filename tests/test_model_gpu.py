@@ -326,6 +326,49 @@ def test_vlm_with_qwen2_backbone_vs_oracle_and_generate():
     assert int(gen[0, 0]) == int(out.logits[0, -1].argmax())
 
 
+def test_vlm_dual_encoder_qwen2_matches_parts():
+    """BASELINE config 4's wiring at toy size: DINOv2-L (frame-wise) + InternVideo2 (4-frame tubes)
+    -> MultiToMe (16 + 16 tokens per frame, interleaved token-wise) -> fusion -> Qwen2 with pdrop +
+    TransV.  The end-to-end forward must equal the same members run one by one, the interleave must
+    be the reference's rule (projector/tome.py:214-231) and the LM stage must match the oracle."""
+    from oracle import qwen2 as oq
+    from timeviper_amd.model import build_synthetic_timeviper
+    from timeviper_amd.model.llm.qwen2 import Qwen2Config
+    from timeviper_amd.model.vit.internvideo2 import InternVideo2VisionConfig
+    pd = "uni_1_0.75-uni_3_0.5"
+    cfg = Qwen2Config(vocab_size=128, hidden_size=128, intermediate_size=256, num_hidden_layers=5,
+                      num_attention_heads=2, num_key_value_heads=1, rope_theta=10000.0)
+    vcfg = InternVideo2VisionConfig(num_frames=4, hidden_size=128, num_hidden_layers=4,
+                                    num_attention_heads=4, image_size=112, patch_size=14)
+    bid = "dinov2-vit-l+internvideo2-1b-16-224px"
+    vlm = build_synthetic_timeviper(cfg, bid, pdrop_type=pd, merge_module="CrossAttention", image_size=112,
+                                    llm_backbone_id="qwen2.5-7b-instruct", member_kwargs={
+                                        "dinov2-vit-l": dict(depth_override=3, default_image_size=112),
+                                        "internvideo2-1b-16-224px": dict(default_image_size=112, vision_config=vcfg)})
+    T = 8
+    tok = vlm.default_token_id
+    ids = torch.tensor([[5, 6] + [tok] * T + [8, 9, 10]], device=DEV)
+    pix = torch.randn(T, 3, 112, 112, device=DEV).bfloat16()
+    with torch.no_grad():
+        out = vlm(input_ids=ids, pixel_values_videos=pix).logits
+        feats = vlm.vision_backbone(pix, is_video=True)
+        assert feats["dinov2-vit-l"].shape == (T, 64, 1024)
+        assert feats["internvideo2-1b-16-224px"].shape == (T // 4, 4 * 64, 128)
+        vis = vlm.projector_forward(feats, is_video=True)
+        assert vis.shape == (T, 32, 128)
+        pj = vlm.projector.projectors
+        a = pj["dinov2-vit-l"](feats["dinov2-vit-l"], compress=True, local_num_frames=1)
+        b = pj["internvideo2-1b-16-224px"](feats["internvideo2-1b-16-224px"], compress=True, local_num_frames=4)
+        assert torch.equal(vis[:, 0::2], a) and torch.equal(vis[:, 1::2], b.reshape(T, 16, 128))
+    sd = {k: v.float().cpu() for k, v in vlm.llm_backbone.llm.state_dict().items()}
+    fused = om.fuse_embeddings_ref(ids.cpu(), vis.float().cpu(), sd["model.embed_tokens.weight"], tok)
+    pa = om.pdrop_bookkeeping_ref(ids.cpu(), T, 32, tok)
+    ocfg = dict(num_hidden_layers=5, num_attention_heads=2, num_key_value_heads=1, head_dim=64,
+                rope_theta=10000.0, rms_norm_eps=cfg.rms_norm_eps, pdrop_type=pd, merge_module="CrossAttention")
+    ref = oq.causal_lm_ref(sd, ocfg, inputs_embeds=fused, pdrop_args=pa)
+    assert relerr(out[:, -1], ref[:, -1]) < 3e-2
+
+
 @pytest.mark.parametrize("tag,extra", [("plain", {}), ("pdrop_nomerge", dict(use_pdrop=True)),
                                        ("pdrop_transv", dict(use_pdrop=True, merge_module="CrossAttention"))])
 def test_qwen2_bf16_vs_reference_golden(tag, extra):

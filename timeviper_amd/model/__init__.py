@@ -8,7 +8,7 @@ import torch
 
 from .generic_vlm import GenericTimeViperVLM, HybridTimeViperVLM
 from .llm import GenericLLMBackbone, NemotronHConfig
-from .vit import (InternVideo2ViTBackbone, TimmViTBackbone, VisionBackbone,
+from .vit import (InternVideo2ViTBackbone, MultiViTBackbone, TimmViTBackbone, VisionBackbone,
                   get_vision_backbone_config)
 
 
@@ -17,6 +17,8 @@ def get_vision_backbone_and_transform(vision_backbone_id: str, image_resize_stra
     cfg = get_vision_backbone_config(vision_backbone_id)
     if cfg["type"] == "internvideo2":
         vb = InternVideo2ViTBackbone(vision_backbone_id, image_resize_strategy, **kw)
+    elif cfg["type"] == "multi":
+        vb = MultiViTBackbone(vision_backbone_id, image_resize_strategy, **kw)
     else:
         vb = TimmViTBackbone(vision_backbone_id, image_resize_strategy, **kw)
     return vb, vb.get_image_transform()
@@ -45,12 +47,16 @@ def build_synthetic_timeviper(llm_config=None,
                               pdrop_type: Optional[str] = None, merge_module: str = "no_merge",
                               device="cuda", dtype=torch.bfloat16, seed: int = 0,
                               vit_depth: Optional[int] = None, image_size: Optional[int] = None,
-                              vision_config=None, llm_backbone_id: str = "nanov2-9b"):
+                              vision_config=None, llm_backbone_id: str = "nanov2-9b",
+                              member_kwargs=None):
     """Random-init TimeViper (there are no checkpoints offline): weights N(0, 0.02),
     A_log = log U[1,16], dt_bias = softplus^-1(U[1e-3,1e-1]), D = 1."""
     torch.manual_seed(seed)
     with torch.device("meta"):
-        if get_vision_backbone_config(vision_backbone_id)["type"] == "internvideo2":
+        vtype = get_vision_backbone_config(vision_backbone_id)["type"]
+        if vtype == "multi":
+            vb = MultiViTBackbone(vision_backbone_id, default_image_size=image_size, member_kwargs=member_kwargs)
+        elif vtype == "internvideo2":
             vb = InternVideo2ViTBackbone(vision_backbone_id, default_image_size=image_size or 224,
                                          vision_config=vision_config)
         else:

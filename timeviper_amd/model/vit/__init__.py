@@ -24,7 +24,21 @@ INTERNVIDEO2_REGISTRY = {      # registry.py:64-73
 }
 
 
+MULTI_REGISTRY = {              # registry.py:74-82
+    "dinosiglip-vit-so-384px": {"backbones": ["dinov2-vit-l", "siglip-vit-so400m-384px"],
+                                "default_image_size": 384},
+}
+
+
 def get_vision_backbone_config(vision_backbone_id: str) -> Dict[str, Any]:
+    if "+" in vision_backbone_id:          # registry.py:87-99
+        members = vision_backbone_id.split("+")
+        size = max(get_vision_backbone_config(b).get("default_image_size", 224) for b in members)
+        return {"type": "multi", "vision_family": "multi", "identifier": vision_backbone_id,
+                "backbones": members, "default_image_size": size}
+    if vision_backbone_id in MULTI_REGISTRY:
+        return {"type": "multi", "vision_family": "multi", "identifier": "multi",
+                **MULTI_REGISTRY[vision_backbone_id]}
     if vision_backbone_id in VISION_MODEL_REGISTRY:
         fam, timm_id, size = VISION_MODEL_REGISTRY[vision_backbone_id]
         return {"type": "timm", "timm_id": timm_id, "default_image_size": size,
@@ -100,3 +114,4 @@ TimmCheckpointBackbone = TimmViTBackbone
 
 from .internvideo2 import (InternVideo2ViTBackbone, InternVideo2VisionConfig,  # noqa: E402
                            InternVideo2VisionTower)
+from .multivit import MultiViTBackbone  # noqa: E402
