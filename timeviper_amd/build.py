@@ -28,6 +28,9 @@ if os.environ.get("TV_SLICE_STAMP"):    # dev only: per-wave barrier-wait stamps
     FLAGS.append("-DTV_SLICE_STAMP")
 
 
+FLAGS += os.environ.get("TV_EXTRA_HIPCC_FLAGS", "").split()   # dev only
+
+
 def _sources():
     return sorted(list(CSRC.glob("*.hip")) + list(CSRC.glob("*.cpp")))
 
