@@ -136,3 +136,33 @@ def test_gated_norm_and_rmsnorm_full_length_rows(K):
     y2 = K.rmsnorm_fn(x[:4096][perm].contiguous(), w, None, z[:4096][perm].contiguous(), 1e-5, H * P // G,
                       norm_before_gate=False)
     assert torch.equal(y2, y[:4096][perm])
+
+
+def test_vit_fused_clips_equal_reference_clips(K):
+    """SigLIP-so400m widths at 384 px, 2 048 frames in ONE call (what `encode_vision` does for
+    frame-independent towers) against the reference's 256-frame clips (generic_vlm.py:274-281):
+    same rows for every frame — launches past 2^31 elements (fc1 output: 6.4e9) index correctly."""
+    from timeviper_amd.model import build_synthetic_timeviper
+    from timeviper_amd.model.llm.nano import NemotronHConfig
+    cfg = NemotronHConfig(vocab_size=128, hidden_size=64, intermediate_size=96, num_hidden_layers=2,
+                          hybrid_override_pattern="M-", num_attention_heads=4, head_dim=16,
+                          num_key_value_heads=2, ssm_state_size=16, mamba_num_heads=8,
+                          mamba_n_groups=2, mamba_head_dim=8, mamba_chunk_size=16)
+    vlm = build_synthetic_timeviper(cfg, "siglip-vit-so400m-384px", vit_depth=3)   # 2 blocks run
+    assert vlm.vit_clip_frames == 256 and vlm.vit_clip_fuse == 8
+    T = 2048 + 40
+    pix = torch.randn(T, 3, 384, 384, device=DEV, dtype=torch.bfloat16)
+    with torch.no_grad():
+        feats = vlm.vision_backbone(pix[:2048], is_video=True)           # one 2 048-frame launch
+        vis = vlm.projector_forward(feats, is_video=True)
+        assert vlm.encode_vision(pix, True).shape == (T, 16, 64)
+        for lo in (0, 1024, 1792):
+            ref = vlm.vision_backbone(pix[lo:lo + 256], is_video=True)   # the reference's clip
+            got = feats[lo:lo + 256]
+            err = (got.float() - ref.float()).norm() / ref.float().norm()
+            assert err < 5e-3, (lo, float(err))          # stream-K GEMMs are not bit-reproducible
+            # ToMe + MLP on the SAME features: frames are independent, so the clip size cannot matter
+            # beyond the GEMM's rounding (matching and merge are exact per frame)
+            pv = vlm.projector_forward(got, is_video=True)
+            errp = (vis[lo:lo + 256].float() - pv.float()).norm() / pv.float().norm()
+            assert errp < 5e-3, (lo, float(errp))

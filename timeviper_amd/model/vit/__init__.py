@@ -85,6 +85,8 @@ class TimmViTBackbone(VisionBackbone):
         self.featurizer.eval()
         self.dtype = torch.bfloat16
 
+    frame_independent = True     # every frame is encoded on its own: any clip size gives the same rows
+
     def forward(self, pixel_values: torch.Tensor, **kwargs) -> torch.Tensor:
         return self.featurizer(pixel_values)
 
