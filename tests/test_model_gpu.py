@@ -438,3 +438,34 @@ def test_qwen2_prefill_plus_decode_matches_full_prefill():
         o1 = model(input_ids=ids[:, 68:69], past_key_values=cache, use_cache=True).logits
         o2 = model(input_ids=ids[:, 69:70], past_key_values=cache, use_cache=True).logits
     assert relerr(o1[:, -1], full[:, 68]) < 3e-2 and relerr(o2[:, -1], full[:, 69]) < 3e-2
+
+
+def test_vit_zero_padded_gemms_match_plain_linears():
+    """so400m widths (qkv N = 3456, MLP hidden 4304 — not multiples of the 256-wide GEMM tile): the
+    inference path runs zero-padded weight copies; it must equal the plain nn.Linear path, follow
+    in-place weight updates, and leave the checkpoint shapes alone."""
+    from timeviper_amd.model.vit.siglip import Block
+    torch.manual_seed(2)
+    blk = Block(1152, 16, 4304).to(DEV).bfloat16().eval()
+    with torch.no_grad():
+        for p in blk.parameters():
+            if p.dim() > 1:
+                p.normal_(0, 0.03)
+        for lin in (blk.attn.qkv, blk.attn.proj, blk.mlp.fc1, blk.mlp.fc2):
+            lin.bias.normal_(0, 0.05)
+    x = torch.randn(4, 729, 1152, device=DEV).bfloat16()
+    with torch.enable_grad():                     # grad mode keeps the plain Linear path
+        ref = blk(x).detach()
+    with torch.no_grad():
+        out = blk(x)
+        assert blk.mlp._padded._val[0].shape == (4352, 1152) and blk.attn._padded._val[0].shape == (3584, 1152)
+        assert relerr(out, ref) < 4e-3
+        blk.mlp.fc1.weight.mul_(0.5)              # in-place update must invalidate the padded copy
+        blk.attn.qkv.bias.add_(0.01)
+        out2 = blk(x)
+    with torch.enable_grad():
+        ref2 = blk(x).detach()
+    assert relerr(out2, ref2) < 4e-3 and relerr(out2, ref) > 1e-2
+    assert blk.mlp.fc1.weight.shape == (4304, 1152) and set(blk.state_dict()) == {
+        "norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias",
+        "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias"}

@@ -21,7 +21,7 @@ with torch.no_grad():
         else:
             p.fill_(1.0)
 vb = vb.bfloat16().eval()
-NF = 4096
+NF = 2048
 pix = torch.randn(NF, 3, 384, 384, device=dev, dtype=torch.bfloat16)
 for s in [int(a) for a in sys.argv[1:]] or [256, 128, 64, 32]:
     with torch.inference_mode():

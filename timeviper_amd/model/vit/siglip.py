@@ -59,6 +59,41 @@ class PatchEmbed(nn.Module):
         return K.patch_embed(x, self.proj.weight, self.proj.bias, pos)
 
 
+GEMM_ALIGN = 256     # hipBLASLt's bf16 macro-tile on gfx950
+
+
+def _aligned(n: int) -> int:
+    return -(-n // GEMM_ALIGN) * GEMM_ALIGN
+
+
+class ZeroPaddedLinears:
+    """Inference-time copies of Linear weights, zero-padded so that the GEMM's N (and the next
+    GEMM's K) is a multiple of the library's 256-wide macro-tile: so400m's 4304 and 3456 are not,
+    and hipBLASLt runs those shapes 6-9 % slower than the padded ones (devtools/bench_gemm_pad.py).
+    The padding is exact: padded outputs are bias 0 + 0, GELU(0) = 0, and padded K columns meet zero
+    weights.  Parameters keep their checkpoint shapes; the copies are rebuilt whenever a parameter
+    is replaced or written in place."""
+
+    def __init__(self):
+        self._key, self._val = None, None
+
+    @staticmethod
+    def wanted(x: torch.Tensor, n: int) -> bool:
+        return x.is_cuda and not torch.is_grad_enabled() and n >= 1024 and n % GEMM_ALIGN != 0
+
+    def get(self, params, build):
+        key = tuple((p.data_ptr(), p._version, p.dtype) for p in params)
+        if key != self._key:
+            self._key, self._val = key, build()
+        return self._val
+
+
+def _pad_rows(w: torch.Tensor, n: int) -> torch.Tensor:
+    out = w.new_zeros((n,) + tuple(w.shape[1:]))
+    out[: w.shape[0]] = w
+    return out
+
+
 class Attention(nn.Module):
     def __init__(self, dim, num_heads):
         super().__init__()
@@ -66,10 +101,17 @@ class Attention(nn.Module):
         self.scale = self.head_dim ** -0.5
         self.qkv = nn.Linear(dim, dim * 3, bias=True)
         self.proj = nn.Linear(dim, dim, bias=True)
+        self._padded = ZeroPaddedLinears()
 
     def forward(self, x):
         B, N, C = x.shape
-        qkv = self.qkv(x).view(B, N, 3, self.num_heads, self.head_dim)
+        if ZeroPaddedLinears.wanted(x, 3 * C):
+            w, b = self._padded.get((self.qkv.weight, self.qkv.bias), lambda: (
+                _pad_rows(self.qkv.weight.detach(), _aligned(3 * C)),
+                _pad_rows(self.qkv.bias.detach(), _aligned(3 * C))))
+            qkv = F.linear(x, w, b)[..., : 3 * C].unflatten(-1, (3, self.num_heads, self.head_dim))
+        else:
+            qkv = self.qkv(x).view(B, N, 3, self.num_heads, self.head_dim)
         o = K.flash_attn_func(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], softmax_scale=self.scale,
                               causal=False)
         return self.proj(o.reshape(B, N, C))
@@ -82,8 +124,17 @@ class Mlp(nn.Module):
         self.act = nn.GELU(approximate="tanh" if act == "gelu_tanh" else "none")
         self.exact_gelu = act != "gelu_tanh"
         self.fc2 = nn.Linear(hidden, dim)
+        self._padded = ZeroPaddedLinears()
 
     def forward(self, x):
+        Hd = self.fc1.out_features
+        if ZeroPaddedLinears.wanted(x, Hd):
+            w1, b1, w2 = self._padded.get((self.fc1.weight, self.fc1.bias, self.fc2.weight), lambda: (
+                _pad_rows(self.fc1.weight.detach(), _aligned(Hd)), _pad_rows(self.fc1.bias.detach(), _aligned(Hd)),
+                _pad_rows(self.fc2.weight.detach().t(), _aligned(Hd)).t().contiguous()))
+            h = F.linear(x, w1, b1)
+            h = K.gelu(h, inplace=True) if self.exact_gelu else self.act(h)
+            return F.linear(h, w2, self.fc2.bias)
         h = self.fc1(x)
         h = K.gelu(h, inplace=True) if self.exact_gelu else self.act(h)
         return self.fc2(h)
