@@ -88,3 +88,64 @@ def internvideo2_tower_ref(sd, pixel_values, num_heads, is_video=None, eps=1e-6)
         m = F.linear(h, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
         x = x + (m.float() * sd[p + "ls2.weight"].float()).to(x.dtype)
     return x[:, 1:, :]
+
+
+# ---------------------------------------------------------------------------------------------
+# ToMe (reference timeviper/model/projector/tome.py) — pinned by tests/golden/tome.npz
+def tome_bipartite_matching_ref(metric: torch.Tensor, r: int):
+    """tome.py:14-67 (the `merge` closure only; `unmerge` is never called on the path).
+    metric (B, T, C); the r even tokens most similar to an odd token are merged into it."""
+    t = metric.shape[1]
+    r = min(r, t // 2)
+    assert r > 0, r
+    unit = metric / metric.norm(dim=-1, keepdim=True)
+    even, odd = unit[..., ::2, :], unit[..., 1::2, :]
+    sim = even @ odd.transpose(-1, -2)
+    best_val, best_odd = sim.max(dim=-1)
+    order = best_val.argsort(dim=-1, descending=True)[..., None]
+    keep_idx, src_idx = order[..., r:, :], order[..., :r, :]
+    dst_idx = best_odd[..., None].gather(dim=-2, index=src_idx)
+
+    def merge(x: torch.Tensor) -> torch.Tensor:
+        ev, od = x[..., ::2, :], x[..., 1::2, :]
+        n, t1, c = ev.shape
+        kept = ev.gather(dim=-2, index=keep_idx.expand(n, t1 - r, c))
+        moved = ev.gather(dim=-2, index=src_idx.expand(n, r, c))
+        od = od.scatter_add(-2, dst_idx.expand(n, r, c), moved)
+        return torch.cat([kept, od], dim=1)
+
+    return merge
+
+
+def tome_merge_round_ref(x: torch.Tensor, size, r: int, heads: int):
+    """One round of `merge_tokens` (tome.py:137-146): metric = mean over `heads` channel chunks,
+    bipartite matching, size-weighted average (`merge_wavg`, tome.py:70-83)."""
+    b, p, c = x.shape
+    metric = x.reshape(b, p, heads, c // heads).mean(2)
+    merge = tome_bipartite_matching_ref(metric, r)
+    if size is None:
+        size = torch.ones_like(x[..., 0, None])
+    xs = merge(x * size)
+    size = merge(size)
+    return xs / size, size
+
+
+def tome_schedule_ref(p: int, target: int):
+    """tome.py:126-136: halve until the remainder fits; 729 -> 16 gives [364, 182, 91, 46, 23, 7]."""
+    rs = []
+    while p != target:
+        if p - target <= p // 2:
+            rs.append(p - target)
+            break
+        rs.append(p // 2)
+        p -= p // 2
+    return rs
+
+
+def tome_merge_tokens_ref(x: torch.Tensor, target: int, heads: int = 16):
+    """`ToMe16_mlp_hd64.merge_tokens` with token_order "raw" (tome.py:118-152)."""
+    size = None
+    for r in tome_schedule_ref(x.shape[1], target):
+        x, size = tome_merge_round_ref(x, size, min(r, x.shape[1] // 2), heads)
+    return x
+

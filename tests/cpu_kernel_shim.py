@@ -7,6 +7,7 @@ import math
 import torch
 
 from oracle import ops as R
+from oracle import vit as RV
 
 
 def _conv_xbc(xBC, weight, bias, d_inner, ngroups, dstate, activation="silu", halo=None):
@@ -116,6 +117,7 @@ def cpu_kernels():
         "patch_embed_video": _patch_video,
         "apply_rotary_pos_emb_": _rope_,
         "silu_mul": lambda g, u: torch.nn.functional.silu(g) * u,
+        "tome_merge_round": RV.tome_merge_round_ref,
     }
     saved = {k: getattr(K, k) for k in patches}
     for k, v in patches.items():

@@ -43,6 +43,8 @@ def test_product_path_has_no_cpu_fallback():
     x = torch.randn(2, 8)
     with pytest.raises(TimeViperHipError):
         kernels.rms_norm(x, torch.ones(8), 1e-5)
+    with pytest.raises(TimeViperHipError):
+        kernels.tome_merge_round(torch.randn(1, 8, 32), None, 2, 16)
     # and nothing under timeviper_amd/ imports the oracle
     for p in (ROOT / "timeviper_amd").rglob("*.py"):
         assert "oracle" not in p.read_text().replace("# oracle", ""), p

@@ -53,10 +53,14 @@ def test_tome_schedule():
 
 
 def test_tome_projector_matches_reference():
+    """module logic (schedule, clip reshape, MLP) with the round operator bound to the oracle"""
+    from cpu_kernel_shim import cpu_kernels
     g = load_golden("tome")
     proj = ToMe16_mlp_hd64(64, 48, num_compressed_tokens=16).eval()
     proj.load_state_dict(golden_state_dict(g), strict=True)
-    with torch.no_grad():
+    with pytest.raises(Exception):          # no host-side path in the product: CPU tensors raise
+        proj.merge_tokens(torch.from_numpy(g["x"]), 16, "raw")
+    with torch.no_grad(), cpu_kernels():
         merged = proj.merge_tokens(torch.from_numpy(g["x"]), 16, "raw")
         y = proj(torch.from_numpy(g["x"]), compress=True, local_num_frames=1)
         y2 = proj(torch.from_numpy(g["x2"]), compress=True, local_num_frames=4)
@@ -162,9 +166,10 @@ def test_multi_projectors_match_reference():
     g = load_golden("multi_projector")
     t = lambda k: torch.from_numpy(g[k])
     keys = {"dinov2-vit-l": 48, "internvideo2-1b-16-224px": 64}
+    from cpu_kernel_shim import cpu_kernels
     proj = MultiToMe16_mlp_hd64(keys, 40, mlp_type="tome_mlp", num_compressed_tokens=16).eval()
     proj.load_state_dict(golden_state_dict(g), strict=True)
-    with torch.no_grad():
+    with torch.no_grad(), cpu_kernels():
         yv = proj({"dinov2-vit-l": t("v_dino"), "internvideo2-1b-16-224px": t("v_iv2")}, compress=True,
                   local_num_frames={"dinov2-vit-l": 1, "internvideo2-1b-16-224px": 4})
         yi = proj({"dinov2-vit-l": t("i_dino"), "internvideo2-1b-16-224px": t("i_iv2")}, compress=True,

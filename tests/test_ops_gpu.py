@@ -526,17 +526,15 @@ def test_tome_hip_matches_reference_golden(K):
 @pytest.mark.parametrize("dtype,F_,T,C,heads", [(torch.bfloat16, 5, 729, 1152, 16), (torch.float32, 3, 257, 128, 16),
                                                 (torch.bfloat16, 2, 1024, 1408, 16), (torch.float32, 4, 7, 64, 16)])
 def test_tome_round_vs_torch_restatement(K, dtype, F_, T, C, heads):
-    """one round against the step-by-step torch restatement of tome.py:14-83 (fp64 on the CPU);
-    sizes carried from a previous round; r up to half the tokens"""
-    from timeviper_amd.model.projector.tome import bipartite_soft_matching, merge_wavg
+    """one round against the oracle's step-by-step restatement of tome.py:14-83 (fp64 on the CPU;
+    pinned by the reference golden in test_oracle_golden.py); sizes carried from a previous
+    round; r up to half the tokens"""
+    from oracle.vit import tome_merge_round_ref
     g = torch.Generator().manual_seed(T + C)
     x = torch.randn(F_, T, C, generator=g).to(dtype)
     size = torch.randint(1, 5, (F_, T, 1), generator=g).to(dtype)
     for r, sz in ((T // 2, None), (max(1, T // 5), size)):
-        xd = x.double()
-        metric = xd.reshape(F_, T, heads, C // heads).mean(2)
-        merge, _ = bipartite_soft_matching(metric, r)
-        x_ref, s_ref = merge_wavg(merge, xd, None if sz is None else sz.double())
+        x_ref, s_ref = tome_merge_round_ref(x.double(), None if sz is None else sz.double(), r, heads)
         xo, so = K.tome_merge_round(x.to(DEV), None if sz is None else sz.to(DEV), r, heads)
         assert xo.shape == x_ref.shape and so.shape == s_ref.shape
         assert torch.equal(so.float().cpu(), s_ref.float()), "merged sizes differ (different matching)"

@@ -208,3 +208,24 @@ def test_qwen2_matches_reference(tag, extra):
     logits = oq.causal_lm_ref(golden_state_dict(g), cfg, input_ids=T(g["ids"]).long(),
                               pdrop_args=QWEN_ARGS if extra else None)
     close(logits, g["logits"], 1e-4, 6e-5)
+
+
+def test_tome_oracle_matches_reference_golden():
+    """oracle/vit.py ToMe restatement against the reference's own `merge_tokens` output
+    (729 -> 16 tokens through six rounds; 4-frame clips 400 -> 64)."""
+    from oracle import vit as ov
+    g = load_golden("tome")
+    x = torch.from_numpy(g["x"])
+    assert ov.tome_schedule_ref(729, 16) == [364, 182, 91, 46, 23, 7]
+    merged = ov.tome_merge_tokens_ref(x, 16, heads=16)
+    assert torch.allclose(merged, torch.from_numpy(g["merged"]), rtol=1e-5, atol=1e-6)
+    sd = golden_state_dict(g)
+
+    def mlp(t):
+        h = torch.nn.functional.gelu(t @ sd["projector.0.weight"].t() + sd["projector.0.bias"])
+        return h @ sd["projector.2.weight"].t() + sd["projector.2.bias"]
+    assert torch.allclose(mlp(merged), torch.from_numpy(g["y"]), rtol=1e-5, atol=1e-6)
+    x2 = torch.from_numpy(g["x2"])
+    assert torch.allclose(mlp(ov.tome_merge_tokens_ref(x2, 64, heads=16)), torch.from_numpy(g["y2"]),
+                          rtol=1e-5, atol=1e-6)
+

@@ -1,5 +1,5 @@
 from .mlp import MLPProjector, MultiMLPProjector
-from .tome import MultiToMe16_mlp_hd64, ToMe16_mlp_hd64, bipartite_soft_matching, merge_wavg
+from .tome import MultiToMe16_mlp_hd64, ToMe16_mlp_hd64
 
 __all__ = ["MLPProjector", "MultiMLPProjector", "ToMe16_mlp_hd64", "MultiToMe16_mlp_hd64",
-           "bipartite_soft_matching", "merge_wavg"]
+           ]

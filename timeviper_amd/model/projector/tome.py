@@ -1,61 +1,16 @@
 """ToMe token merging 729 -> 16 tokens/frame + MLP (reference
-timeviper/model/projector/tome.py:14-231).  On the GPU every round is one call of the HIP
-operator `kernels.tome_merge_round` (metric, bipartite matching, sort, size-weighted merge:
-csrc/tome.hip); the torch functions below restate the reference step by step and are what
-the CPU tests check against the reference golden vectors."""
-from typing import Callable, Dict, Tuple, Union
+timeviper/model/projector/tome.py:14-231).  Every round is one call of the HIP operator
+`kernels.tome_merge_round` (`bipartite_soft_matching` :14-67 + `merge_wavg` :70-83 in four
+kernels: metric, matching, sort, size-weighted merge — csrc/tome.hip).  There is no host-side
+path: CPU tensors raise, like every other operator (the step-by-step restatement that the
+tests pin against the reference golden vectors is test infrastructure, not part of this package)."""
+from typing import Dict, Union
 
 import torch
 import torch.nn as nn
 
 from ... import kernels as K
 from .mlp import _interleave
-
-
-def bipartite_soft_matching(metric: torch.Tensor, r: int) -> Tuple[Callable, Callable]:
-    """Balanced (even/odd) bipartite matching; returns merge(x, mode) (tome.py:14-67).
-    metric (B, T, C); r tokens of the even set are merged into their best odd match."""
-    t = metric.shape[1]
-    r = min(r, t // 2)
-    assert r > 0, r
-    with torch.no_grad():
-        unit = metric / metric.norm(dim=-1, keepdim=True)
-        even, odd = unit[..., ::2, :], unit[..., 1::2, :]
-        sim = even @ odd.transpose(-1, -2)
-        best_val, best_odd = sim.max(dim=-1)
-        order = best_val.argsort(dim=-1, descending=True)[..., None]
-        keep_idx, src_idx = order[..., r:, :], order[..., :r, :]
-        dst_idx = best_odd[..., None].gather(dim=-2, index=src_idx)
-
-    def merge(x: torch.Tensor, mode="mean") -> torch.Tensor:
-        ev, od = x[..., ::2, :], x[..., 1::2, :]
-        n, t1, c = ev.shape
-        kept = ev.gather(dim=-2, index=keep_idx.expand(n, t1 - r, c))
-        moved = ev.gather(dim=-2, index=src_idx.expand(n, r, c))
-        od = od.scatter_add(-2, dst_idx.expand(n, r, c), moved)
-        return torch.cat([kept, od], dim=1)
-
-    def unmerge(x: torch.Tensor) -> torch.Tensor:
-        nk = keep_idx.shape[1]
-        kept, od = x[..., :nk, :], x[..., nk:, :]
-        n, _, c = kept.shape
-        moved = od.gather(dim=-2, index=dst_idx.expand(n, r, c))
-        out = torch.zeros(n, metric.shape[1], c, device=x.device, dtype=x.dtype)
-        out[..., 1::2, :] = od
-        out.scatter_(dim=-2, index=(2 * keep_idx).expand(n, nk, c), src=kept)
-        out.scatter_(dim=-2, index=(2 * src_idx).expand(n, r, c), src=moved)
-        return out
-
-    return merge, unmerge
-
-
-def merge_wavg(merge: Callable, x: torch.Tensor, size: torch.Tensor = None):
-    """Size-weighted average merge (tome.py:70-83)."""
-    if size is None:
-        size = torch.ones_like(x[..., 0, None])
-    x = merge(x * size, mode="sum")
-    size = merge(size, mode="sum")
-    return x / size, size
 
 
 def merge_schedule(p: int, target: int):
@@ -96,12 +51,7 @@ class ToMe16_mlp_hd64(nn.Module):
         b, p, c = x.shape
         head = self.num_attention_heads
         for r in merge_schedule(p, target_num_token):
-            if x.is_cuda:       # HIP kernels: metric, matching, sort and weighted merge of a round
-                x, size = K.tome_merge_round(x, size, min(r, p // 2), head)
-            else:               # host-side restatement (CPU tests against the reference golden)
-                metric = x.reshape(b, p, head, c // head).mean(2)
-                merge, _ = bipartite_soft_matching(metric, r)
-                x, size = merge_wavg(merge, x, size)
+            x, size = K.tome_merge_round(x, size, min(r, p // 2), head)
             p = x.shape[1]
         if token_order in ("ascending", "descending"):
             idx = size.squeeze(-1).argsort(dim=1, descending=token_order == "descending")
