@@ -239,9 +239,17 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)
-        print(json.dumps(line), flush=True)
+    # RCCL writes a version banner through C stdio, which is block-buffered on a pipe and would
+    # otherwise surface at process exit, AFTER the result: every rank drains it before the last
+    # barrier, so that rank 0's JSON line is the last line of the job's stdout
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
     if sharded:
+        torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    if rank == 0:
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
