@@ -58,8 +58,12 @@ def worker(rank, world, port, merge, T, q):
         ids = torch.tensor([[5, 6, 7] + [tok] * T + [8, 9, 10, 11, 12]])
         pix = torch.randn(T, 3, 96, 96, generator=g)
         with cpu_kernels(), torch.no_grad():
-            runner = SequenceParallelTimeViper(vlm, rank, world)
+            # one case with the model-derived frame split, one with a strongly skewed split (4 + 1)
+            runner = SequenceParallelTimeViper(vlm, rank, world,
+                                               causal_skew=10.0 if merge == "CrossAttention" else None)
             lo, hi = runner.frame_range(T)
+            if merge == "CrossAttention":
+                assert runner.frame_split(T) == [(0, 4), (4, 5)]
             logits = runner.forward(ids, pix[lo:hi], T)
             trace = [t.clone() for t in runner.trace]
             if rank == 0:
@@ -165,3 +169,23 @@ def test_ragged_and_empty_shards():
         for part, ref in got[r]:
             assert part.shape == ref.shape
             assert np.allclose(part, ref, rtol=1e-4, atol=1e-5), (r, np.abs(part - ref).max())
+
+
+def test_split_frames_balances_causal_cost():
+    """k = 0 is the even split; k > 0 equalises f_r (1 + k (F_before + f_r / 2)) over the ranks with
+    contiguous, exhaustive, monotonically shrinking ranges; degenerate inputs stay valid."""
+    from timeviper_amd.distributed import split_frames
+    assert split_frames(10240, 8) == [(1280 * r, 1280 * (r + 1)) for r in range(8)]
+    k = 9e-6
+    sp = split_frames(10240, 8, k)
+    assert sp[0][0] == 0 and sp[-1][1] == 10240 and all(a[1] == b[0] for a, b in zip(sp, sp[1:]))
+    sizes = [b - a for a, b in sp]
+    assert sizes == sorted(sizes, reverse=True) and sizes[0] > 1280 > sizes[-1]
+    cost = [(b - a) * (1 + k * (a + (b - a) / 2)) for a, b in sp]
+    assert max(cost) / min(cost) < 1.002
+    even = [(b - a) * (1 + k * (a + (b - a) / 2)) for a, b in split_frames(10240, 8)]
+    assert max(even) > 1.025 * max(cost)                     # what the skew buys: ~3 % of the step
+    for n, w in ((3, 8), (17, 8), (1, 2), (0, 4)):
+        sp = split_frames(n, w, 1e-2)
+        assert len(sp) == w and sp[0][0] == 0 and sp[-1][1] == n
+        assert all(a[1] == b[0] and a[0] <= a[1] for a, b in zip(sp, sp[1:]))

@@ -58,19 +58,79 @@ def chain_states(states: torch.Tensor, decays: torch.Tensor, rank: int) -> torch
     return inc
 
 
-def split_frames(n_frames: int, world: int) -> List[Tuple[int, int]]:
-    base, rem = divmod(n_frames, world)
-    out, lo = [], 0
-    for r in range(world):
-        hi = lo + base + (1 if r < rem else 0)
-        out.append((lo, hi))
-        lo = hi
+def split_frames(n_frames: int, world: int, causal_skew: float = 0.0) -> List[Tuple[int, int]]:
+    """Contiguous frame ranges, one per rank.  `causal_skew` = k >= 0 models a rank's step time as
+    f_r (1 + k (F_before_r + f_r / 2)): work linear in its frames (ViT, GEMMs, scans) plus causal
+    attention of its frames against everything before them.  k = 0 gives the even split; k > 0
+    hands later ranks fewer frames so that all ranks finish together (k from
+    `estimate_causal_skew`; at 10 240 frames over 8 ranks the last rank's attention is otherwise
+    1.9x the mean: ~3 % of the step)."""
+    if causal_skew <= 0.0 or world == 1 or n_frames < 2 * world:
+        base, rem = divmod(n_frames, world)
+        sizes = [base + (1 if r < rem else 0) for r in range(world)]
+    else:
+        k = float(causal_skew)
+
+        def sizes_for(cost):
+            out, before = [], 0.0
+            for _ in range(world):
+                a = 1.0 + k * before
+                f = (-a + math.sqrt(a * a + 2.0 * k * cost)) / k
+                out.append(f)
+                before += f
+            return out
+        lo, hi = 0.0, n_frames * (1.0 + k * n_frames)
+        for _ in range(80):                       # bisection on the common per-rank cost
+            mid = 0.5 * (lo + hi)
+            lo, hi = (mid, hi) if sum(sizes_for(mid)) < n_frames else (lo, mid)
+        real = sizes_for(hi)
+        sizes = [int(v) for v in real]            # largest remainders take the frames left over
+        order = sorted(range(world), key=lambda r: real[r] - sizes[r], reverse=True)
+        for r in order[: n_frames - sum(sizes)]:
+            sizes[r] += 1
+    out, lo_f = [], 0
+    for n in sizes:
+        out.append((lo_f, lo_f + n))
+        lo_f += n
     return out
 
 
+# effective rates behind `estimate_causal_skew` (measured on MI355X, DESIGN.md section 5): the whole
+# forward without the LLM attention sustains ~0.95 PFLOP/s of its linear-layer FLOPs, the causal
+# attention kernel 0.86 PFLOP/s
+_LINEAR_RATE, _ATTN_RATE = 0.95e15, 0.86e15
+
+
+def estimate_causal_skew(vlm, tokens_per_frame: int) -> float:
+    """k of `split_frames` from the model's own shapes: seconds of causal attention per
+    (query frame, key frame) pair over seconds of everything else per frame."""
+    import torch.nn as nn
+    lin = lambda m: sum(p.weight.numel() for p in m.modules() if isinstance(p, nn.Linear))
+    bb = vlm.llm_backbone.llm.backbone
+    vb = vlm.vision_backbone
+    patches = getattr(vb, "num_patches", 0)
+    flops_lin = 2.0 * lin(vb) * patches
+    keep, attn_pair = 1.0, 0.0
+    ratios = list(getattr(bb, "pdrop_ratios", [1])) if getattr(bb, "use_pdrop", False) else [1]
+    layers = list(getattr(bb, "pdrop_layers", [])) if getattr(bb, "use_pdrop", False) else []
+    for i, block in enumerate(bb.layers):
+        if i in layers:
+            keep = float(ratios[layers.index(i) + 1])
+        flops_lin += 2.0 * lin(block) * tokens_per_frame * keep
+        if getattr(block, "block_type", "") == "attention":
+            mx = block.mixer
+            attn_pair += 4.0 * (tokens_per_frame * keep) ** 2 * mx.head_dim * mx.num_heads
+    if flops_lin <= 0.0:
+        return 0.0
+    return (attn_pair / _ATTN_RATE) / (flops_lin / _LINEAR_RATE)
+
+
 class SequenceParallelTimeViper:
-    def __init__(self, vlm, rank: int, world: int, group=None):
+    def __init__(self, vlm, rank: int, world: int, group=None, causal_skew: Optional[float] = None):
+        """`causal_skew`: see `split_frames`; None = estimate it from the model (every rank computes
+        the same number from the same shapes), 0 = even frame split."""
         self.vlm, self.rank, self.world, self.group = vlm, rank, world, group
+        self.causal_skew = causal_skew
         self.llm = vlm.llm_backbone.llm
         if vlm.llm_backbone.llm_family != "nano":
             raise NotImplementedError("sequence parallelism is built for the hybrid Mamba-2 backbone only "
@@ -80,7 +140,15 @@ class SequenceParallelTimeViper:
 
     # ---------------------------------------------------------------- layout
     def frame_range(self, n_frames: int) -> Tuple[int, int]:
-        return split_frames(n_frames, self.world)[self.rank]
+        return self.frame_split(n_frames)[self.rank]
+
+    def frame_split(self, n_frames: int) -> List[Tuple[int, int]]:
+        if self.causal_skew is None:
+            tpf = getattr(self.vlm, "num_compressed_tokens", 16)
+            if hasattr(self.vlm.vision_backbone, "backbone_ids"):
+                tpf *= len(self.vlm.vision_backbone.backbone_ids)
+            self.causal_skew = estimate_causal_skew(self.vlm, tpf)
+        return split_frames(n_frames, self.world, self.causal_skew)
 
     def shard_layout(self, input_ids: torch.Tensor, n_frames: int, tok_per_frame: int):
         """Global token ranges [start, end) of every rank's shard, for a prompt of the form
@@ -92,7 +160,7 @@ class SequenceParallelTimeViper:
         assert last - first + 1 == n_frames == int(is_img.sum()), "one contiguous <image> run expected"
         n_before, n_after = first, ids.numel() - last - 1
         bounds = []
-        for r, (lo, hi) in enumerate(split_frames(n_frames, self.world)):
+        for r, (lo, hi) in enumerate(self.frame_split(n_frames)):
             s = n_before + lo * tok_per_frame if r > 0 else 0
             e = n_before + hi * tok_per_frame + (n_after if r == self.world - 1 else 0)
             bounds.append((s, e))
