@@ -49,7 +49,7 @@ def build(merge):
 def worker(rank, world, port, merge, T, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.set_num_threads(2)
+    torch.set_num_threads(2 if world <= 4 else 1)
     try:
         from timeviper_amd.distributed import SequenceParallelTimeViper
         vlm = build(merge)
@@ -62,7 +62,7 @@ def worker(rank, world, port, merge, T, q):
             runner = SequenceParallelTimeViper(vlm, rank, world,
                                                causal_skew=10.0 if merge == "CrossAttention" else None)
             lo, hi = runner.frame_range(T)
-            if merge == "CrossAttention":
+            if merge == "CrossAttention" and world == 2:
                 assert runner.frame_split(T) == [(0, 4), (4, 5)]
             logits = runner.forward(ids, pix[lo:hi], T)
             trace = [t.clone() for t in runner.trace]
@@ -80,9 +80,9 @@ def worker(rank, world, port, merge, T, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("merge", ["no_merge", "CrossAttention"])
-def test_sequence_parallel_matches_single_process(merge):
-    world, T = 2, 5
+@pytest.mark.parametrize("merge,world,T", [("no_merge", 2, 5), ("CrossAttention", 2, 5), ("CrossAttention", 8, 21)])
+def test_sequence_parallel_matches_single_process(merge, world, T):
+    """world 8 = the node size the driver scales to: eight ranks, unequal frame ranges"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
