@@ -101,6 +101,9 @@ int tv_layernorm_fwd(const void* x, const void* delta, const void* weight,
                      int64_t x_stride, int64_t delta_stride, int64_t sum_stride,
                      int64_t y_stride, float eps, int dtype, void* stream);
 int tv_gelu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream);
+/* M1: y = relu(x)^2, the "relu2" activation of NemotronHMLP.forward (modeling_nano.py:993-994,
+ * ACT2FN["relu2"]: square(relu(x)), one rounding to dtype); in place when y == x. */
+int tv_relu2_fwd(const void* x, void* y, int64_t n, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------
  * S4  gated, grouped RMSNorm.  Replaces mamba_ssm rmsnorm_fn(x, weight,

@@ -118,6 +118,7 @@ def cpu_kernels():
         "apply_rotary_pos_emb_": _rope_,
         "silu_mul": lambda g, u: torch.nn.functional.silu(g) * u,
         "tome_merge_round": RV.tome_merge_round_ref,
+        "relu2": lambda x, inplace=False: torch.square(torch.relu(x)),
     }
     saved = {k: getattr(K, k) for k in patches}
     for k, v in patches.items():

@@ -475,6 +475,18 @@ def test_layernorm_and_gelu(K, dtype):
         close(K.gelu(r.to(DEV)), torch.nn.functional.gelu(r.float()), *TOL[dtype])
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_relu2(K, dtype):
+    """bit-exact: square(relu(x)) has one rounding in the reference's dtype (modeling_nano.py:993)"""
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(37, 1571, generator=g) * 3).to(dtype)          # ragged: not a multiple of the vector
+    ref = torch.square(torch.relu(x))
+    y = K.relu2(x.to(DEV))
+    assert torch.equal(y.cpu(), ref)
+    z = x.to(DEV).clone()
+    assert K.relu2(z, inplace=True).data_ptr() == z.data_ptr() and torch.equal(z.cpu(), ref)
+
+
 def test_zero_length_inputs(K):
     """A rank of the sharded runner can be left with no tokens: every operator must accept
     L = 0 (and a one-token shard with a conv halo)."""

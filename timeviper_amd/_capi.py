@@ -28,6 +28,7 @@ SIGNATURES = {
     "tv_rmsnorm_fwd": (_i, [_p, _p, _p, _p, _p, _l, _i, _l, _l, _l, _l, _f, _i, _i, _p]),
     "tv_layernorm_fwd": (_i, [_p] * 6 + [_l, _i, _l, _l, _l, _l, _f, _i, _p]),
     "tv_gelu_fwd": (_i, [_p, _p, _l, _i, _p]),
+    "tv_relu2_fwd": (_i, [_p, _p, _l, _i, _p]),
     "tv_rmsnorm_gated_fwd": (_i, [_p, _p, _p, _p, _l, _i, _i, _l, _l, _l, _f, _i, _i, _p]),
     "tv_ssd_scan_workspace_bytes": (_z, [_i] * 7),
     "tv_ssd_scan_fwd": (_i, [_p] * 11 + [_i] * 6 + [_l] * 12 + [_i, _i, _f, _f, _i, _p, _z, _p]),

@@ -241,8 +241,18 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return __builtin_fmaf(hx, copysignf(erf_abs, x), hx);
 }
 
-// exact-formula (erf) GELU, elementwise, 16 bytes per lane, grid-stride
-template <typename T>
+// relu(x)^2 (NemotronHMLP's "relu2" activation, modeling_nano.py:993-994)
+__device__ __forceinline__ float relu2(float x) {
+  const float r = fmaxf(x, 0.f);
+  return r * r;
+}
+enum { ACT_GELU = 0, ACT_RELU2 = 1 };
+template <int ACT> __device__ __forceinline__ float act_apply(float x) {
+  return ACT == ACT_GELU ? gelu_erf(x) : relu2(x);
+}
+
+// elementwise activation (exact-formula GELU / relu^2), 16 bytes per lane, grid-stride
+template <typename T, int ACT>
 __global__ __launch_bounds__(256) void gelu_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                    int64_t nvec, int64_t n) {
   constexpr int V = Vec16<T>::N;
@@ -258,7 +268,7 @@ __global__ __launch_bounds__(256) void gelu_kernel(const T* __restrict__ x, T* _
     for (int u = 0; u < U; ++u) {
       vec_t o;
 #pragma unroll
-      for (int j = 0; j < V; ++j) o[j] = from_f32<T>(gelu_erf(to_f32(v[u][j])));
+      for (int j = 0; j < V; ++j) o[j] = from_f32<T>(act_apply<ACT>(to_f32(v[u][j])));
       *(vec_t*)(y + (i + u * stride) * V) = o;
     }
   }
@@ -266,12 +276,12 @@ __global__ __launch_bounds__(256) void gelu_kernel(const T* __restrict__ x, T* _
     const vec_t v = *(const vec_t*)(x + i * V);
     vec_t o;
 #pragma unroll
-    for (int j = 0; j < V; ++j) o[j] = from_f32<T>(gelu_erf(to_f32(v[j])));
+    for (int j = 0; j < V; ++j) o[j] = from_f32<T>(act_apply<ACT>(to_f32(v[j])));
     *(vec_t*)(y + i * V) = o;
   }
   if (blockIdx.x == 0) {   // ragged tail (< one vector)
     const int64_t k = nvec * V + threadIdx.x;
-    if (k < n) y[k] = from_f32<T>(gelu_erf(to_f32(x[k])));
+    if (k < n) y[k] = from_f32<T>(act_apply<ACT>(to_f32(x[k])));
   }
 }
 
@@ -475,20 +485,31 @@ extern "C" int tv_layernorm_fwd(const void* x, const void* delta, const void* we
   TV_UNSUPPORTED("layernorm: dtype %d", dtype);
 }
 
-extern "C" int tv_gelu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream) {
-  TV_CHECK_ARG(n == 0 || (x && y), "gelu: null pointer");
-  TV_CHECK_ARG(n >= 0, "gelu: bad size");
+namespace {
+template <int ACT>
+int launch_act(const char* name, const void* x, void* y, int64_t n, int dtype, void* stream) {
+  if (n < 0) { tv_set_error("%s: bad size", name); return TV_ERR_BAD_ARG; }
   if (n == 0) return TV_OK;
+  if (!x || !y) { tv_set_error("%s: null pointer", name); return TV_ERR_BAD_ARG; }
   const int vec = dtype == TV_F32 ? 4 : 8;
-  if (!aligned16(x) || !aligned16(y)) TV_UNSUPPORTED("gelu: pointers must be 16-byte aligned");
+  if (!aligned16(x) || !aligned16(y)) TV_UNSUPPORTED("%s: pointers must be 16-byte aligned", name);
   const int64_t nvec = n / vec;
   const unsigned grid = (unsigned)((nvec + 255) / 256 < 8192 ? (nvec + 255) / 256 + (nvec == 0) : 8192);
   hipStream_t s = (hipStream_t)stream;
   switch (dtype) {
-    case TV_F32: gelu_kernel<float><<<grid, 256, 0, s>>>((const float*)x, (float*)y, nvec, n); break;
-    case TV_BF16: gelu_kernel<bf16_t><<<grid, 256, 0, s>>>((const bf16_t*)x, (bf16_t*)y, nvec, n); break;
-    case TV_F16: gelu_kernel<f16_t><<<grid, 256, 0, s>>>((const f16_t*)x, (f16_t*)y, nvec, n); break;
-    default: TV_UNSUPPORTED("gelu: dtype %d", dtype);
+    case TV_F32: gelu_kernel<float, ACT><<<grid, 256, 0, s>>>((const float*)x, (float*)y, nvec, n); break;
+    case TV_BF16: gelu_kernel<bf16_t, ACT><<<grid, 256, 0, s>>>((const bf16_t*)x, (bf16_t*)y, nvec, n); break;
+    case TV_F16: gelu_kernel<f16_t, ACT><<<grid, 256, 0, s>>>((const f16_t*)x, (f16_t*)y, nvec, n); break;
+    default: TV_UNSUPPORTED("%s: dtype %d", name, dtype);
   }
   TV_LAUNCH_CHECK();
+}
+}  // namespace
+
+extern "C" int tv_gelu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream) {
+  return launch_act<ACT_GELU>("gelu", x, y, n, dtype, stream);
+}
+
+extern "C" int tv_relu2_fwd(const void* x, void* y, int64_t n, int dtype, void* stream) {
+  return launch_act<ACT_RELU2>("relu2", x, y, n, dtype, stream);
 }

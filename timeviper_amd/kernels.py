@@ -189,6 +189,15 @@ def gelu(x, inplace=False):
     return y
 
 
+def relu2(x, inplace=False):
+    """square(relu(x)) — NemotronHMLP's activation (modeling_nano.py:993-994), elementwise."""
+    _gpu(x)
+    xc = x if x.is_contiguous() else x.contiguous()
+    y = xc if inplace else torch.empty_like(xc)
+    check(_capi.lib().tv_relu2_fwd(_p(xc), _p(y), xc.numel(), _dt(xc), _stream()), "tv_relu2_fwd")
+    return y
+
+
 def rmsnorm_fn(x, weight, bias=None, z=None, eps=1e-6, group_size=None,
                norm_before_gate=True, upcast=True):
     """mamba_ssm.ops.triton.layernorm_gated.rmsnorm_fn as the reference calls it

@@ -326,7 +326,8 @@ class NemotronHMLP(nn.Module):
         self.act_fn = ReLUSquared()
 
     def forward(self, x):
-        return self.down_proj(self.act_fn(self.up_proj(x)))
+        # `act_fn` stays for the module tree; the activation runs as one in-place HIP pass
+        return self.down_proj(K.relu2(self.up_proj(x), inplace=True))
 
 
 class NemotronHAttention(nn.Module):
