@@ -25,8 +25,10 @@ from typing import Optional, Tuple
 import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from ... import kernels as K
+from .siglip import ZeroPaddedLinears, _aligned, _pad_rows
 from . import VisionBackbone
 
 
@@ -96,11 +98,19 @@ class Attention(nn.Module):
         self.qk_normalization = qk_normalization
         self.q_norm = RMSNorm(dim) if qk_normalization else nn.Identity()
         self.k_norm = RMSNorm(dim) if qk_normalization else nn.Identity()
+        self._padded = ZeroPaddedLinears()
 
     def forward(self, x):
         B, N, C = x.shape
-        qkv = self.qkv(x)
-        q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+        if ZeroPaddedLinears.wanted(x, 3 * C):      # 3 x 1408 = 4224 -> 4352 (GEMM tile multiple)
+            qb = self.qkv.bias
+            w, b = self._padded.get((self.qkv.weight,) + ((qb,) if qb is not None else ()), lambda: (
+                _pad_rows(self.qkv.weight.detach(), _aligned(3 * C)),
+                None if qb is None else _pad_rows(qb.detach(), _aligned(3 * C))))
+            qkv = F.linear(x, w, b)
+        else:
+            qkv = self.qkv(x)
+        q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:3 * C]
         if self.qk_normalization:
             q, k = self.q_norm(q), self.k_norm(k)
         hd = (B, N, self.num_heads, self.head_dim)
