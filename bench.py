@@ -173,6 +173,11 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
+    if local_rank == 0:         # a tree without build artefacts: compile once, the others wait
+        from timeviper_amd.build import ensure_built
+        ensure_built()
+    if sharded:
+        torch.distributed.barrier()
     from timeviper_amd import kernels as K
     from timeviper_amd.model import build_synthetic_timeviper
     from timeviper_amd.model.llm.nano import NemotronHConfig

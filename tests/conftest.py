@@ -14,6 +14,8 @@ GOLDEN = ROOT / "tests" / "golden"
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    from timeviper_amd.build import ensure_built
+    ensure_built()          # hipcc cross-compiles without a GPU; no-op when the .so is in the tree
 
 
 def pytest_collection_modifyitems(config, items):

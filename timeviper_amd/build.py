@@ -67,6 +67,13 @@ def build(force: bool = False, jobs: int = 4) -> Path:
     return LIB
 
 
+def ensure_built() -> Path:
+    """Compile the library if the tree does not carry it (a checkout without build artefacts);
+    a no-op when `lib/libtimeviper_hip.so` exists.  This is a BUILD step, not a fallback: without a
+    working hipcc it raises, and the operators keep failing loudly."""
+    return LIB if LIB.exists() else build()
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")
