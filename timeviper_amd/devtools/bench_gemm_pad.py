@@ -3,12 +3,10 @@ import torch
 import torch.nn.functional as F
 from bench_gemm import timeit
 
-M = 163940
-for name, K, N in [("in_proj N=22656", 4480, 22656), ("in_proj N=22784", 4480, 22784),
-                   ("mlp_up N=15680", 4480, 15680), ("mlp_up N=15872", 4480, 15872),
-                   ("mlp_down K=15680", 15680, 4480), ("mlp_down K=15872", 15872, 4480),
-                   ("out_proj N=4480", 10240, 4480), ("out_proj N=4608", 10240, 4608),
-                   ("K=4480 N=5120", 4480, 5120), ("K=4608 N=5120", 4608, 5120)]:
+import sys
+M = int(sys.argv[1]) * 729 if len(sys.argv) > 1 else 2048 * 729
+for name, K, N in [("fc1 N=4304", 1152, 4304), ("fc1 N=4352", 1152, 4352), ("fc2 K=4304", 4304, 1152),
+                   ("fc2 K=4352", 4352, 1152), ("qkv N=3456", 1152, 3456), ("qkv N=3584", 1152, 3584)]:
     x = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
     w = torch.randn(N, K, device="cuda", dtype=torch.bfloat16) * 0.02
     b = torch.zeros(N, device="cuda", dtype=torch.bfloat16)
