@@ -469,3 +469,44 @@ def test_vit_zero_padded_gemms_match_plain_linears():
     assert blk.mlp.fc1.weight.shape == (4304, 1152) and set(blk.state_dict()) == {
         "norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias",
         "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias"}
+
+
+def test_internvideo2_fused_clips_equal_separate_clips():
+    """`encode_vision` hands InternVideo2 (alone or inside a dual encoder) several 256-frame clips at
+    once; the tower regroups each clip with the reference's clip-length-dependent reshape
+    (model.py:178-182) and batches the tubes — the result must equal separate 256-frame calls, incl.
+    a ragged last clip."""
+    from timeviper_amd.model import build_synthetic_timeviper
+    from timeviper_amd.model.llm.nano import NemotronHConfig
+    from timeviper_amd.model.vit.internvideo2 import InternVideo2VisionConfig
+    cfg = NemotronHConfig(vocab_size=128, hidden_size=64, intermediate_size=96, num_hidden_layers=2,
+                          hybrid_override_pattern="M-", num_attention_heads=4, head_dim=16,
+                          num_key_value_heads=2, ssm_state_size=16, mamba_num_heads=8,
+                          mamba_n_groups=2, mamba_head_dim=8, mamba_chunk_size=16)
+    vcfg = InternVideo2VisionConfig(num_frames=4, hidden_size=64, num_hidden_layers=3,
+                                    num_attention_heads=2, image_size=112, patch_size=14)
+    T = 2 * 256 + 8
+    torch.manual_seed(4)
+    pix4 = torch.randn(T, 3, 112, 112, device=DEV).bfloat16()
+    for bid, kw in (("internvideo2-1b-16-224px", dict(vision_config=vcfg, image_size=112)),
+                    ("dinov2-vit-l+internvideo2-1b-16-224px", dict(image_size=112, member_kwargs={
+                        "dinov2-vit-l": dict(depth_override=2, default_image_size=112),
+                        "internvideo2-1b-16-224px": dict(default_image_size=112, vision_config=vcfg)}))):
+        vlm = build_synthetic_timeviper(cfg, bid, **kw)
+        pix = pix4 if "+" in bid else pix4.unsqueeze(1)
+        vb = vlm.vision_backbone
+        with torch.no_grad():
+            assert vlm.encode_vision(pix, True).shape == (T, 16 * (2 if "+" in bid else 1), 64)
+            fused = vb(pix, is_video=True, clip_frames=256)                     # what encode_vision calls
+            sep = [vb(c, is_video=True) for c in pix.split(256)]                # the reference's clips
+            for key in (fused if isinstance(fused, dict) else {None: 0}):
+                f = fused[key] if key is not None else fused
+                r = torch.cat([c[key] if key is not None else c for c in sep])
+                assert f.shape == r.shape and relerr(f, r) < 5e-3, (bid, key)
+            # ToMe + MLP see tubes / frames one by one: same features -> same tokens for any batching
+            # (features that differ by GEMM rounding may flip a near-tie in the discrete matching,
+            # which is why the projector is compared on identical inputs)
+            pf = vlm.projector_forward(fused, is_video=True)
+            first = {k: v[: (64 if "internvideo2" in k else 256)] for k, v in fused.items()} \
+                if isinstance(fused, dict) else fused[:64]
+            assert relerr(pf[:256], vlm.projector_forward(first, is_video=True)) < 5e-3, bid

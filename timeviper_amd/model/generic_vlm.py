@@ -66,7 +66,8 @@ class GenericTimeViperVLM(nn.Module):
         # every frame on its own (timm ViTs + frame-wise ToMe) give the same result for any clip
         # size, and larger GEMM / elementwise launches run ~6 % faster on MI355X (288 GB), so such
         # towers are fed `vit_clip_fuse` clips at a time.  InternVideo2 regroups frames into tubes
-        # with a reshape that depends on the clip length (model.py:178-182): it keeps 256.
+        # with a reshape that depends on the clip length (model.py:178-182): it regroups every 256 frames
+        # as a separate call would, then runs the tubes of all fused clips as one batch.
         self.vit_clip_fuse = 8
 
     # ---- attributes read by callers (evaluate.py:223,392-393,619) ----
@@ -151,10 +152,15 @@ class GenericTimeViperVLM(nn.Module):
     @torch.no_grad()
     def encode_vision(self, vision_inputs, is_video: bool):
         """eval branch of :266-281: clips of 256 frames through ViT + projector."""
-        n = self.vit_clip_frames
-        if getattr(self.vision_backbone, "frame_independent", False):
+        vb, n, kw = self.vision_backbone, self.vit_clip_frames, {}
+        if getattr(vb, "frame_independent", False):
             n *= max(1, int(self.vit_clip_fuse))
-        feats = [self.projector_forward(self.vision_backbone(clip, is_video=is_video), is_video=is_video)
+        elif getattr(vb, "batched_clips", False) and is_video:
+            # the backbone regroups every `vit_clip_frames` frames as a separate call would and runs
+            # the tubes of `vit_clip_fuse` clips as one batch
+            kw = {"clip_frames": n}
+            n *= max(1, int(self.vit_clip_fuse))
+        feats = [self.projector_forward(vb(clip, is_video=is_video, **kw), is_video=is_video)
                  for clip in vision_inputs.split(split_size=n)]
         return torch.cat(feats, dim=0)
 

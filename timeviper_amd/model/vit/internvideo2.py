@@ -276,15 +276,21 @@ class InternVideo2VisionTower(nn.Module):
         self.vision_tower.requires_grad_(False)
 
     @torch.no_grad()
-    def forward(self, pixel_values: torch.Tensor, is_video: Optional[bool] = None):
+    def forward(self, pixel_values: torch.Tensor, is_video: Optional[bool] = None,
+                clip_frames: Optional[int] = None):
         """Video input arrives (T, B, C, H, W); it is regrouped into 4-frame clips with the
         reference's permute + reshape (model.py:178-182) — for B == 1 and T > 4 that
-        reshape, not a permute, decides which frames share a clip, and it is kept as is."""
+        reshape, not a permute, decides which frames share a clip, and it is kept as is.
+        `clip_frames`: the caller's clip length (256 in `generic_vlm.py:274`); a longer input is
+        regrouped clip by clip exactly as separate calls would be and the tubes of all clips run
+        through the tower in ONE batch (tubes are independent)."""
         if is_video is None:
             is_video = pixel_values.shape[1] > 1
         if is_video:
-            T, B, C, H, W = pixel_values.shape
-            px = pixel_values.permute(1, 2, 0, 3, 4).reshape(B * (T // 4), C, 4, H, W)
+            C, H, W = pixel_values.shape[2:]
+            step = clip_frames or pixel_values.shape[0]
+            px = torch.cat([c.permute(1, 2, 0, 3, 4).reshape(c.shape[1] * (c.shape[0] // 4), C, 4, H, W)
+                            for c in pixel_values.split(step)])
         else:
             px = pixel_values.permute(0, 2, 1, 3, 4)
         return self.vision_tower(px, use_image=not is_video)[:, 1:, :]
@@ -316,8 +322,11 @@ class InternVideo2ViTBackbone(VisionBackbone):
         state = torch.load(ckpt_path, map_location="cpu")
         return self.featurizer.vision_tower.load_state_dict(state, strict=False)
 
-    def forward(self, pixel_values: torch.Tensor, is_video: Optional[bool] = None, **kwargs):
-        return self.featurizer(pixel_values, is_video=is_video)
+    batched_clips = True     # forward(..., clip_frames=n) == per-clip calls concatenated
+
+    def forward(self, pixel_values: torch.Tensor, is_video: Optional[bool] = None,
+                clip_frames: Optional[int] = None, **kwargs):
+        return self.featurizer(pixel_values, is_video=is_video, clip_frames=clip_frames)
 
     @property
     def get_identifier(self) -> str:

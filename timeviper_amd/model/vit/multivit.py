@@ -67,13 +67,16 @@ class MultiViTBackbone(VisionBackbone):
             px = F.interpolate(px, size=(size, size), mode="bilinear", align_corners=False)
         return px.unsqueeze(1) if isinstance(member, InternVideo2ViTBackbone) else px
 
-    def forward(self, pixel_values: torch.Tensor, is_video: Optional[bool] = None, **kwargs):
+    batched_clips = True     # members are frame-independent or take `clip_frames` themselves
+
+    def forward(self, pixel_values: torch.Tensor, is_video: Optional[bool] = None,
+                clip_frames: Optional[int] = None, **kwargs):
         out = {}
         for bid in self.backbone_ids:
             member = self.backbones[bid.replace("-", "_")]
             px = self._frames_for(member, pixel_values)
             if isinstance(member, InternVideo2ViTBackbone):
-                out[bid] = member(px, is_video=bool(is_video))
+                out[bid] = member(px, is_video=bool(is_video), clip_frames=clip_frames)
             else:
                 out[bid] = member(px)
         return out
