@@ -166,3 +166,38 @@ def test_vit_fused_clips_equal_reference_clips(K):
             pv = vlm.projector_forward(got, is_video=True)
             errp = (vis[lo:lo + 256].float() - pv.float()).norm() / pv.float().norm()
             assert errp < 5e-3, (lo, float(errp))
+
+
+def test_pdrop_token_ops_full_length(K):
+    """The four evaluate.py stages (1 -> .8 -> .6 -> .4 -> .2 of 163 840 vision tokens, generic_vlm /
+    evaluate.py:170) at full size, integer work checked exactly: keep indices == CPU
+    `torch.linspace(dtype=long)`, dropped = exact complement, gather == torch indexing (bit-exact),
+    and the rank scores of the last prompt token == a direct softmax on the same rows."""
+    NV, D = 10240 * 16, 4480
+    hidden = torch.randn(NV + 100, D, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3)).bfloat16()
+    n = NV
+    for r in (0.8, 0.6, 0.4, 0.2):
+        keep = int(NV * r)
+        idx = K.uniform_keep_indices(n, keep, offset=20)
+        ref = torch.linspace(0, n - 1, keep, dtype=torch.long) + 20                 # CPU semantics
+        assert torch.equal(idx.cpu(), ref), r
+        drop = K.dropped_indices(idx, 20, n)
+        assert drop.numel() == n - keep
+        both = torch.cat([idx, drop]).sort().values
+        assert torch.equal(both, torch.arange(20, 20 + n, device=DEV)), r
+        rows = K.gather_rows(hidden, idx)
+        assert torch.equal(rows, hidden[idx]), r
+        n = keep
+    # "attn" ranking: 40 query heads / 8 kv heads x 128 over 163 940 keys
+    Hq, Hkv, Dh, Lk = 40, 8, 128, NV + 100
+    g = torch.Generator(device=DEV).manual_seed(5)
+    q = torch.randn(Hq, Dh, device=DEV, generator=g).bfloat16()
+    k = torch.randn(Lk, Hkv, Dh, device=DEV, generator=g).bfloat16()
+    sc = K.attn_rank_scores(q, k, Lk, 20, NV)
+    assert sc.shape == (NV,)
+    logit = torch.einsum("hd,khd->hk", q.float(), k.float().repeat_interleave(Hq // Hkv, 1)).bfloat16()
+    logit = (logit.float() / math.sqrt(Dh)).bfloat16().float()
+    p = torch.softmax(logit, dim=-1).bfloat16().float().mean(0).bfloat16().float()[20:20 + NV]
+    top = lambda t: set(torch.topk(t, 2048).indices.tolist())
+    assert len(top(sc.float()) & top(p)) >= 2048 * 0.98            # bf16 ties at the cut may differ
+    assert rel(sc, p) < 2e-2
