@@ -280,11 +280,16 @@ int tv_dropped_indices(const int64_t* keep_sorted, int64_t n_keep,
  * pixels (F,Cin,H,W) contiguous `dtype`; weight (Dout, Cin*p*p) `dtype`
  * (the Conv weight flattened); bias (Dout) / pos (gh*gw, Dout) optional;
  * out (F, gh*gw, Dout).
+ * workspace: tv_patch_embed_workspace_bytes(dout, cin, patch) bytes, 16-byte
+ * aligned, caller-provided: the launcher packs the weight into it ((c,dy) rows
+ * padded to the 16-wide MFMA k-step) before the GEMM; NULL selects the slower
+ * path that re-pads the raw weight inside every work-group.
  * --------------------------------------------------------------------- */
+size_t tv_patch_embed_workspace_bytes(int dout, int cin, int patch);
 int tv_patch_embed_fwd(const void* pixels, const void* weight, const void* bias,
                        const void* pos, void* out, int frames, int cin,
                        int height, int width, int patch, int dout, int dtype,
-                       void* stream);
+                       void* workspace, void* stream);
 /* Same GEMM with an explicit frame layout: the pixel offset of (frame f,
  * channel c) is (f / frames_per_group) * group_stride + (f % frames_per_group)
  * * frame_stride + c * chan_stride (elements).  Conv3d input (B,C,T,H,W) with
@@ -296,7 +301,8 @@ int tv_patch_embed_strided_fwd(const void* pixels, const void* weight,
                                int frames, int cin, int height, int width,
                                int patch, int dout, int frames_per_group,
                                int64_t group_stride, int64_t frame_stride,
-                               int64_t chan_stride, int dtype, void* stream);
+                               int64_t chan_stride, int dtype, void* workspace,
+                               void* stream);
 
 #ifdef __cplusplus
 }

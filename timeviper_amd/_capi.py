@@ -44,8 +44,9 @@ SIGNATURES = {
     "tv_silu_mul_fwd": (_i, [_p, _p, _p, _l, _i, _l, _l, _l, _i, _p]),
     "tv_tome_workspace_bytes": (C.c_size_t, [_i, _i, _i, _i]),
     "tv_tome_merge_round": (_i, [_p] * 4 + [_i] * 6 + [_p, C.c_size_t, _p]),
-    "tv_patch_embed_fwd": (_i, [_p] * 5 + [_i] * 7 + [_p]),
-    "tv_patch_embed_strided_fwd": (_i, [_p] * 5 + [_i] * 7 + [_l] * 3 + [_i, _p]),
+    "tv_patch_embed_workspace_bytes": (_z, [_i] * 3),
+    "tv_patch_embed_fwd": (_i, [_p] * 5 + [_i] * 7 + [_p, _p]),
+    "tv_patch_embed_strided_fwd": (_i, [_p] * 5 + [_i] * 7 + [_l] * 3 + [_i, _p, _p]),
 }
 
 

@@ -12,5 +12,5 @@ void tv_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int tv_abi_version(void) { return 2; }
+extern "C" int tv_abi_version(void) { return 3; }
 extern "C" const char* tv_last_error(void) { return g_err; }

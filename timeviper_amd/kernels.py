@@ -496,8 +496,10 @@ def patch_embed(pixels, weight, bias=None, pos=None, patch: Optional[int] = None
     b = None if bias is None else bias.to(pixels.dtype).contiguous()
     ps = None if pos is None else pos.reshape(-1, Dout).to(pixels.dtype).contiguous()
     out = torch.empty((F_, (H // p) * (W // p), Dout), dtype=pixels.dtype, device=pixels.device)
+    ws = torch.empty((_capi.lib().tv_patch_embed_workspace_bytes(Dout, Cin, p),), dtype=torch.uint8,
+                     device=pixels.device)
     check(_capi.lib().tv_patch_embed_fwd(_p(pixels), _p(w), _p(b), _p(ps), _p(out), F_, Cin, H,
-                                         W, p, Dout, _dt(pixels), _stream()),
+                                         W, p, Dout, _dt(pixels), _p(ws), _stream()),
           "tv_patch_embed_fwd")
     return out
 
@@ -514,7 +516,9 @@ def patch_embed_video(pixels, weight, bias=None, pos=None):
     ps = None if pos is None else pos.reshape(-1, Dout).to(pixels.dtype).contiguous()
     npatch = (H // p) * (W // p)
     out = torch.empty((B, T * npatch, Dout), dtype=pixels.dtype, device=pixels.device)
+    ws = torch.empty((_capi.lib().tv_patch_embed_workspace_bytes(Dout, Cin, p),), dtype=torch.uint8,
+                     device=pixels.device)
     check(_capi.lib().tv_patch_embed_strided_fwd(
         _p(pixels), _p(w), _p(b), _p(ps), _p(out), B * T, Cin, H, W, p, Dout, T,
-        Cin * T * H * W, H * W, T * H * W, _dt(pixels), _stream()), "tv_patch_embed_strided_fwd")
+        Cin * T * H * W, H * W, T * H * W, _dt(pixels), _p(ws), _stream()), "tv_patch_embed_strided_fwd")
     return out
