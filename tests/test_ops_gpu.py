@@ -414,6 +414,34 @@ def test_patch_embed(K, F_, C, H, W, p, Dout):
     close(out2, R.patch_embed_ref(pix.float(), w.float()), 2e-2, 2e-2)
 
 
+@pytest.mark.parametrize("p,H,W,Dout,dtype", [(16, 64, 48, 132, torch.bfloat16), (12, 36, 60, 64, torch.float16),
+                                              (7, 21, 35, 40, torch.bfloat16), (14, 42, 42, 1152, torch.bfloat16)])
+def test_patch_embed_paths(K, p, H, W, Dout, dtype):
+    """every staging path: dword rows for patch 16 / 14, the generic vector path (12), scalar rows for
+    an odd patch and width (7 x 35), with the packed-weight workspace and (straight through the C
+    ABI) without it; channel counts that are not a multiple of the 128-wide tile"""
+    from timeviper_amd import _capi
+    g = torch.Generator().manual_seed(p * H + W)
+    F_, C = 5, 3
+    pix = torch.randn(F_, C, H, W, generator=g).to(dtype)
+    w = (torch.randn(Dout, C, p, p, generator=g) / (p * 1.7)).to(dtype)
+    b = (torch.randn(Dout, generator=g) * 0.1).to(dtype)
+    pos = (torch.randn((H // p) * (W // p), Dout, generator=g) * 0.1).to(dtype)
+    ref = R.patch_embed_ref(pix.float(), w.float(), b.float(), pos.float())
+    tol = TOL[dtype]
+    out = K.patch_embed(pix.to(DEV), w.to(DEV), b.to(DEV), pos.to(DEV))
+    close(out, ref, *tol, "packed weight")
+    pd, wd, bd, psd = pix.to(DEV), w.reshape(Dout, -1).contiguous().to(DEV), b.to(DEV), pos.to(DEV)
+    raw = torch.empty_like(out)
+    st = _capi.lib().tv_patch_embed_fwd(pd.data_ptr(), wd.data_ptr(), bd.data_ptr(), psd.data_ptr(), raw.data_ptr(),
+                                        F_, C, H, W, p, Dout, _capi.TV_BF16 if dtype == torch.bfloat16 else _capi.TV_F16,
+                                        None, torch.cuda.current_stream().cuda_stream)
+    assert st == 0, _capi.lib().tv_last_error()
+    torch.cuda.synchronize()
+    close(raw, ref, *tol, "no workspace")
+    assert torch.equal(raw, out)          # same products in the same order: bit-identical
+
+
 def test_patch_embed_video(K):
     g = torch.Generator().manual_seed(77)
     pix = torch.randn(2, 3, 4, 28, 42, generator=g).to(torch.bfloat16)
