@@ -189,3 +189,25 @@ def test_split_frames_balances_causal_cost():
         sp = split_frames(n, w, 1e-2)
         assert len(sp) == w and sp[0][0] == 0 and sp[-1][1] == n
         assert all(a[1] == b[0] and a[0] <= a[1] for a, b in zip(sp, sp[1:]))
+
+
+def test_causal_skew_estimate_for_the_default_model():
+    """k from the 9B model's own shapes (built on the meta device): later ranks get fewer frames, by
+    the few percent the causal-attention imbalance is worth."""
+    from timeviper_amd.distributed import estimate_causal_skew, split_frames
+    from timeviper_amd.model import GenericLLMBackbone, HybridTimeViperVLM
+    from timeviper_amd.model.llm.nano import NemotronHConfig
+    from timeviper_amd.model.vit import TimmViTBackbone
+    with torch.device("meta"):
+        vb = TimmViTBackbone("siglip-vit-so400m-384px")
+        llm = GenericLLMBackbone("nanov2-9b", config=NemotronHConfig.nemotron_nano_9b_v2(), merge_module="CrossAttention",
+                                 use_pdrop=True, pdrop_type="uni_14_0.8-attn_21_0.6-attn_30_0.4-attn_39_0.2")
+        vlm = HybridTimeViperVLM("x", vb, llm, arch_specifier="tome_mlp-16")
+    k = estimate_causal_skew(vlm, 16)
+    assert 5e-6 < k < 1.5e-5
+    sizes = [b - a for a, b in split_frames(10240, 8, k)]
+    assert sum(sizes) == 10240 and 1300 < sizes[0] < 1360 and 1200 < sizes[-1] < 1260
+    with torch.device("meta"):
+        llm0 = GenericLLMBackbone("nanov2-9b", config=NemotronHConfig.nemotron_nano_9b_v2())
+        vlm0 = HybridTimeViperVLM("x", vb, llm0, arch_specifier="tome_mlp-16")
+    assert estimate_causal_skew(vlm0, 16) > k            # without pdrop attention weighs more
