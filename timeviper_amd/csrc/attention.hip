@@ -3,7 +3,7 @@
 // Structure (wave64, v_mfma_f32_32x32x16): a workgroup of 8 waves owns 256 query
 // rows of one (batch, q-head) (4 waves / 128 rows for short queries); each wave keeps
 // its 32 query rows as MFMA B fragments in registers for the whole kernel.  K/V tiles
-// of 64 keys arrive by LDS-DMA into a 3-stage ring shared by the waves, two tiles ahead
+// of 96 keys arrive by LDS-DMA into a 3-stage ring shared by the waves, two tiles ahead
 // of the math (counted vmcnt, one barrier per tile).  The score tile is computed
 // TRANSPOSED, S^T = K . Q^T, so every lane owns one query column: the softmax
 // row statistics are per-lane scalars (one cross-half shuffle per tile), and the
@@ -21,7 +21,9 @@
 namespace {
 
 constexpr int FA_QW = 32;                  // query rows per wave
-constexpr int FA_KB = 64;                  // keys per tile
+#ifndef FA_KT
+#define FA_KT 3                            // key sub-tiles of 32 per LDS tile (96 keys: +7 % causal d=128 vs 64)
+#endif
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -58,22 +60,25 @@ struct AttnArgs {
 };
 
 // KS = ceil(D/16) k-steps of QK^T, DT = ceil(D/32) d-tiles of PV, NW waves per workgroup.
-// K/V tiles of 64 keys go global -> LDS by LDS-DMA (global_load_lds_dwordx4, 16 bytes per
+// K/V tiles of 32*KT keys go global -> LDS by LDS-DMA (global_load_lds_dwordx4, 16 bytes per
 // lane, no VGPR round trip: staging through registers cost a third of the kernel) into a
 // ring of 3 stages, two tiles ahead of the math, with counted vmcnt waits and one barrier
 // per tile.  LDS rows are 256 bytes (128 elements); the 16-byte chunks of a row are
 // XOR-swizzled on the DMA source address so that the row reads of K (ds_read_b128, chunk ^
 // row%16) and the transposing reads of V (ds_read_b64_tr_b16, chunk ^ 4(row%4)) are bank
 // conflict free.  Chunks past head_dim are never copied (the K ones QK^T reads are zeroed once).
-template <typename T, int KS, int DT, int NW>
+template <typename T, int KS, int DT, int NW, int KT>
 __global__ __launch_bounds__(NW * 64) void flash_fwd_kernel(AttnArgs a) {
+  constexpr int FA_KB = 32 * KT;     // keys per tile
+  constexpr int NPK = FA_KB / 4;     // 1 KiB DMA pieces (4 key rows) of K per tile; as many of V
   typedef typename Frag<T>::v8 v8;
   typedef typename Frag<T>::v4 v4;
   constexpr int QB = NW * FA_QW;     // query rows per workgroup
   constexpr int ROWB = 256;          // LDS bytes per key row
   constexpr int TILEB = FA_KB * ROWB;
   constexpr int NS = 3;              // ring stages
-  constexpr int PPW = 32 / NW;       // 1 KiB DMA pieces per wave and tile (16 K + 16 V pieces)
+  constexpr int PPW = 2 * NPK / NW;  // DMA pieces per wave and tile
+  static_assert(2 * NPK % NW == 0, "pieces must divide over the waves");
   extern __shared__ __attribute__((aligned(16))) unsigned char fa_smem[];
   unsigned char* const sK = fa_smem;
   unsigned char* const sV = fa_smem + NS * TILEB;
@@ -136,8 +141,8 @@ __global__ __launch_bounds__(NW * 64) void flash_fwd_kernel(AttnArgs a) {
 #pragma unroll
   for (int i = 0; i < PPW; ++i) {
     const int pc = wave + NW * i;
-    const bool isK = pc < 16;
-    const int row = 4 * (pc & 15) + (lane >> 4);
+    const bool isK = pc < NPK;
+    const int row = 4 * (isK ? pc : pc - NPK) + (lane >> 4);
     const int c = (lane & 15) ^ (isK ? (row & 15) : 4 * (row & 3));
     p_row[i] = row;
     p_chunk[i] = c;
@@ -148,7 +153,7 @@ __global__ __launch_bounds__(NW * 64) void flash_fwd_kernel(AttnArgs a) {
     const int kbase = kt * FA_KB;
     const int stage = kt % NS;
     const int pc = wave + NW * i;
-    const bool isK = pc < 16;            // wave-uniform
+    const bool isK = pc < NPK;           // wave-uniform
     const void* tb = ssdk::uniform_ptr(isK ? (const void*)(kp + (int64_t)kbase * a.ksl)
                                            : (const void*)(vp + (int64_t)kbase * a.vsl));
     const int left = a.Lk - kbase;          // rows of this tile that exist
@@ -157,7 +162,7 @@ __global__ __launch_bounds__(NW * 64) void flash_fwd_kernel(AttnArgs a) {
       const int rr = min(p_row[i], left - 1);
       off = (unsigned)(((int64_t)rr * (isK ? a.ksl : a.vsl) + p_chunk[i] * 8) * (int)sizeof(T));
     }
-    const unsigned dst = ssdk::lds_addr_of((isK ? sK : sV) + stage * TILEB + (pc & 15) * 1024);
+    const unsigned dst = ssdk::lds_addr_of((isK ? sK : sV) + stage * TILEB + (isK ? pc : pc - NPK) * 1024);
     if (p_chunk[i] < dchunks) ssdk::glds16(tb, off, dst);     // EXEC masks the pad chunks
   };
   auto issue_tile = [&](int kt) {
@@ -199,29 +204,29 @@ __global__ __launch_bounds__(NW * 64) void flash_fwd_kernel(AttnArgs a) {
     if (active) {
       // ---- S^T = K . Q^T  (2 key sub-tiles of 32); all K fragment reads ahead of the MFMAs;
       // the copies of tile kt+2 are issued between the MFMAs, whose pipe time hides them ----
-      f32x16 sacc[2];
-      v8 kf[2][KS];
+      f32x16 sacc[KT];
+      v8 kf[KT][KS];
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < KT; ++t)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) kf[t][ks] = *(const v8*)(cK + t * (32 * ROWB) + k_rd[ks]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int t = 0; t < KT; ++t) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) sacc[t][i] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           sacc[t] = Frag<T>::mfma(kf[t][ks], qf[ks], sacc[t]);
           // PPW pieces spread over the 2*KS MFMAs
-          constexpr int every = (2 * KS) / PPW > 0 ? (2 * KS) / PPW : 1;
+          constexpr int every = (KT * KS) / PPW > 0 ? (KT * KS) / PPW : 1;
           const int idx = t * KS + ks;
           if (ahead && idx % every == 0 && idx / every < PPW) issue_piece(kt + 2, idx / every);
         }
       }
       if (ahead) {      // pieces that did not fit the spacing (PPW > 2*KS)
 #pragma unroll
-        for (int i = (2 * KS) / ((2 * KS) / PPW > 0 ? (2 * KS) / PPW : 1); i < PPW; ++i) issue_piece(kt + 2, i);
+        for (int i = (KT * KS) / ((KT * KS) / PPW > 0 ? (KT * KS) / PPW : 1); i < PPW; ++i) issue_piece(kt + 2, i);
       }
       // ---- mask, running max on the raw scores (the scale is positive, so it commutes with
       // max), then p = 2^(s*scale - m) as one FMA + v_exp per score; packed fp32 math ----
@@ -229,7 +234,7 @@ __global__ __launch_bounds__(NW * 64) void flash_fwd_kernel(AttnArgs a) {
       const bool need_mask = (kbase + FA_KB > a.Lk) || (a.causal && kbase + FA_KB - 1 > q0 + shift);
       if (need_mask) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < KT; ++t)
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             const int key = kbase + t * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
@@ -239,7 +244,7 @@ __global__ __launch_bounds__(NW * 64) void flash_fwd_kernel(AttnArgs a) {
       }
       float tmax = -INFINITY;
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < KT; ++t)
 #pragma unroll
         for (int i = 0; i < 16; i += 2) tmax = fmaxf(fmaxf(tmax, sacc[t][i]), sacc[t][i + 1]);
       tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
@@ -250,7 +255,7 @@ __global__ __launch_bounds__(NW * 64) void flash_fwd_kernel(AttnArgs a) {
       const f32x2 sc2 = {a.scale_log2, a.scale_log2}, nm2 = {-m_use, -m_use};
       f32x2 ps2 = {0.f, 0.f};
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < KT; ++t)
 #pragma unroll
         for (int i = 0; i < 16; i += 2) {
           const f32x2 e = __builtin_elementwise_fma(f32x2{sacc[t][i], sacc[t][i + 1]}, sc2, nm2);
@@ -288,8 +293,8 @@ __global__ __launch_bounds__(NW * 64) void flash_fwd_kernel(AttnArgs a) {
         v4 vlo[2][DT], vhi[2][DT];
         read_v(0, vlo[0], vhi[0]);
 #pragma unroll
-        for (int s_ = 0; s_ < 4; ++s_) {
-          if (s_ < 3) read_v(s_ + 1, vlo[(s_ + 1) & 1], vhi[(s_ + 1) & 1]);
+        for (int s_ = 0; s_ < 2 * KT; ++s_) {
+          if (s_ < 2 * KT - 1) read_v(s_ + 1, vlo[(s_ + 1) & 1], vhi[(s_ + 1) & 1]);
           const int t = s_ >> 1, rb = (s_ & 1) * 8;
           v8 pf;
 #pragma unroll
@@ -338,21 +343,22 @@ __global__ __launch_bounds__(NW * 64) void flash_fwd_kernel(AttnArgs a) {
 
 template <typename T, int KS, int DT>
 int launch_fa_d(const AttnArgs& a, int B, hipStream_t st) {
-  constexpr int lds = 2 * 3 * FA_KB * 256;     // K and V rings: 3 stages x 64 rows x 256 B
+  constexpr int KT = FA_KT;
+  constexpr int lds = 2 * 3 * 32 * KT * 256;   // K and V rings: 3 stages x 32 KT rows x 256 B
   hipError_t e;
   if (a.Lq > 128) {
-    e = hipFuncSetAttribute((const void*)flash_fwd_kernel<T, KS, DT, 8>,
+    e = hipFuncSetAttribute((const void*)flash_fwd_kernel<T, KS, DT, 8, KT>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e == hipSuccess) {
       dim3 grid((a.Lq + 255) / 256, a.Hq, B);
-      flash_fwd_kernel<T, KS, DT, 8><<<grid, 512, lds, st>>>(a);
+      flash_fwd_kernel<T, KS, DT, 8, KT><<<grid, 512, lds, st>>>(a);
     }
   } else {
-    e = hipFuncSetAttribute((const void*)flash_fwd_kernel<T, KS, DT, 4>,
+    e = hipFuncSetAttribute((const void*)flash_fwd_kernel<T, KS, DT, 4, KT>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e == hipSuccess) {
       dim3 grid((a.Lq + 127) / 128, a.Hq, B);
-      flash_fwd_kernel<T, KS, DT, 4><<<grid, 256, lds, st>>>(a);
+      flash_fwd_kernel<T, KS, DT, 4, KT><<<grid, 256, lds, st>>>(a);
     }
   }
   if (e != hipSuccess) {
@@ -397,7 +403,7 @@ extern "C" int tv_flash_attn_fwd(const void* q, const void* k, const void* v, vo
   if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15))
     TV_UNSUPPORTED("flash_attn: q/k/v must be 16-byte aligned");
   // the K/V copies address a 64-key tile with 32-bit byte offsets from its first key
-  if (64 * k_stride_l * 2 >= (1ll << 31) || 64 * v_stride_l * 2 >= (1ll << 31))
+  if (128 * k_stride_l * 2 >= (1ll << 31) || 128 * v_stride_l * 2 >= (1ll << 31))
     TV_UNSUPPORTED("flash_attn: k/v row stride too large");
   if (seqlen_q == 0) return TV_OK;
   AttnArgs a;
