@@ -9,8 +9,7 @@ See `oracle/ops.py` for the pinning status.
 """
 from __future__ import annotations
 
-import math
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
 
 import torch

@@ -17,7 +17,6 @@ published algorithm; anchored on the call site :371-380).
 from __future__ import annotations
 
 import math
-from typing import Optional, Tuple
 
 import torch
 import torch.nn.functional as F

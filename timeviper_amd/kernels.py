@@ -18,7 +18,7 @@ eager fallback: tensors must live on the GPU and the HIP library must be built.
 from __future__ import annotations
 
 import math
-from typing import Optional, Tuple
+from typing import Optional
 
 import torch
 

@@ -15,7 +15,7 @@ loads with strict=True; the pooling head is kept for that reason only and never 
 """
 from __future__ import annotations
 
-from typing import Optional, Tuple
+from typing import Optional
 
 import torch
 import torch.nn as nn
