@@ -3,11 +3,12 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--frames T]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one pass of `GenericTimeViperVLM.forward` (ViT over 256-frame clips ->
+One "step" = one pass of `GenericTimeViperVLM.forward` (ViT over 256-frame clips, eight per launch ->
 ToMe+MLP projector -> fusion -> 56-layer Nemotron-Nano-9B-v2 hybrid stack with TransV
 pdrop -> last-token logits) over T frames that are already resident in HBM.  With N > 1
-the frame/token sequence is sharded over the ranks (timeviper_amd.distributed) and the
-total work is fixed ("scaling": "strong").  Rank 0 prints ONE JSON line.
+the frame/token sequence is sharded over the ranks (timeviper_amd.distributed; frame ranges sized so
+that causal attention does not leave the last rank behind) and the total work is fixed
+("scaling": "strong").  Rank 0 prints ONE JSON line.
 
 roofline: the SSD selective-scan kernel — algorithmic bytes (45 312 B per
 token per Mamba layer at Nano dims, bf16) / its launch durations measured live with
