@@ -34,13 +34,19 @@ from . import kernels as K
 
 
 # ------------------------------------------------------------------ collectives
-def all_gather_varlen(t: torch.Tensor, group=None) -> List[torch.Tensor]:
-    """all-gather of tensors that differ in dim 0 (padded to the longest)."""
+def all_gather_varlen(t: torch.Tensor, group=None, lens: Optional[List[int]] = None) -> List[torch.Tensor]:
+    """all-gather of tensors that differ in dim 0 (padded to the longest).  `lens`: every rank's
+    dim-0 length when the caller already knows them on the host (saves the size exchange and its
+    device-to-host synchronisation)."""
     world = dist.get_world_size(group)
-    n = torch.tensor([t.shape[0]], device=t.device, dtype=torch.int64)
-    ns = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(ns, n, group=group)
-    ns = [int(v) for v in ns]
+    if lens is None:
+        n = torch.tensor([t.shape[0]], device=t.device, dtype=torch.int64)
+        ns = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(ns, n, group=group)
+        ns = [int(v) for v in ns]
+    else:
+        ns = [int(v) for v in lens]
+        assert len(ns) == world and ns[dist.get_rank(group)] == t.shape[0], (ns, t.shape)
     mx = max(ns)
     pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     pad[: t.shape[0]] = t
@@ -131,6 +137,7 @@ class SequenceParallelTimeViper:
         the same number from the same shapes), 0 = even frame split."""
         self.vlm, self.rank, self.world, self.group = vlm, rank, world, group
         self.causal_skew = causal_skew
+        self.shard_lens: Optional[List[int]] = None     # host-side shard lengths (set by forward)
         self.llm = vlm.llm_backbone.llm
         if vlm.llm_backbone.llm_family != "nano":
             raise NotImplementedError("sequence parallelism is built for the hybrid Mamba-2 backbone only "
@@ -166,6 +173,17 @@ class SequenceParallelTimeViper:
             bounds.append((s, e))
         return bounds, n_before, n_after
 
+    def _lens(self, mine: int, device) -> List[int]:
+        """Every rank's current shard length.  Inside `forward` they are tracked on the host (layout
+        + the counts `_pdrop` exchanges anyway); a mixer called on its own asks the other ranks."""
+        if self.shard_lens is not None:
+            assert self.shard_lens[self.rank] == mine, (self.shard_lens, mine)
+            return self.shard_lens
+        n = torch.tensor([mine], device=device, dtype=torch.int64)
+        ns = [torch.zeros_like(n) for _ in range(self.world)]
+        dist.all_gather(ns, n, group=self.group)
+        return [int(v) for v in ns]
+
     # ---------------------------------------------------------------- mixers
     def _mamba(self, mixer, normed):
         Bsz, L, _ = normed.shape
@@ -180,16 +198,14 @@ class SequenceParallelTimeViper:
         tail = xBC.new_zeros((Bsz, Kw - 1, xBC.shape[-1]))
         if n_tail:
             tail[:, Kw - 1 - n_tail:] = xBC[:, L - n_tail:]
-        cnt = torch.tensor([n_tail], device=xBC.device, dtype=torch.int64)
         tails = [torch.empty_like(tail) for _ in range(self.world)]
-        cnts = [torch.zeros_like(cnt) for _ in range(self.world)]
         dist.all_gather(tails, tail, group=self.group)
-        dist.all_gather(cnts, cnt, group=self.group)
+        cnts = [min(n, Kw - 1) for n in self._lens(L, xBC.device)]   # host-side inside forward(): no sync
         halo = None
         if self.rank > 0:
             rows, need = [], Kw - 1
             for j in range(self.rank - 1, -1, -1):
-                take = min(int(cnts[j]), need)
+                take = min(cnts[j], need)
                 if take:
                     rows.insert(0, tails[j][:, Kw - 1 - take:])
                     need -= take
@@ -225,8 +241,9 @@ class SequenceParallelTimeViper:
         q = attn.q_proj(normed).view(Bsz, L, attn.num_heads, attn.head_dim)
         k = attn.k_proj(normed).view(L, attn.num_key_value_heads * attn.head_dim)
         v = attn.v_proj(normed).view(L, attn.num_key_value_heads * attn.head_dim)
-        ks = all_gather_varlen(k, self.group)
-        vs = all_gather_varlen(v, self.group)
+        lens = self._lens(L, k.device)
+        ks = all_gather_varlen(k, self.group, lens)
+        vs = all_gather_varlen(v, self.group, lens)
         kf = torch.cat(ks[: self.rank + 1]).view(1, -1, attn.num_key_value_heads, attn.head_dim)
         vf = torch.cat(vs[: self.rank + 1]).view(1, -1, attn.num_key_value_heads, attn.head_dim)
         o = K.flash_attn_func(q, kf, vf, causal=True)      # bottom-right aligned: Lk >= Lq
@@ -308,7 +325,8 @@ class SequenceParallelTimeViper:
         n_new = torch.tensor([new.shape[0]], device=dev, dtype=torch.int64)
         ns = [torch.zeros_like(n_new) for _ in range(self.world)]
         dist.all_gather(ns, n_new, group=self.group)
-        new_start = int(sum(int(v) for v in ns[: self.rank]))
+        self.shard_lens = [int(v) for v in ns]                 # every rank's new shard length
+        new_start = sum(self.shard_lens[: self.rank])
         return new.unsqueeze(0), new_start, top
 
     # ---------------------------------------------------------------- forward
@@ -323,6 +341,7 @@ class SequenceParallelTimeViper:
         tpf = vis.shape[1]
         bounds, n_before, n_after = self.shard_layout(input_ids, n_frames, tpf)
         start, end = bounds[self.rank]
+        self.shard_lens = [e - s0 for s0, e in bounds]         # host-side shard lengths, kept current by _pdrop
         embed = vlm.llm_backbone.embed_input_ids
         parts = []
         if self.rank == 0 and n_before:
@@ -358,4 +377,5 @@ class SequenceParallelTimeViper:
         if self.rank == self.world - 1:
             logits = self.llm.lm_head(hidden[:, -1:]).float()
         dist.broadcast(logits, src=self.world - 1, group=self.group)
+        self.shard_lens = None
         return logits
