@@ -23,7 +23,7 @@ def test_library_builds_and_exports_header_symbols():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/timeviper_hip.h but not exported"
     assert set(_capi.SIGNATURES) == set(syms)
-    assert lib.tv_abi_version() == 3
+    assert lib.tv_abi_version() == _capi.ABI_VERSION == 3
 
 
 def test_bad_arguments_fail_loudly_without_gpu():

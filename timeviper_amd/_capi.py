@@ -54,6 +54,9 @@ class TimeViperHipError(RuntimeError):
     pass
 
 
+ABI_VERSION = 3      # tv_abi_version() of the library these SIGNATURES describe (csrc/capi.cpp)
+
+
 def lib_path() -> Path:
     return Path(os.environ.get("TIMEVIPER_HIP_LIB", str(_LIB_PATH)))
 
@@ -73,6 +76,9 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)  # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
+        if handle.tv_abi_version() != ABI_VERSION:
+            raise TimeViperHipError(f"{path} has ABI version {handle.tv_abi_version()}, this package binds "
+                                    f"version {ABI_VERSION}: rebuild it (`python -m timeviper_amd.build --force`)")
         _lib = handle
     return _lib
 
