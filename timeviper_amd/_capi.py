@@ -71,6 +71,10 @@ def lib() -> C.CDLL:
                 f"{path} not found: the HIP extension has not been built. "
                 "Run `python -m timeviper_amd.build` (or __graft_entry__.build())."
             )
+        # torch first: it ships its own HIP runtime, and the one that is mapped first serves the
+        # whole process — loading this library before torch binds it to /opt/rocm's copy and leaves
+        # the two runtimes disagreeing about the devices ("no ROCm-capable device is detected")
+        import torch  # noqa: F401
         handle = C.CDLL(str(path))
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the symbol is missing
