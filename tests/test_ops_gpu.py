@@ -282,6 +282,8 @@ def test_selective_state_update(K):
     (1, 1, 77, 8, 2, 128, True),         # decode-like single query
     (1, 300, 300, 4, 2, 80, True),
     (1, 130, 130, 4, 2, 96, False),
+    (5, 300, 300, 13, 13, 72, False),    # 65 (batch, head) pairs: the XCD-ordered 1-D grid, padded to 72
+    (9, 700, 200, 8, 4, 64, False),      # same path, 3 query blocks, GQA, Lk < Lq
 ])
 def test_flash_attention(K, dtype, B, Lq, Lk, Hq, Hkv, D, causal):
     g = torch.Generator().manual_seed(Lq * 3 + Lk + D)

@@ -57,6 +57,7 @@ struct AttnArgs {
   int64_t qsb, qsl, qsh, ksb, ksl, ksh, vsb, vsl, vsh, osb, osl, osh;
   float scale_log2;  // softmax_scale * log2(e)
   int causal;
+  int nqb, nb;       // nqb > 0: 1-D XCD-aware grid, nqb query blocks per (batch, head), nb batches; 0: 3-D grid
 };
 
 // KS = ceil(D/16) k-steps of QK^T, DT = ceil(D/32) d-tiles of PV, NW waves per workgroup.
@@ -87,8 +88,22 @@ __global__ __launch_bounds__(NW * 64) void flash_fwd_kernel(AttnArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int r = lane & 31, hh = lane >> 5;
   // causal: launch the heaviest (last) query blocks first
-  const int qblk = a.causal ? (gridDim.x - 1 - blockIdx.x) : blockIdx.x;
-  const int h = blockIdx.y, b = blockIdx.z;
+  // 3-D grid (causal: heaviest query blocks first), or — many short sequences (ViT frames) — a 1-D
+  // grid whose ids walk the query blocks of ONE (batch, head) on one XCD (id % 8): the blocks that
+  // share K / V then share an L2 instead of pulling the same keys into three of them
+  int qblk, h, b;
+  if (a.nqb > 0) {
+    const int slot = blockIdx.x >> 3;
+    const int pair = (slot / a.nqb) * 8 + (blockIdx.x & 7);
+    qblk = slot % a.nqb;
+    h = pair % a.Hq;
+    b = pair / a.Hq;
+    if (b >= a.nb) return;                    // (batch, head) pairs are padded to a multiple of 8
+  } else {
+    qblk = a.causal ? (gridDim.x - 1 - blockIdx.x) : blockIdx.x;
+    h = blockIdx.y;
+    b = blockIdx.z;
+  }
   const int hk = h / (a.Hq / a.Hkv);
   const int q0 = qblk * QB + wave * FA_QW;      // first query row of this wave
   const int qrow = q0 + r;                      // this lane's query row
@@ -350,8 +365,18 @@ int launch_fa_d(const AttnArgs& a, int B, hipStream_t st) {
     e = hipFuncSetAttribute((const void*)flash_fwd_kernel<T, KS, DT, 8, KT>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e == hipSuccess) {
-      dim3 grid((a.Lq + 255) / 256, a.Hq, B);
-      flash_fwd_kernel<T, KS, DT, 8, KT><<<grid, 512, lds, st>>>(a);
+      const int nqb = (a.Lq + 255) / 256;
+      static const int xcd_ = [] { const char* v = getenv("TV_FA_XCD"); return v ? atoi(v) : 1; }();
+      if (xcd_ && !a.causal && nqb <= 8 && (int64_t)B * a.Hq >= 64) {
+        AttnArgs ax = a;
+        ax.nqb = nqb;
+        ax.nb = B;
+        const int64_t pairs = ((int64_t)B * a.Hq + 7) / 8 * 8;
+        flash_fwd_kernel<T, KS, DT, 8, KT><<<dim3((unsigned)(pairs * nqb), 1, 1), 512, lds, st>>>(ax);
+      } else {
+        dim3 grid(nqb, a.Hq, B);
+        flash_fwd_kernel<T, KS, DT, 8, KT><<<grid, 512, lds, st>>>(a);
+      }
     }
   } else {
     e = hipFuncSetAttribute((const void*)flash_fwd_kernel<T, KS, DT, 4, KT>,
@@ -415,6 +440,8 @@ extern "C" int tv_flash_attn_fwd(const void* q, const void* k, const void* v, vo
   a.osb = o_stride_b; a.osl = o_stride_l; a.osh = o_stride_h;
   a.scale_log2 = softmax_scale * 1.4426950408889634f;
   a.causal = causal;
+  a.nqb = 0;
+  a.nb = batch;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == TV_BF16) return launch_fa<bf16_t>(a, batch, st);
   return launch_fa<f16_t>(a, batch, st);
