@@ -144,7 +144,9 @@ def causal_conv1d_update_ref(x_bc, conv_state, weight, bias=None, activation="si
 def rmsnorm_gated_ref(x, weight, z=None, eps=1e-5, group_size=None):
     """mamba_ssm rmsnorm_fn(..., norm_before_gate=False) as called at :371-380.
     PARITY UNPINNED (third-party mamba_ssm==2.2.5, not in the reference tree):
-    u = x*silu(z); per group: u * rsqrt(mean(u^2)+eps) * w, fp32."""
+    u = x*silu(z); per group: u * rsqrt(mean(u^2)+eps) * w, fp32.  The only in-tree statement of
+    the semantics is the docstring of visualize/nano/my_ssd_combined.py:1975, :2032 ("If False, we
+    do RMSNorm(x * F.silu(z))") and the group_size = dim // ngroups convention of its call :1678-1688."""
     u = x.float()
     if z is not None:
         u = u * F.silu(z.float())
