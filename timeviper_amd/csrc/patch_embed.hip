@@ -147,7 +147,8 @@ __global__ __launch_bounds__(PE_THREADS) void patch_embed_kernel(PeArgs a) {
     for (int j = 0; j < PE_IT; ++j) {
       const int rl = srl0 + j * (PE_THREADS / PE_TM);
       const int row = row0 + rl;
-      const int c = row / a.p, dy = row - c * a.p;
+      const int pp = HP > 0 ? 2 * HP : a.p;          // compile-time divisor on the common paths
+      const int c = row / pp, dy = row - c * pp;
       const bool row_ok = row < rows_total;
       prow[j] = load_row(pbase + (int64_t)c * a.chan_stride + (int64_t)dy * a.W, m_ok && row_ok);
       if (!PACKED) wrow[j] = load_row(wbase + (int64_t)row * a.p, n_ok && row_ok);
