@@ -94,7 +94,9 @@ __global__ __launch_bounds__(NW * 64) void flash_fwd_kernel(AttnArgs a) {
   int qblk, h, b;
   if (a.nqb > 0) {
     const int slot = blockIdx.x >> 3;
-    const int pair = (slot / a.nqb) * 8 + (blockIdx.x & 7);
+    // an XCD owns a contiguous range of (batch, head) pairs: neighbouring heads of a frame interleave
+    // in memory (head_dim 72 = 144-byte rows inside 128-byte lines), so their shared lines hit one L2
+    const int pair = (blockIdx.x & 7) * (int)(gridDim.x / (8 * a.nqb)) + slot / a.nqb;
     qblk = slot % a.nqb;
     h = pair % a.Hq;
     b = pair / a.Hq;
