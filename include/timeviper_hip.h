@@ -43,6 +43,10 @@ typedef enum {
 int tv_abi_version(void);
 /* Human readable string of the last error on this thread (never NULL). */
 const char* tv_last_error(void);
+/* Hash of the sources (csrc/, include/, compiler flags) this binary was built from; the Python
+ * binding compares it with the hash of the tree it runs from, so that a kernel edit is never
+ * tested or benchmarked through a stale library (timeviper_amd/build.py source_id()). */
+const char* tv_build_id(void);
 
 /* ------------------------------------------------------------------------
  * S2  causal depthwise conv1d (+bias, +SiLU), channels-last.

@@ -100,6 +100,32 @@ def _dropped(keep_sorted, start, n):
     return allidx[~torch.isin(allidx, keep_sorted)]
 
 
+def _conv_update(x, conv_state, weight, bias=None, activation=None):
+    y, new = R.causal_conv1d_update_ref(x, conv_state, weight.reshape(x.shape[1], -1), bias, activation)
+    conv_state.copy_(new.to(conv_state.dtype))
+    return y.to(x.dtype)
+
+
+def _state_update(state, x, dt, A, B, C, D=None, z=None, dt_bias=None, dt_softplus=False):
+    """one token of the recurrence (modeling_nano.py:528-539 with per-head A / dt / D)"""
+    Bsz, H, P = x.shape
+    G = B.shape[1]
+    head = lambda t, nd: None if t is None else (t if t.dim() == nd else t[(..., *([0] * (t.dim() - nd)))]).float()
+    A1, D1, b1 = head(A, 1), head(D, 1), head(dt_bias, 1)
+    d = (dt if dt.dim() == 2 else dt[..., 0]).float()
+    if b1 is not None:
+        d = d + b1
+    if dt_softplus:
+        d = torch.nn.functional.softplus(d)
+    Bh = B.float().repeat_interleave(H // G, dim=1)
+    Ch = C.float().repeat_interleave(H // G, dim=1)
+    state.mul_(torch.exp(d * A1)[..., None, None]).add_((d[..., None] * x.float())[..., None] * Bh[:, :, None, :])
+    y = torch.einsum("bhpn,bhn->bhp", state, Ch)
+    if D1 is not None:
+        y = y + D1[None, :, None] * x.float()
+    return y.to(x.dtype)
+
+
 @contextlib.contextmanager
 def cpu_kernels():
     from timeviper_amd import kernels as K
@@ -119,6 +145,7 @@ def cpu_kernels():
         "silu_mul": lambda g, u: torch.nn.functional.silu(g) * u,
         "tome_merge_round": RV.tome_merge_round_ref,
         "relu2": lambda x, inplace=False: torch.square(torch.relu(x)),
+        "causal_conv1d_update": _conv_update, "selective_state_update": _state_update,
     }
     saved = {k: getattr(K, k) for k in patches}
     for k, v in patches.items():

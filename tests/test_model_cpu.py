@@ -206,3 +206,79 @@ def test_multivit_registry_and_contract():
     assert vb.backbone_ids == ["dinov2-vit-l", "internvideo2-1b-16-224px"]
     assert list(vb.backbones.keys()) == ["dinov2_vit_l", "internvideo2_1b_16_224px"]
     assert vb.backbones["dinov2_vit_l"].embed_dim == 1024 and vb.backbones["internvideo2_1b_16_224px"].embed_dim == 64
+
+
+def test_evaluate_py_call_sequence_on_a_saved_checkpoint(tmp_path):
+    """The outer drop-in surface as `evaluate.py` drives it (reference evaluate.py:183-214 build_model,
+    :507-530 generate -> extract_answer): factories -> `HybridTimeViperVLM.from_pretrained(checkpoint,
+    ...)` with `strict=True` loading -> `model.generate(input_ids, pixel_values=..., pixel_values_videos=...,
+    attention_mask=..., max_new_tokens=..., use_cache=True, do_sample=False, temperature=0,
+    answer_prompt=...)` returning the decoded, prompt-stripped TEXT (generic_vlm.py:743-760).  Kernels
+    are the oracle-backed shims (no GPU here): this is the host logic above the C ABI."""
+    from cpu_kernel_shim import cpu_kernels
+    from timeviper_amd.model import (HybridTimeViperVLM, get_llm_backbone_and_tokenizer)
+    from timeviper_amd.model.llm import NemotronHConfig
+    from timeviper_amd.model.vit import TimmViTBackbone
+
+    def backbones():
+        cfg = NemotronHConfig(vocab_size=128, hidden_size=64, intermediate_size=96, num_hidden_layers=8,
+                              hybrid_override_pattern="M-M*M-*M", num_attention_heads=4, head_dim=16,
+                              num_key_value_heads=2, ssm_state_size=16, mamba_num_heads=8,
+                              mamba_n_groups=2, mamba_head_dim=8, mamba_chunk_size=16)
+        vb = TimmViTBackbone("siglip-vit-b16-224px", depth_override=2, default_image_size=96)
+        llm, tokenizer = get_llm_backbone_and_tokenizer(
+            "nanov2-9b", llm_max_length=None, attn_implementation="flash_attention_2",
+            merge_module="CrossAttention", use_pdrop=True, pdrop_type="uni_2_0.75-attn_3_0.5", config=cfg)
+        return vb, llm, tokenizer
+
+    # a "pretrained checkpoint": the state dict of a randomly initialised model, as torch.save writes it
+    torch.manual_seed(3)
+    vb, llm, _ = backbones()
+    src = HybridTimeViperVLM("src", vb, llm, arch_specifier="tome_mlp-16")
+    ckpt = tmp_path / "timeviper.pt"
+    torch.save(src.state_dict(), ckpt)
+
+    torch.manual_seed(4)                       # a different init: only the checkpoint can make them agree
+    vb, llm, tokenizer = backbones()
+    model = HybridTimeViperVLM.from_pretrained(pretrained_checkpoint=ckpt, model_id="cobra-siglip+3b",
+                                               vision_backbone=vb, llm_backbone=llm,
+                                               arch_specifier="tome_mlp-16", visual_token_order="raw")
+    assert not model.training and all(not p.requires_grad for p in model.parameters())
+    assert next(model.parameters()).dtype == torch.bfloat16
+    for (k, a), (_, b) in zip(sorted(src.state_dict().items()), sorted(model.state_dict().items())):
+        assert torch.equal(a.to(torch.bfloat16), b), k
+    # a checkpoint with a missing / unexpected key must be refused (strict=True, :896-899)
+    bad = dict(src.state_dict())
+    bad.pop(next(iter(bad)))
+    torch.save(bad, tmp_path / "bad.pt")
+    vb2, llm2, _ = backbones()
+    with pytest.raises(RuntimeError):
+        HybridTimeViperVLM.from_pretrained(tmp_path / "bad.pt", "m", vb2, llm2, arch_specifier="tome_mlp-16")
+
+    # attributes evaluate.py / vllm_infer.py read (SURVEY 8b)
+    assert model.llm_tokenizer is tokenizer and model.config is model.llm_backbone.llm.config
+    assert model.arch_specifier == "tome_mlp-16" and model.llm_backbone.half_precision_dtype == torch.bfloat16
+    T, tok = 4, model.default_token_id
+    batch_itm = {"input_ids": torch.tensor([[5, 6] + [tok] * T + [7, 8, 9]]),
+                 "pixel_values": None,
+                 "pixel_values_videos": torch.randn(T, 3, 96, 96).to(torch.bfloat16),
+                 "attention_mask": torch.ones(1, T + 5, dtype=torch.long)}
+    with cpu_kernels():
+        kw = dict(pixel_values=batch_itm["pixel_values"], pixel_values_videos=batch_itm["pixel_values_videos"],
+                  attention_mask=batch_itm["attention_mask"], max_new_tokens=5, use_cache=True,
+                  do_sample=False, temperature=0)
+        text = model.generate(batch_itm["input_ids"], answer_prompt="Best Options: (", **kw)
+        ids = model.generate(batch_itm["input_ids"], answer_prompt="Best Options: (", return_ids=True, **kw)
+        text_plain = model.generate(batch_itm["input_ids"], answer_prompt=None, **kw)
+        # the prefill behind it: prompt + tokenised answer prompt, greedy first token
+        ap = tokenizer("Best Options: (", add_special_tokens=False, return_tensors="pt").input_ids
+        out = model(input_ids=torch.cat([batch_itm["input_ids"], ap], dim=1),
+                    pixel_values_videos=batch_itm["pixel_values_videos"])
+    assert isinstance(text, str) and isinstance(text_plain, str)
+    assert text == tokenizer.decode(ids[0], skip_special_tokens=False).strip()
+    assert 1 <= ids.shape[1] <= 5 and int(ids[0, 0]) == int(out.logits[0, -1].argmax())
+    assert f"<{tok}>" not in text                      # the prompt (and its <image> run) is stripped
+    # padded batches are refused loudly rather than mis-decoded
+    with cpu_kernels(), pytest.raises(NotImplementedError):
+        model.generate(batch_itm["input_ids"], pixel_values_videos=batch_itm["pixel_values_videos"],
+                       attention_mask=torch.tensor([[0] + [1] * (T + 4)]), max_new_tokens=1)

@@ -258,7 +258,9 @@ def test_vlm_end_to_end_tiny():
     # same token selection -> logits comparable at bf16 tolerance
     ref = om.causal_lm_ref(sd, ocfg, fused, pa, last_only=True, forced_kept=trace)
     assert relerr(out.logits, ref) < 8e-2
-    gen = vlm.generate(input_ids=ids, pixel_values_videos=pix, max_new_tokens=4)
+    gen = vlm.generate(ids, pixel_values_videos=pix, max_new_tokens=4, return_ids=True)
+    txt = vlm.generate(ids, pixel_values_videos=pix, max_new_tokens=4)      # reference contract: decoded text
+    assert isinstance(txt, str) and txt == vlm.llm_tokenizer.decode(gen[0]).strip()
     assert gen.shape[0] == 1 and 1 <= gen.shape[1] <= 4
     assert int(gen[0, 0]) == int(out.logits[0, -1].argmax())
 
@@ -321,7 +323,9 @@ def test_vlm_with_qwen2_backbone_vs_oracle_and_generate():
                 rope_theta=10000.0, rms_norm_eps=cfg.rms_norm_eps, pdrop_type=pd, merge_module="CrossAttention")
     ref = oq.causal_lm_ref(sd, ocfg, inputs_embeds=fused, pdrop_args=pa)
     assert relerr(out.logits[:, -1], ref[:, -1]) < 3e-2
-    gen = vlm.generate(input_ids=ids, pixel_values_videos=pix, max_new_tokens=4)
+    gen = vlm.generate(ids, pixel_values_videos=pix, max_new_tokens=4, return_ids=True)
+    txt = vlm.generate(ids, pixel_values_videos=pix, max_new_tokens=4)      # reference contract: decoded text
+    assert isinstance(txt, str) and txt == vlm.llm_tokenizer.decode(gen[0]).strip()
     assert gen.shape[0] == 1 and 1 <= gen.shape[1] <= 4
     assert int(gen[0, 0]) == int(out.logits[0, -1].argmax())
 

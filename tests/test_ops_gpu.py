@@ -505,6 +505,20 @@ def test_layernorm_and_gelu(K, dtype):
         close(K.gelu(r.to(DEV)), torch.nn.functional.gelu(r.float()), *TOL[dtype])
 
 
+@pytest.mark.parametrize("D", [1152, 4480])     # wave-per-row kernel / block-per-row kernel
+def test_layernorm_large_mean_small_std(K, D):
+    """Rows with |mean| >> std: E[x^2] - mean^2 would lose the variance to cancellation (fp32:
+    50^2 = 2500 against 0.0025); the kernels take the sum of squared deviations in a second
+    register pass, like torch's LayerNorm."""
+    g = torch.Generator().manual_seed(77)
+    x = 50.0 + 0.05 * torch.randn(19, D, generator=g)
+    w = 1 + 0.1 * torch.randn(D, generator=g)
+    b = 0.1 * torch.randn(D, generator=g)
+    ref = torch.nn.functional.layer_norm(x.double(), (D,), w.double(), b.double(), 1e-6)
+    y = K.layer_norm(x.to(DEV), w.to(DEV), b.to(DEV), 1e-6)
+    close(y, ref, 2e-3, 2e-3, "layernorm, mean 50 / std 0.05")
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_relu2(K, dtype):
     """bit-exact: square(relu(x)) has one rounding in the reference's dtype (modeling_nano.py:993)"""

@@ -22,6 +22,7 @@ _p, _i, _l, _f, _z = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 SIGNATURES = {
     "tv_abi_version": (_i, []),
     "tv_last_error": (C.c_char_p, []),
+    "tv_build_id": (C.c_char_p, []),
     "tv_causal_conv1d_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _l, _l, _l, _l, _i, _i, _p]),
     "tv_causal_conv1d_xbc_fwd": (_i, [_p] * 7 + [_i] * 6 + [_l, _l, _i, _i, _p]),
     "tv_causal_conv1d_update": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
@@ -83,6 +84,12 @@ def lib() -> C.CDLL:
         if handle.tv_abi_version() != ABI_VERSION:
             raise TimeViperHipError(f"{path} has ABI version {handle.tv_abi_version()}, this package binds "
                                     f"version {ABI_VERSION}: rebuild it (`python -m timeviper_amd.build --force`)")
+        if "TIMEVIPER_HIP_LIB" not in os.environ:     # the in-tree library must match the in-tree sources
+            from .build import source_id
+            have, want = handle.tv_build_id().decode(), source_id()
+            if have != want:
+                raise TimeViperHipError(f"{path} was built from other sources (build id {have}, tree {want}): "
+                                        "run `python -m timeviper_amd.build` (ensure_built() does it)")
         _lib = handle
     return _lib
 

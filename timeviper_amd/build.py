@@ -1,13 +1,17 @@
 """Build libtimeviper_hip.so (gfx950) from timeviper_amd/csrc with plain hipcc.
 
 The library is a C-ABI shared object (include/timeviper_hip.h); it does not link
-against torch.  Objects are cached by source mtime so rebuilds take seconds.
+against torch.  Objects are cached by CONTENT: every object carries a sidecar with the
+hash of its source, the shared headers and the compiler flags, and the library embeds the
+hash of the whole source set (`tv_build_id()`), so a kernel edit can never be benchmarked
+through a stale binary — not even on a box whose file mtimes were reset by a copy.
 
     python -m timeviper_amd.build [--force] [--jobs N]
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import os
 import subprocess
 import sys
@@ -18,6 +22,7 @@ ROOT = Path(__file__).resolve().parent
 CSRC = ROOT / "csrc"
 OBJ = ROOT / "lib" / "obj"
 LIB = ROOT / "lib" / "libtimeviper_hip.so"
+LIB_ID = ROOT / "lib" / "libtimeviper_hip.id"
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off",
@@ -35,43 +40,66 @@ def _sources():
     return sorted(list(CSRC.glob("*.hip")) + list(CSRC.glob("*.cpp")))
 
 
-def _deps_mtime():
-    hdrs = list(CSRC.glob("*.hpp")) + list((ROOT.parent / "include").glob("*.h"))
-    return max(h.stat().st_mtime for h in hdrs)
+def _headers():
+    return sorted(list(CSRC.glob("*.hpp")) + list((ROOT.parent / "include").glob("*.h")))
 
 
-def _compile(src: Path, force: bool) -> Path:
+def _hash(paths, extra: str = "") -> str:
+    h = hashlib.sha256(extra.encode())
+    for p in paths:
+        h.update(p.name.encode())
+        h.update(p.read_bytes())
+    return h.hexdigest()[:16]
+
+
+def source_id() -> str:
+    """Hash of every source, header and compiler flag the library is built from."""
+    return _hash(_sources() + _headers(), " ".join(FLAGS))
+
+
+def _compile(src: Path, force: bool, build_id: str) -> Path:
     obj = OBJ / (src.name + ".o")
-    newest = max(src.stat().st_mtime, _deps_mtime())
-    if not force and obj.exists() and obj.stat().st_mtime >= newest:
+    tag = OBJ / (src.name + ".hash")
+    flags = list(FLAGS)
+    if src.name == "capi.cpp":                    # the one translation unit that carries the id
+        flags.append(f'-DTV_BUILD_ID="{build_id}"')
+    want = _hash([src] + _headers(), " ".join(flags))
+    if not force and obj.exists() and tag.exists() and tag.read_text() == want:
         return obj
-    cmd = [HIPCC, *FLAGS, "-x", "hip", "-c", str(src), "-o", str(obj)]
+    cmd = [HIPCC, *flags, "-x", "hip", "-c", str(src), "-o", str(obj)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src.name}:\n{r.stdout}\n{r.stderr}")
     if r.stderr.strip():
         sys.stderr.write(r.stderr)
+    tag.write_text(want)
     return obj
 
 
 def build(force: bool = False, jobs: int = 4) -> Path:
     OBJ.mkdir(parents=True, exist_ok=True)
     srcs = _sources()
+    bid = source_id()
     with ThreadPoolExecutor(max_workers=jobs) as ex:
-        objs = list(ex.map(lambda s: _compile(s, force), srcs))
-    if force or not LIB.exists() or any(o.stat().st_mtime > LIB.stat().st_mtime for o in objs):
+        objs = list(ex.map(lambda s: _compile(s, force, bid), srcs))
+    if force or not LIB.exists() or not LIB_ID.exists() or LIB_ID.read_text() != bid:
         cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", str(LIB), *map(str, objs)]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        LIB_ID.write_text(bid)
     return LIB
 
 
 def ensure_built() -> Path:
-    """Compile the library if the tree does not carry it (a checkout without build artefacts);
-    a no-op when `lib/libtimeviper_hip.so` exists.  This is a BUILD step, not a fallback: without a
-    working hipcc it raises, and the operators keep failing loudly."""
-    return LIB if LIB.exists() else build()
+    """Make `lib/libtimeviper_hip.so` match the sources in the tree: a no-op when the library's
+    recorded build id equals the hash of csrc/ + include/ (+ flags), else an incremental rebuild.
+    This is a BUILD step, not a fallback: without a working hipcc it raises, and the operators
+    keep failing loudly.  (`_capi.lib()` checks `tv_build_id()` of the loaded library against the
+    same hash, so a stale binary cannot be used silently either.)"""
+    if LIB.exists() and LIB_ID.exists() and LIB_ID.read_text() == source_id():
+        return LIB
+    return build()
 
 
 if __name__ == "__main__":

@@ -14,3 +14,8 @@ void tv_set_error(const char* fmt, ...) {
 
 extern "C" int tv_abi_version(void) { return 3; }
 extern "C" const char* tv_last_error(void) { return g_err; }
+#ifndef TV_BUILD_ID
+#define TV_BUILD_ID "unknown"
+#endif
+// hash of the sources this library was built from (timeviper_amd/build.py source_id())
+extern "C" const char* tv_build_id(void) { return TV_BUILD_ID; }

@@ -127,18 +127,33 @@ __global__ __launch_bounds__(NORM_THREADS) void layernorm_kernel(
         for (int i = 0; i < V; ++i) vals[k][i] = to_f32(v[i]);
       }
 #pragma unroll
-      for (int i = 0; i < V; ++i) { s1 += vals[k][i]; s2 = fmaf(vals[k][i], vals[k][i], s2); }
+      for (int i = 0; i < V; ++i) s1 += vals[k][i];
     }
   }
+  // two passes over the registers (mean, then sum of squared deviations), like torch's
+  // LayerNorm: E[x^2] - mean^2 loses the variance of rows with |mean| >> std to cancellation
   s1 = wave_sum(s1);
-  s2 = wave_sum(s2);
-  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; }
+  if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = s1;
   __syncthreads();
-  float t1 = 0.f, t2 = 0.f;
+  float t1 = 0.f;
 #pragma unroll
-  for (int i = 0; i < NORM_THREADS / 64; ++i) { t1 += red[0][i]; t2 += red[1][i]; }
+  for (int i = 0; i < NORM_THREADS / 64; ++i) t1 += red[0][i];
   const float mean = t1 / (float)D;
-  const float var = fmaxf(t2 / (float)D - mean * mean, 0.f);
+#pragma unroll
+  for (int k = 0; k < NORM_MAXV; ++k) {
+    const int iv = threadIdx.x + k * NORM_THREADS;
+    if (iv < nv) {
+#pragma unroll
+      for (int i = 0; i < V; ++i) { const float d = vals[k][i] - mean; s2 = fmaf(d, d, s2); }
+    }
+  }
+  s2 = wave_sum(s2);
+  if ((threadIdx.x & 63) == 0) red[1][threadIdx.x >> 6] = s2;
+  __syncthreads();
+  float t2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NORM_THREADS / 64; ++i) t2 += red[1][i];
+  const float var = t2 / (float)D;
   const float rstd = rsqrtf(var + eps);
 #pragma unroll
   for (int k = 0; k < NORM_MAXV; ++k) {
@@ -199,13 +214,22 @@ __global__ __launch_bounds__(NORM_THREADS) void layernorm_wave_kernel(
         for (int i = 0; i < V; ++i) vals[k][i] = to_f32(xv[k][i]);
       }
 #pragma unroll
-      for (int i = 0; i < V; ++i) { s1 += vals[k][i]; s2 = fmaf(vals[k][i], vals[k][i], s2); }
+      for (int i = 0; i < V; ++i) s1 += vals[k][i];
     }
   }
   s1 = wave_sum(s1);
-  s2 = wave_sum(s2);
   const float mean = s1 / (float)D;
-  const float var = fmaxf(s2 / (float)D - mean * mean, 0.f);
+  // second register pass: sum of squared deviations (no E[x^2] - mean^2 cancellation)
+#pragma unroll
+  for (int k = 0; k < NORM_MAXV; ++k) {
+    const int iv = lane + k * 64;
+    if (iv < nv) {
+#pragma unroll
+      for (int i = 0; i < V; ++i) { const float d = vals[k][i] - mean; s2 = fmaf(d, d, s2); }
+    }
+  }
+  s2 = wave_sum(s2);
+  const float var = s2 / (float)D;
   const float rstd = rsqrtf(var + eps);
 #pragma unroll
   for (int k = 0; k < NORM_MAXV; ++k) {

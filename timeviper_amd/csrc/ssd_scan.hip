@@ -1,6 +1,7 @@
 // S3 dispatcher: tv_ssd_scan_fwd picks an MFMA march kernel (bf16, d_state 128,
 // MFMA-tileable head_dim: the slice march when a workspace is supplied, else the chunk
 // march) or the generic fp32 recurrence kernel.
+#include <atomic>
 #include "common.hpp"
 
 int tv_ssd_generic_launch(const void* x, const void* dt, const void* A, const void* Bm,
@@ -43,10 +44,11 @@ int tv_ssd_slice_launch(const void* x, const void* dt, const void* A, const void
                         void* workspace, size_t workspace_bytes, hipStream_t st);
 
 // 0 auto, 1 generic recurrence, 2 chunk march (ssd_march.hip), 3 slice march (ssd_slice.hip)
-static int g_ssd_impl = 0;
+// process-wide override for tests / dev tools; atomic so that concurrent callers never race on it
+static std::atomic<int> g_ssd_impl{0};
 static const int kAutoImpl = 3;   // slice march; falls back to the chunk march / generic kernel
 
-extern "C" void tv_ssd_scan_set_impl(int impl) { g_ssd_impl = impl; }
+extern "C" void tv_ssd_scan_set_impl(int impl) { g_ssd_impl.store(impl, std::memory_order_relaxed); }
 
 extern "C" size_t tv_ssd_scan_workspace_bytes(int batch, int seqlen, int nheads, int headdim,
                                               int ngroups, int dstate, int dtype) {
@@ -82,13 +84,14 @@ extern "C" int tv_ssd_scan_fwd(const void* x, const void* dt, const void* A, con
     if (total_decay) (void)hipMemsetAsync(total_decay, 0, (size_t)batch * nheads * sizeof(float), st);
     return TV_OK;
   }
-  bool march = g_ssd_impl != 1 && dt_stride_l % 2 == 0 && dt_stride_b % 2 == 0 &&
+  const int forced = g_ssd_impl.load(std::memory_order_relaxed);   // one read per call
+  bool march = forced != 1 && dt_stride_l % 2 == 0 && dt_stride_b % 2 == 0 &&
                (((uintptr_t)dt) & 3) == 0 &&
                tv_ssd_march_supported(seqlen, nheads, headdim, ngroups, dstate, dtype, x_stride_l,
                                       b_stride_l, b_stride_g, c_stride_l, c_stride_g, y_stride_l, x, Bm, Cm, y);
-  if (g_ssd_impl >= 2 && !march)
+  if (forced >= 2 && !march)
     TV_UNSUPPORTED("ssd_scan: MFMA march kernel forced but shape/dtype unsupported");
-  const int impl = g_ssd_impl ? g_ssd_impl : kAutoImpl;
+  const int impl = forced ? forced : kAutoImpl;
   if (march && impl == 3 && workspace &&
       tv_ssd_slice_supported(seqlen, nheads, headdim, ngroups, dstate, dtype, x_stride_l,
                              b_stride_l, b_stride_g, c_stride_l, c_stride_g, y_stride_l, x, Bm, Cm, y)) {

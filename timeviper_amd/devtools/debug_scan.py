@@ -1,7 +1,7 @@
 import sys, math
 from pathlib import Path
 import torch
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 from timeviper_amd import kernels as K
 from oracle import ops as R
 torch.manual_seed(0)

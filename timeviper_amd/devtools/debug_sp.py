@@ -3,7 +3,9 @@ import os, sys
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+from pathlib import Path
+_ROOT = Path(__file__).resolve().parent.parent.parent
+sys.path.insert(0, str(_ROOT)); sys.path.insert(0, str(_ROOT / "tests"))
 from test_distributed_cpu import free_port
 from test_distributed_gpu import stage_collectives_through_host
 

@@ -131,6 +131,11 @@ def estimate_causal_skew(vlm, tokens_per_frame: int) -> float:
     return (attn_pair / _ATTN_RATE) / (flops_lin / _LINEAR_RATE)
 
 
+def _global_rank(group, group_rank: int) -> int:
+    """torch's broadcast `src` is a GLOBAL rank; a rank index inside `group` must be translated."""
+    return group_rank if group is None else dist.get_global_rank(group, group_rank)
+
+
 class SequenceParallelTimeViper:
     def __init__(self, vlm, rank: int, world: int, group=None, causal_skew: Optional[float] = None):
         """`causal_skew`: see `split_frames`; None = estimate it from the model (every rank computes
@@ -269,7 +274,7 @@ class SequenceParallelTimeViper:
             q_row = torch.empty((sa.num_heads, sa.head_dim), dtype=feats.dtype, device=dev)
             if self.rank == self.world - 1:
                 q_row = sa.q_proj(feats[row - start: row - start + 1]).view(sa.num_heads, sa.head_dim).contiguous()
-            dist.broadcast(q_row, src=self.world - 1, group=self.group)
+            dist.broadcast(q_row, src=_global_rank(self.group, self.world - 1), group=self.group)
             n_local = max(0, min(L, row + 1 - start))             # local keys that take part
             k_loc = sa.k_proj(feats[:n_local]).view(n_local, sa.num_key_value_heads, sa.head_dim)
             rep = sa.num_heads // sa.num_key_value_heads
@@ -376,6 +381,6 @@ class SequenceParallelTimeViper:
         logits = torch.empty((1, 1, self.cfg.vocab_size), dtype=torch.float32, device=hidden.device)
         if self.rank == self.world - 1:
             logits = self.llm.lm_head(hidden[:, -1:]).float()
-        dist.broadcast(logits, src=self.world - 1, group=self.group)
+        dist.broadcast(logits, src=_global_rank(self.group, self.world - 1), group=self.group)
         self.shard_lens = None
         return logits

@@ -36,12 +36,23 @@ def _dt(t: torch.Tensor) -> int:
 
 
 def _gpu(*ts: Optional[torch.Tensor]) -> None:
+    cur = None
     for t in ts:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise TimeViperHipError(
                 "timeviper_amd kernels run on the GPU only (got a CPU tensor); "
                 "there is no CPU fallback in the product path"
             )
+        # the launch goes to the CURRENT device's stream (`_stream`): a tensor of another device
+        # would hand that stream foreign pointers.  One process drives one GPU here.
+        if cur is None:
+            cur = torch.cuda.current_device()
+        if t.device.index != cur:
+            raise TimeViperHipError(
+                f"tensor on cuda:{t.device.index} but the current device is cuda:{cur}: "
+                "call torch.cuda.set_device() (one process per GPU)")
 
 
 def _stream() -> int:

@@ -244,21 +244,62 @@ class GenericTimeViperVLM(nn.Module):
                                  cache_position=fused_cache_position, logits_to_keep=logits_to_keep,
                                  train_pdrop_args=train_pdrop_args)
 
+    def prepare_inputs_for_generation(self, input_ids, past_key_values=None, attention_mask=None,
+                                      inputs_embeds=None, cache_position=None, **kwargs):
+        """generic_vlm.py:762-848 for the native greedy loop below.  Prefill (no cache yet, or more
+        than one position): the tokenised `answer_prompt` is appended to the prompt (:772-785) and the
+        pixels ride along (:793-795).  Decode step: no pixels; position = tokens the attention cache
+        holds (:797-826; the reference reads layer 7 / 14's KV length, `get_seq_length()` here finds
+        the first attention layer) and, under flash_attention_2, no mask (:828-832)."""
+        is_prefill = past_key_values is None or cache_position is None or cache_position.shape[0] != 1
+        if is_prefill:
+            ap = kwargs.get("answer_prompt")
+            if ap:
+                ap_ids = self.llm_backbone.tokenizer(ap, add_special_tokens=False, return_tensors="pt").input_ids
+                ap_ids = ap_ids.to(input_ids.device).expand(input_ids.shape[0], -1)
+                input_ids = torch.cat([input_ids, ap_ids], dim=1)
+                if attention_mask is not None:
+                    attention_mask = torch.cat([attention_mask, torch.ones_like(ap_ids)], dim=1)
+            if attention_mask is not None and not bool(attention_mask.all()):
+                raise NotImplementedError("padded prompts (attention_mask with zeros) are not on the batch-1 "
+                                          "evaluation path")
+            return {"input_ids": input_ids, "attention_mask": None, "past_key_values": past_key_values,
+                    "pixel_values": kwargs.get("pixel_values"),
+                    "pixel_values_videos": kwargs.get("pixel_values_videos"), "use_cache": True,
+                    "cache_position": torch.zeros(1, dtype=torch.long)}
+        past_len = past_key_values.get_seq_length()
+        cp = torch.tensor([max(past_len, 1)])          # host side: the mixers branch on it
+        return {"input_ids": input_ids[:, -1:], "attention_mask": None, "past_key_values": past_key_values,
+                "pixel_values": None, "pixel_values_videos": None, "use_cache": True, "cache_position": cp,
+                "position_ids": cp.view(1, 1).to(input_ids.device)}
+
     @torch.inference_mode()
-    def generate(self, input_ids=None, pixel_values=None, pixel_values_videos=None,
-                 attention_mask=None, max_new_tokens: int = 128, use_cache: bool = True,
-                 do_sample: bool = False, temperature: float = 0, answer_prompt=None,
-                 return_ids: bool = True, **kwargs):
-        """Greedy decoding with the hybrid cache (what evaluate.py:507-525 asks of HF's
-        GenerationMixin: do_sample=False, use_cache=True).  Returns the generated ids."""
-        if do_sample:
+    def generate(self, *args, **kwargs):
+        """Greedy decoding with the hybrid cache: what evaluate.py:507-525 asks of HF's
+        GenerationMixin (`do_sample=False, use_cache=True, temperature=0, answer_prompt=...`), with
+        the reference's return contract (generic_vlm.py:743-760): the DECODED text of the new tokens
+        (prompt stripped, `.strip()`-ed), which evaluate.py:529 hands to `extract_answer`.
+        `return_ids=True` (or HF's `return_dict_in_generate=True`, or a tokenizer without `decode`)
+        returns the (1, n_new) id tensor instead."""
+        input_ids = args[0] if args else kwargs.pop("input_ids", None)
+        pixel_values = kwargs.pop("pixel_values", None)
+        pixel_values_videos = kwargs.pop("pixel_values_videos", None)
+        attention_mask = kwargs.pop("attention_mask", None)
+        max_new_tokens = int(kwargs.pop("max_new_tokens", 128))
+        return_ids = bool(kwargs.pop("return_ids", False)) or bool(kwargs.pop("return_dict_in_generate", False))
+        if kwargs.pop("do_sample", False):
             raise NotImplementedError("only greedy decoding is on the evaluation path")
+        eos = kwargs.pop("eos_token_id", None)
+        eos = self.eos_token_ids_to_use if eos is None else eos
+        eos = set(int(t) for t in (eos if isinstance(eos, (list, tuple)) else [eos]))
         llm = self.llm_backbone.llm
         cache = llm.new_cache(1, dtype=self.dtype, device=self.device)
-        out = self.forward(input_ids=input_ids, pixel_values=pixel_values,
-                           pixel_values_videos=pixel_values_videos, past_key_values=cache,
-                           use_cache=True, cache_position=torch.zeros(1, dtype=torch.long))
-        eos = set(int(t) for t in self.eos_token_ids_to_use)
+        mi = self.prepare_inputs_for_generation(input_ids, past_key_values=None, attention_mask=attention_mask,
+                                                pixel_values=pixel_values, pixel_values_videos=pixel_values_videos,
+                                                answer_prompt=kwargs.pop("answer_prompt", None))
+        out = self.forward(input_ids=mi["input_ids"], pixel_values=mi["pixel_values"],
+                           pixel_values_videos=mi["pixel_values_videos"], past_key_values=cache,
+                           use_cache=True, cache_position=mi["cache_position"])
         new_tokens: List[int] = []
         tok = out.logits[:, -1].argmax(-1)
         pdargs = self.pdrop_args if self.use_pdrop else None
@@ -267,13 +308,34 @@ class GenericTimeViperVLM(nn.Module):
             new_tokens.append(t)
             if t in eos:
                 break
-            past_len = cache.get_seq_length()
-            cp = torch.tensor([max(past_len, 1)])  # host side: the mixers branch on it
-            out = self.llm_backbone(input_ids=tok.view(1, 1), past_key_values=cache, use_cache=True,
-                                    cache_position=cp, position_ids=cp.view(1, 1).to(self.device),
+            mi = self.prepare_inputs_for_generation(tok.view(1, 1), past_key_values=cache,
+                                                    cache_position=torch.zeros(1, dtype=torch.long))
+            out = self.llm_backbone(input_ids=mi["input_ids"], past_key_values=cache, use_cache=True,
+                                    cache_position=mi["cache_position"], position_ids=mi["position_ids"],
                                     train_pdrop_args=pdargs)
             tok = out.logits[:, -1].argmax(-1)
-        return torch.tensor([new_tokens], device=self.device)
+        ids = torch.tensor([new_tokens], device=self.device)
+        tokenizer = self.llm_backbone.tokenizer
+        if return_ids or not hasattr(tokenizer, "decode"):
+            return ids
+        return tokenizer.decode(ids[0], skip_special_tokens=False).strip()
+
+    @classmethod
+    def from_pretrained(cls, pretrained_checkpoint, model_id: str, vision_backbone: VisionBackbone,
+                        llm_backbone: GenericLLMBackbone, enable_mixed_precision_training: bool = True,
+                        arch_specifier: str = "gelu_mlp", visual_token_order: str = "raw"):
+        """generic_vlm.py:874-910 (called at evaluate.py:198-214): build, `torch.load` the
+        state dict, `load_state_dict(strict=True)`, freeze, eval, move to the GPU in bf16."""
+        vlm = cls(model_id, vision_backbone, llm_backbone,
+                  enable_mixed_precision_training=enable_mixed_precision_training,
+                  arch_specifier=arch_specifier, visual_token_order=visual_token_order)
+        pretrained_weights = torch.load(pretrained_checkpoint, map_location="cpu")
+        vlm.load_state_dict(pretrained_weights, strict=True)
+        vlm.requires_grad_(False)
+        vlm.eval()
+        device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
+        vlm.to(device, dtype=torch.bfloat16)
+        return vlm
 
 
 class HybridTimeViperVLM(GenericTimeViperVLM):

@@ -59,6 +59,25 @@ class SyntheticTokenizer:
     def convert_tokens_to_ids(self, tok):
         return self.image_token_id if tok == DEFAULT_TOKEN else 3
 
+    def decode(self, ids, skip_special_tokens: bool = False) -> str:
+        """ids -> text: one `<id>` word per token (there is no vocabulary offline)."""
+        return " ".join(f"<{int(i)}>" for i in ids)
+
+    def __call__(self, text: str, add_special_tokens: bool = False, return_tensors: str = "pt"):
+        """text -> ids, one id per whitespace-separated word (a `<id>` word maps back to its id,
+        anything else to a stable id in [3, vocab-1)) — the call shape of
+        `tokenizer(answer_prompt, add_special_tokens=False, return_tensors="pt").input_ids`
+        (generic_vlm.py:774-776)."""
+        import types
+        import zlib
+        out = []
+        for w in text.split():
+            if w.startswith("<") and w.endswith(">") and w[1:-1].isdigit():
+                out.append(int(w[1:-1]))
+            else:
+                out.append(3 + zlib.crc32(w.encode()) % max(1, self.vocab_size - 4))
+        return types.SimpleNamespace(input_ids=torch.tensor([out], dtype=torch.long))
+
     def __len__(self):
         return self.vocab_size
 

@@ -415,6 +415,12 @@ class NemotronHBlock(nn.Module):
         super().__init__()
         self.config, self.layer_idx = config, layer_idx
         self.residual_in_fp32 = config.residual_in_fp32
+        if self.residual_in_fp32:
+            # the reference upcasts the residual stream to fp32 (modeling_nano.py:942-943); the fused
+            # residual-add + RMSNorm path here carries it in the activation dtype, so a config that
+            # asks for fp32 residuals must not run silently with different arithmetic
+            raise NotImplementedError("residual_in_fp32=True is not implemented (the checkpoints on the "
+                                      "evaluation path, Nemotron-Nano-9B-v2, use False)")
         self.norm = NemotronHRMSNorm(config.hidden_size, eps=config.layer_norm_epsilon)
         self.block_type = config.layers_block_type[layer_idx]
         if self.block_type == "mamba":
