@@ -220,6 +220,21 @@ int tv_attn_rank_scores(const void* q, const void* k, void* scores,
                         int64_t k_stride_l, int64_t k_stride_h,
                         int vis_start, int n_vis, float scale, int dtype,
                         void* workspace, size_t workspace_bytes, void* stream);
+/* The two halves of tv_attn_rank_scores for a sequence-sharded caller: every rank
+ * computes the logits of ITS keys, logits (n_keys, Hq) fp32 key-major — per-shard pieces
+ * concatenate along dim 0 — with the reference's roundings (q.K^T and the 1/sqrt(d) scaling
+ * rounded to `dtype`, modeling_nano.py:1923-1927); after an all-gather every rank runs the
+ * softmax statistics + head mean on the full (n_keys, Hq) array.  tv_attn_rank_scores is exactly
+ * these two calls, so one GPU and N GPUs rank — and keep — the same tokens.
+ * workspace of the second call: 2 * nheads_q floats. */
+int tv_attn_rank_logits(const void* q, const void* k, void* logits, int n_keys,
+                        int nheads_q, int nheads_kv, int headdim,
+                        int64_t k_stride_l, int64_t k_stride_h, float scale,
+                        int dtype, void* stream);
+int tv_attn_rank_scores_from_logits(const void* logits, void* scores, int n_keys,
+                                    int nheads_q, int vis_start, int n_vis,
+                                    int dtype, void* workspace,
+                                    size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
  * T1  row gather (token keep / drop).  Replaces features[i][top_rank_index,:]

@@ -66,14 +66,22 @@ def _fa_fwd(q, k, v, attention_mask=None, query_length=None, is_causal=True, **k
     return _fa(q, k, v, causal=is_causal)
 
 
-def _rank(q_row, k, n_keys, vis_start, n_vis, scale=None):
+def _rank_logits(q_row, k, scale=None):
+    """(keys, heads) logits with the reference's roundings (modeling_nano.py:1923-1927)"""
     H, D = q_row.shape
     rep = H // k.shape[1]
     dt = k.dtype
-    logit = torch.einsum("hd,khd->hk", q_row.float(), k[:n_keys].float().repeat_interleave(rep, 1)).to(dt)
-    logit = (logit.float() / math.sqrt(D)).to(dt).float()
-    p = torch.softmax(logit, dim=-1).to(dt).float()
-    return p.mean(0).to(dt).float()[vis_start:vis_start + n_vis]
+    logit = torch.einsum("hd,khd->kh", q_row.float(), k.float().repeat_interleave(rep, 1)).to(dt)
+    return (logit.float() / math.sqrt(D)).to(dt).float()
+
+
+def _rank_from_logits(logits, vis_start, n_vis, dtype):
+    p = torch.softmax(logits, dim=0).to(dtype).float()
+    return p.mean(1).to(dtype).float()[vis_start:vis_start + n_vis]
+
+
+def _rank(q_row, k, n_keys, vis_start, n_vis, scale=None):
+    return _rank_from_logits(_rank_logits(q_row, k[:n_keys], scale), vis_start, n_vis, k.dtype)
 
 
 def _patch_video(pix, w, b=None, pos=None):
@@ -138,6 +146,7 @@ def cpu_kernels():
         "uniform_keep_indices": lambda n, keep, offset=0, device="cpu":
             R.uniform_keep_indices_ref(n, keep) + offset,
         "dropped_indices": _dropped, "attn_rank_scores": _rank,
+        "attn_rank_logits": _rank_logits, "attn_rank_scores_from_logits": _rank_from_logits,
         "patch_embed": lambda pix, w, b=None, pos=None, patch=None:
             R.patch_embed_ref(pix, w, b, pos).to(pix.dtype),
         "patch_embed_video": _patch_video,

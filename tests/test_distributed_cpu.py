@@ -46,6 +46,33 @@ def build(merge):
     return vlm
 
 
+class HostReadCounter:
+    """Counts the Tensor methods that copy a value to the host (each one is a device
+    synchronisation when the tensor lives on a GPU); `paused()` exempts a region."""
+    NAMES = ("item", "tolist", "__int__", "__float__", "__bool__", "__index__", "nonzero", "cpu", "numpy")
+
+    def __init__(self):
+        self.count, self.on, self.saved = 0, False, {}
+
+    def __enter__(self):
+        for n in self.NAMES:
+            orig = getattr(torch.Tensor, n)
+            self.saved[n] = orig
+
+            def wrapped(t, *a, __orig=orig, **kw):
+                if self.on:
+                    self.count += 1
+                return __orig(t, *a, **kw)
+            setattr(torch.Tensor, n, wrapped)
+        self.on = True
+        return self
+
+    def __exit__(self, *exc):
+        self.on = False
+        for n, f in self.saved.items():
+            setattr(torch.Tensor, n, f)
+
+
 def worker(rank, world, port, merge, T, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -64,7 +91,26 @@ def worker(rank, world, port, merge, T, q):
             lo, hi = runner.frame_range(T)
             if merge == "CrossAttention" and world == 2:
                 assert runner.frame_split(T) == [(0, 4), (4, 5)]
+            # host reads: none in the layer loop outside the pdrop stages; inside a stage at most the
+            # one copy of world + 1 positions (a .tolist()) — counted here on every rank
+            counter, in_stage = HostReadCounter(), [0]
+            run_layers, pdrop = runner.run_layers, runner._pdrop
+
+            def counted_layers(*a, **kw):
+                with counter:
+                    return run_layers(*a, **kw)
+
+            def exempt_pdrop(*a, **kw):
+                before = counter.count
+                out = pdrop(*a, **kw)
+                in_stage[0] += counter.count - before
+                counter.count = before
+                return out
+            runner.run_layers, runner._pdrop = counted_layers, exempt_pdrop
             logits = runner.forward(ids, pix[lo:hi], T)
+            n_stages = len(runner.trace)
+            assert counter.count == 0, f"{counter.count} host reads in the layer loop"
+            assert in_stage[0] <= 2 * n_stages, (in_stage[0], n_stages)
             trace = [t.clone() for t in runner.trace]
             if rank == 0:
                 ref = vlm(input_ids=ids, pixel_values_videos=pix).logits

@@ -32,7 +32,21 @@ def stage_collectives_through_host():
         bc(h, src=src, group=group)
         t.copy_(h)
 
-    dist.all_gather, dist.broadcast = all_gather, broadcast
+    agt = dist.all_gather_into_tensor
+
+    class _Done:
+        def wait(self):
+            return True
+
+    def all_gather_into_tensor(out, t, group=None, async_op=False):
+        if not t.is_cuda:
+            return agt(out, t, group=group, async_op=async_op)
+        host = torch.empty(out.shape, dtype=out.dtype)
+        agt(host, t.cpu(), group=group)
+        out.copy_(host)
+        return _Done() if async_op else None
+
+    dist.all_gather, dist.broadcast, dist.all_gather_into_tensor = all_gather, broadcast, all_gather_into_tensor
 
 
 def worker(rank, world, port, merge, T, q, pd=PD):
@@ -108,3 +122,73 @@ def test_sequence_parallel_hip_matches_single_process(merge, pd):
         # kept differently by the sharded softmax, so only the uniform stage is compared
         # exactly here (the fp32 gloo test compares every stage exactly)
         assert (trace[0] == ref_trace[0]).all()
+
+
+def stage_worker(rank, world, port, q):
+    """One "attn" pdrop stage on IDENTICAL inputs: the full hidden states cut into two shards
+    against the unsharded `pdrop_no_pack`."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        stage_collectives_through_host()
+        from timeviper_amd.distributed import SequenceParallelTimeViper
+        from timeviper_amd.model import build_synthetic_timeviper
+        from timeviper_amd.model.llm.nano import NemotronHConfig
+        cfg = NemotronHConfig(vocab_size=128, hidden_size=256, intermediate_size=384, num_hidden_layers=8,
+                              hybrid_override_pattern="M-M*M-*M", num_attention_heads=8, head_dim=64,
+                              num_key_value_heads=2, ssm_state_size=128, mamba_num_heads=8,
+                              mamba_n_groups=2, mamba_head_dim=40, mamba_chunk_size=64)
+        vlm = build_synthetic_timeviper(cfg, "siglip-vit-b16-224px", pdrop_type="attn_3_0.5-attn_6_0.25",
+                                        merge_module="CrossAttention", vit_depth=1, image_size=96, seed=5)
+        bb = vlm.llm_backbone.llm.backbone
+        n_before, n_vis, n_after = 7, 4096, 9
+        L = n_before + n_vis + n_after
+        g = torch.Generator(device="cuda").manual_seed(11)
+        hidden = torch.randn(1, L, 256, device="cuda", generator=g).bfloat16()
+        cut = n_before + 2309                                 # an uneven split inside the vision span
+        bounds = [(0, cut), (cut, L)]
+        runner = SequenceParallelTimeViper(vlm, rank, world)
+        runner.shard_lens = [e - s0 for s0, e in bounds]
+        meta = {"num_vision_tokens": n_vis, "vision_index": n_before, "text_prompt_len": n_before + n_after}
+        s0, e0 = bounds[rank]
+        with torch.no_grad():
+            new, new_start, top = runner._pdrop(0, 3, hidden[:, s0:e0].contiguous(), s0, meta)
+            if rank == 0:
+                bb.last_pdrop_trace = []
+                pa = {"first_vision_token_positions": torch.tensor([n_before]), "num_vision_tokens": [n_vis],
+                      "text_prompt_lens": [n_before + n_after], "is_interleaved": False}
+                _, _, ref_new, _, _ = bb.flash_rank_drop(0, 3, hidden, None, None, None, train_pdrop_args=pa)
+                ref_top = bb.last_pdrop_trace[0]["kept"]
+                q.put((top.cpu().numpy(), ref_top.cpu().numpy(), new.float().cpu().numpy(),
+                       ref_new[:, :new.shape[1]].float().cpu().numpy(), runner.shard_lens))
+        dist.barrier()
+    except BaseException:
+        import traceback
+        traceback.print_exc()
+        os._exit(1)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_attn_rank_keeps_exactly_the_single_gpu_tokens():
+    """north_star: bit-exact token-drop masks.  The sharded stage runs the SAME kernels as the
+    unsharded one (tv_attn_rank_logits on each rank's keys -> all-gather -> tv_attn_rank_scores_from_logits
+    + the same stable sort), so on identical inputs two ranks keep exactly the tokens one GPU keeps."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=stage_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        top, ref_top, new, ref_new, lens = q.get(timeout=600)
+    finally:
+        for p in procs:
+            p.join(120)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs), "worker failed (see its traceback above)"
+    assert top.shape == ref_top.shape == (2048,) and (top == ref_top).all(), "kept indices differ"
+    assert sum(lens) == 7 + 2048 + 9
+    assert (new == ref_new).all()                 # rank 0's rows: pre-vision text + its kept vision rows

@@ -38,6 +38,8 @@ SIGNATURES = {
     "tv_flash_attn_fwd": (_i, [_p] * 5 + [_i] * 6 + [_l] * 12 + [_f, _i, _i, _p]),
     "tv_attn_rank_workspace_bytes": (_z, [_i, _i]),
     "tv_attn_rank_scores": (_i, [_p, _p, _p, _i, _i, _i, _i, _l, _l, _i, _i, _f, _i, _p, _z, _p]),
+    "tv_attn_rank_logits": (_i, [_p, _p, _p, _i, _i, _i, _i, _l, _l, _f, _i, _p]),
+    "tv_attn_rank_scores_from_logits": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
     "tv_gather_rows": (_i, [_p, _p, _p, _l, _i, _l, _l, _i, _p]),
     "tv_uniform_keep_indices": (_i, [_p, _l, _l, _l, _p]),
     "tv_dropped_indices": (_i, [_p, _l, _l, _l, _p, _p]),
@@ -55,7 +57,7 @@ class TimeViperHipError(RuntimeError):
     pass
 
 
-ABI_VERSION = 3      # tv_abi_version() of the library these SIGNATURES describe (csrc/capi.cpp)
+ABI_VERSION = 4      # tv_abi_version() of the library these SIGNATURES describe (csrc/capi.cpp)
 
 
 def lib_path() -> Path:

@@ -61,7 +61,7 @@ __global__ void dropped_kernel(const int64_t* __restrict__ keep, int64_t n_keep,
 }
 
 // ----------------------------------------------------------- attn rank
-// logits[h][k] = scale * q_h . K[k, g(h)]
+// logits[k][h] = scale * q_h . K[k, g(h)]   (key-major: per-shard pieces concatenate along dim 0)
 template <typename T>
 __global__ __launch_bounds__(256) void rank_logits_kernel(const T* __restrict__ q,
                                                           const T* __restrict__ k,
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void rank_logits_kernel(const T* __restrict__ 
       // the reference forms q.K^T and the 1/sqrt(d) scaling in the activation
       // dtype (:1923-1927) before the fp32 softmax: round twice like it does
       acc = to_f32(from_f32<T>(acc));
-      if (lane == 0) logits[(int64_t)h * n_keys + key] = to_f32(from_f32<T>(acc * scale));
+      if (lane == 0) logits[(int64_t)key * Hq + h] = to_f32(from_f32<T>(acc * scale));
     }
   }
 }
@@ -99,12 +99,12 @@ __global__ __launch_bounds__(256) void rank_logits_kernel(const T* __restrict__ 
 // per head: m = max, s = sum exp(l - m)
 __global__ __launch_bounds__(1024) void rank_stats_kernel(const float* __restrict__ logits,
                                                           float* __restrict__ stats,
-                                                          int n_keys) {
+                                                          int n_keys, int Hq) {
   __shared__ float red[16];
   const int h = blockIdx.x;
-  const float* l = logits + (int64_t)h * n_keys;
+  const float* l = logits + h;
   float m = -INFINITY;
-  for (int i = threadIdx.x; i < n_keys; i += blockDim.x) m = fmaxf(m, l[i]);
+  for (int i = threadIdx.x; i < n_keys; i += blockDim.x) m = fmaxf(m, l[(int64_t)i * Hq]);
   m = wave_max(m);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
   __syncthreads();
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(1024) void rank_stats_kernel(const float* __restric
   for (int i = 1; i < (int)(blockDim.x >> 6); ++i) m = fmaxf(m, red[i]);
   __syncthreads();
   float s = 0.f;
-  for (int i = threadIdx.x; i < n_keys; i += blockDim.x) s += expf(l[i] - m);
+  for (int i = threadIdx.x; i < n_keys; i += blockDim.x) s += expf(l[(int64_t)i * Hq] - m);
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
@@ -136,7 +136,7 @@ __global__ void rank_scores_kernel(const float* __restrict__ logits,
   float acc = 0.f;
   for (int h = 0; h < Hq; ++h) {
     float p = 0.f;
-    if (key < n_keys) p = expf(logits[(int64_t)h * n_keys + key] - stats[2 * h]) / stats[2 * h + 1];
+    if (key < n_keys) p = expf(logits[(int64_t)key * Hq + h] - stats[2 * h]) / stats[2 * h + 1];
     acc += to_f32(from_f32<T>(p));
   }
   scores[j] = to_f32(from_f32<T>(acc / (float)Hq));
@@ -155,17 +155,40 @@ int launch_gather(const void* src, const int64_t* index, void* dst, int64_t n, i
 }
 
 template <typename T>
-int launch_rank(const void* q, const void* k, void* scores, int n_keys, int Hq, int Hkv, int D,
-                int64_t ksl, int64_t ksh, int vis_start, int n_vis, float scale, void* ws,
-                hipStream_t s) {
-  float* logits = (float*)ws;
-  float* stats = logits + (int64_t)Hq * n_keys;
+int launch_rank_logits(const void* q, const void* k, float* logits, int n_keys, int Hq, int Hkv,
+                       int D, int64_t ksl, int64_t ksh, float scale, hipStream_t s) {
   rank_logits_kernel<T><<<dim3((n_keys + 3) / 4), 256, (size_t)Hq * D * sizeof(float), s>>>(
       (const T*)q, (const T*)k, logits, n_keys, Hq, Hkv, D, ksl, ksh, scale);
-  rank_stats_kernel<<<dim3(Hq), 1024, 0, s>>>(logits, stats, n_keys);
+  TV_LAUNCH_CHECK();
+}
+
+template <typename T>
+int launch_rank_scores(const float* logits, void* scores, int n_keys, int Hq, int vis_start,
+                       int n_vis, float* stats, hipStream_t s) {
+  rank_stats_kernel<<<dim3(Hq), 1024, 0, s>>>(logits, stats, n_keys, Hq);
   rank_scores_kernel<T><<<dim3((n_vis + 255) / 256), 256, 0, s>>>(logits, stats, (float*)scores,
                                                                    n_keys, Hq, vis_start, n_vis);
   TV_LAUNCH_CHECK();
+}
+
+int rank_logits_dispatch(const void* q, const void* k, float* logits, int n_keys, int Hq, int Hkv,
+                         int D, int64_t ksl, int64_t ksh, float scale, int dtype, hipStream_t s) {
+  switch (dtype) {
+    case TV_F32: return launch_rank_logits<float>(q, k, logits, n_keys, Hq, Hkv, D, ksl, ksh, scale, s);
+    case TV_BF16: return launch_rank_logits<bf16_t>(q, k, logits, n_keys, Hq, Hkv, D, ksl, ksh, scale, s);
+    case TV_F16: return launch_rank_logits<f16_t>(q, k, logits, n_keys, Hq, Hkv, D, ksl, ksh, scale, s);
+  }
+  TV_UNSUPPORTED("attn_rank: dtype %d", dtype);
+}
+
+int rank_scores_dispatch(const float* logits, void* scores, int n_keys, int Hq, int vis_start,
+                         int n_vis, float* stats, int dtype, hipStream_t s) {
+  switch (dtype) {
+    case TV_F32: return launch_rank_scores<float>(logits, scores, n_keys, Hq, vis_start, n_vis, stats, s);
+    case TV_BF16: return launch_rank_scores<bf16_t>(logits, scores, n_keys, Hq, vis_start, n_vis, stats, s);
+    case TV_F16: return launch_rank_scores<f16_t>(logits, scores, n_keys, Hq, vis_start, n_vis, stats, s);
+  }
+  TV_UNSUPPORTED("attn_rank: dtype %d", dtype);
 }
 
 }  // namespace
@@ -213,6 +236,34 @@ extern "C" size_t tv_attn_rank_workspace_bytes(int n_keys, int nheads_q) {
   return ((size_t)nheads_q * (size_t)n_keys + 2 * (size_t)nheads_q) * sizeof(float);
 }
 
+extern "C" int tv_attn_rank_logits(const void* q, const void* k, void* logits, int n_keys,
+                                   int nheads_q, int nheads_kv, int headdim, int64_t k_stride_l,
+                                   int64_t k_stride_h, float scale, int dtype, void* stream) {
+  TV_CHECK_ARG(n_keys >= 0 && nheads_q > 0 && nheads_kv > 0 && nheads_q % nheads_kv == 0 && headdim > 0,
+               "attn_rank_logits: bad sizes");
+  if (n_keys == 0) return TV_OK;
+  TV_CHECK_ARG(q && k && logits, "attn_rank_logits: null pointer");
+  if (headdim > 256) TV_UNSUPPORTED("attn_rank: headdim %d > 256", headdim);
+  return rank_logits_dispatch(q, k, (float*)logits, n_keys, nheads_q, nheads_kv, headdim, k_stride_l,
+                              k_stride_h, scale, dtype, (hipStream_t)stream);
+}
+
+extern "C" int tv_attn_rank_scores_from_logits(const void* logits, void* scores, int n_keys,
+                                               int nheads_q, int vis_start, int n_vis, int dtype,
+                                               void* workspace, size_t workspace_bytes,
+                                               void* stream) {
+  TV_CHECK_ARG(n_keys > 0 && nheads_q > 0 && n_vis >= 0 && vis_start >= 0,
+               "attn_rank_scores_from_logits: bad sizes");
+  TV_CHECK_ARG(logits && scores && workspace, "attn_rank_scores_from_logits: null pointer");
+  if (workspace_bytes < 2 * (size_t)nheads_q * sizeof(float)) {
+    tv_set_error("attn_rank_scores_from_logits: workspace too small");
+    return TV_ERR_WORKSPACE;
+  }
+  if (n_vis == 0) return TV_OK;
+  return rank_scores_dispatch((const float*)logits, scores, n_keys, nheads_q, vis_start, n_vis,
+                              (float*)workspace, dtype, (hipStream_t)stream);
+}
+
 extern "C" int tv_attn_rank_scores(const void* q, const void* k, void* scores, int n_keys,
                                    int nheads_q, int nheads_kv, int headdim, int64_t k_stride_l,
                                    int64_t k_stride_h, int vis_start, int n_vis, float scale,
@@ -228,17 +279,13 @@ extern "C" int tv_attn_rank_scores(const void* q, const void* k, void* scores, i
     return TV_ERR_WORKSPACE;
   }
   if (n_vis == 0) return TV_OK;
+  // the two halves a sequence-sharded caller runs separately (logits of its own keys; statistics
+  // and scores over the gathered logits): the same kernels, so 1 GPU and N GPUs keep the same tokens
   hipStream_t s = (hipStream_t)stream;
-  switch (dtype) {
-    case TV_F32:
-      return launch_rank<float>(q, k, scores, n_keys, nheads_q, nheads_kv, headdim, k_stride_l,
-                                k_stride_h, vis_start, n_vis, scale, workspace, s);
-    case TV_BF16:
-      return launch_rank<bf16_t>(q, k, scores, n_keys, nheads_q, nheads_kv, headdim, k_stride_l,
-                                 k_stride_h, vis_start, n_vis, scale, workspace, s);
-    case TV_F16:
-      return launch_rank<f16_t>(q, k, scores, n_keys, nheads_q, nheads_kv, headdim, k_stride_l,
-                                k_stride_h, vis_start, n_vis, scale, workspace, s);
-  }
-  TV_UNSUPPORTED("attn_rank: dtype %d", dtype);
+  float* logits = (float*)workspace;
+  float* stats = logits + (int64_t)nheads_q * n_keys;
+  const int st = rank_logits_dispatch(q, k, logits, n_keys, nheads_q, nheads_kv, headdim, k_stride_l,
+                                      k_stride_h, scale, dtype, s);
+  if (st != TV_OK) return st;
+  return rank_scores_dispatch(logits, scores, n_keys, nheads_q, vis_start, n_vis, stats, dtype, s);
 }

@@ -55,6 +55,17 @@ def all_gather_varlen(t: torch.Tensor, group=None, lens: Optional[List[int]] = N
     return [o[:k] for o, k in zip(out, ns)]
 
 
+def all_gather_stack(t: torch.Tensor, group=None) -> torch.Tensor:
+    """(world, *t.shape): every rank's equally-shaped `t`, gathered straight into one tensor
+    (no per-rank temporaries, unlike the list form of all_gather)."""
+    world = dist.get_world_size(group)
+    t = t.contiguous()
+    flat = t.reshape(1, -1)                     # (world * 1, numel): the concatenating form every backend takes
+    out = torch.empty((world, flat.shape[1]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, flat, group=group)
+    return out.view((world,) + tuple(t.shape))
+
+
 def chain_states(states: torch.Tensor, decays: torch.Tensor, rank: int) -> torch.Tensor:
     """Incoming SSM state of shard `rank` from the per-shard (zero-init) final states
     (R,B,H,P,N) and total log-decays (R,B,H):  In_r = exp(L_{r-1}) In_{r-1} + S_{r-1}."""
@@ -165,7 +176,7 @@ class SequenceParallelTimeViper:
     def shard_layout(self, input_ids: torch.Tensor, n_frames: int, tok_per_frame: int):
         """Global token ranges [start, end) of every rank's shard, for a prompt of the form
         [text_before | <image> x T | text_after] (the benchmark / evaluate.py layout)."""
-        ids = input_ids[0]
+        ids = input_ids[0].cpu()            # one device-to-host copy; everything below is host arithmetic
         is_img = ids == self.vlm.default_token_id
         pos = is_img.nonzero().flatten()
         first, last = int(pos[0]), int(pos[-1])
@@ -203,8 +214,7 @@ class SequenceParallelTimeViper:
         tail = xBC.new_zeros((Bsz, Kw - 1, xBC.shape[-1]))
         if n_tail:
             tail[:, Kw - 1 - n_tail:] = xBC[:, L - n_tail:]
-        tails = [torch.empty_like(tail) for _ in range(self.world)]
-        dist.all_gather(tails, tail, group=self.group)
+        tails = all_gather_stack(tail, self.group)
         cnts = [min(n, Kw - 1) for n in self._lens(L, xBC.device)]   # host-side inside forward(): no sync
         halo = None
         if self.rank > 0:
@@ -231,26 +241,35 @@ class SequenceParallelTimeViper:
             kw["dt_limit"] = mixer.time_step_limit
         A = mixer._neg_A()
         y, S, dec = K.mamba_chunk_scan_combined(xh, dt, A, Bm, Cm, return_total_decay=True, **kw)
-        S_all = [torch.empty_like(S) for _ in range(self.world)]
-        d_all = [torch.empty_like(dec) for _ in range(self.world)]
-        dist.all_gather(S_all, S, group=self.group)
-        dist.all_gather(d_all, dec, group=self.group)
+        S_all = all_gather_stack(S, self.group)
+        d_all = all_gather_stack(dec, self.group)
         if self.rank > 0:
-            inc = chain_states(torch.stack(S_all), torch.stack(d_all), self.rank)
+            inc = chain_states(S_all, d_all, self.rank)
             y, _ = K.mamba_chunk_scan_combined(xh, dt, A, Bm, Cm, initial_states=inc, **kw)
         y = mixer.norm(y.view(Bsz, L, d_in), gate)
         return mixer.out_proj(y)
 
     def _attention(self, attn, normed):
         Bsz, L, _ = normed.shape
+        assert Bsz == 1, "the sequence-sharded runner is batch 1 (the evaluation path)"
+        kvd = attn.num_key_value_heads * attn.head_dim
+        lens = self._lens(L, normed.device)
+        mx = max(lens)
+        # K and V of this shard in ONE padded buffer, gathered asynchronously (RCCL runs the
+        # collective on its own stream) while q_proj — the largest of the three GEMMs — computes
+        kv = torch.empty((2, mx, kvd), dtype=normed.dtype, device=normed.device)
+        kv[0, :L] = attn.k_proj(normed).view(L, kvd)
+        kv[1, :L] = attn.v_proj(normed).view(L, kvd)
+        if L < mx:
+            kv[:, L:].zero_()
+        gathered = torch.empty((self.world, kv.numel()), dtype=kv.dtype, device=kv.device)
+        work = dist.all_gather_into_tensor(gathered, kv.view(1, -1), group=self.group, async_op=True)
+        gathered = gathered.view((self.world,) + tuple(kv.shape))
         q = attn.q_proj(normed).view(Bsz, L, attn.num_heads, attn.head_dim)
-        k = attn.k_proj(normed).view(L, attn.num_key_value_heads * attn.head_dim)
-        v = attn.v_proj(normed).view(L, attn.num_key_value_heads * attn.head_dim)
-        lens = self._lens(L, k.device)
-        ks = all_gather_varlen(k, self.group, lens)
-        vs = all_gather_varlen(v, self.group, lens)
-        kf = torch.cat(ks[: self.rank + 1]).view(1, -1, attn.num_key_value_heads, attn.head_dim)
-        vf = torch.cat(vs[: self.rank + 1]).view(1, -1, attn.num_key_value_heads, attn.head_dim)
+        work.wait()
+        upto = self.rank + 1
+        kf = torch.cat([gathered[r, 0, :lens[r]] for r in range(upto)]).view(1, -1, attn.num_key_value_heads, attn.head_dim)
+        vf = torch.cat([gathered[r, 1, :lens[r]] for r in range(upto)]).view(1, -1, attn.num_key_value_heads, attn.head_dim)
         o = K.flash_attn_func(q, kf, vf, causal=True)      # bottom-right aligned: Lk >= Lq
         return attn.o_proj(o.reshape(Bsz, L, attn.num_heads * attn.head_dim))
 
@@ -277,62 +296,83 @@ class SequenceParallelTimeViper:
             dist.broadcast(q_row, src=_global_rank(self.group, self.world - 1), group=self.group)
             n_local = max(0, min(L, row + 1 - start))             # local keys that take part
             k_loc = sa.k_proj(feats[:n_local]).view(n_local, sa.num_key_value_heads, sa.head_dim)
-            rep = sa.num_heads // sa.num_key_value_heads
-            # logits with the reference's roundings (q.K^T and /sqrt(d) in the activation dtype)
-            logit = torch.einsum("hd,khd->hk", q_row.float().view(sa.num_heads, sa.head_dim),
-                                 k_loc.float().repeat_interleave(rep, dim=1)).to(feats.dtype)
-            logit = (logit.float() / math.sqrt(sa.head_dim)).to(feats.dtype).float()
-            m_loc = logit.max(dim=1).values if n_local else torch.full((sa.num_heads,), -float("inf"), device=dev)
-            ms = [torch.empty_like(m_loc) for _ in range(self.world)]
-            dist.all_gather(ms, m_loc, group=self.group)
-            m = torch.stack(ms).max(dim=0).values
-            s_loc = torch.exp(logit - m[:, None]).sum(dim=1)
-            ss = [torch.empty_like(s_loc) for _ in range(self.world)]
-            dist.all_gather(ss, s_loc, group=self.group)
-            ssum = torch.stack(ss).sum(dim=0)
-            p = (torch.exp(logit - m[:, None]) / ssum[:, None]).to(feats.dtype).float()
-            sc = p.mean(dim=0).to(feats.dtype).float()            # (n_local,)
-            lo = max(vis0 - start, 0)
-            hi = max(min(vis_end - start, n_local), lo)
-            scores = torch.cat(all_gather_varlen(sc[lo:hi].contiguous(), self.group))
+            # the SAME two kernels the unsharded model runs (tv_attn_rank_scores = logits of the keys,
+            # then statistics + head mean over all of them): each rank computes the logits of its own
+            # keys, the (keys, heads) pieces are all-gathered, and every rank ranks the identical array
+            # — one GPU and N GPUs keep the same tokens, bit for bit
+            lg = K.attn_rank_logits(q_row, k_loc)
+            n_all = [max(0, min(n, row + 1 - s0)) for n, s0 in zip(self.shard_lens, self._starts())]
+            logits = torch.cat(all_gather_varlen(lg, self.group, n_all))
+            assert logits.shape[0] == row + 1
+            scores = K.attn_rank_scores_from_logits(logits, vis0, image_tokens, feats.dtype)
             order = torch.sort(scores, descending=True, stable=True).indices
             top = (order[:keep] + vis0).sort().values
         elif "uni" in ctype:
             top = K.uniform_keep_indices(image_tokens, keep, offset=vis0, device=dev)
         else:
             raise NotImplementedError(ctype)
+        # Where the (identical, sorted) kept indices fall in every rank's old range.  "uni" indices are
+        # a pure function of (image_tokens, keep): located on the host from the CPU reference formula
+        # (what the kernel reproduces bit for bit) without touching the device; "attn" needs the
+        # ranking's outcome: ONE device-to-host copy of world + 1 positions per stage — no collective,
+        # and every later shape in this function is a host integer
+        starts = self._starts()
+        ends = [s0 + n for s0, n in zip(starts, self.shard_lens)]
+        edges = starts + [ends[-1]]
+        if "uni" in ctype:
+            top_h = torch.linspace(0, image_tokens - 1, keep, dtype=torch.long) + vis0
+            pos = torch.searchsorted(top_h, torch.tensor(edges)).tolist()
+        else:
+            pos = torch.searchsorted(top, torch.tensor(edges, device=dev)).tolist()
+        kept_per_rank = [pos[r + 1] - pos[r] for r in range(self.world)]
         # rows of this shard that survive: [pre-vision text | kept vision | trailing text]
         end = start + L
-        g = torch.arange(start, end, device=dev)
-        mine = top[(top >= start) & (top < end)]
-        local_idx = torch.cat([g[g < vis0], mine, g[g >= vis_end]]) - start
-        new = K.gather_rows(feats, local_idx)
+        assert (start, end) == (starts[self.rank], ends[self.rank])
+        mine = top[pos[self.rank]: pos[self.rank + 1]]
+        pre_hi, post_lo = min(end, vis0), max(start, vis_end)
+        parts = []
+        if pre_hi > start:
+            parts.append(torch.arange(0, pre_hi - start, device=dev))
+        parts.append(mine - start)
+        n_text = max(0, end - post_lo)
+        if n_text:
+            parts.append(torch.arange(post_lo - start, L, device=dev))
+        new = K.gather_rows(feats, torch.cat(parts))
         # TransV merge: trailing text (last rank) attends to ALL dropped vision rows
         if bb.merge_modules is not None and bb.merge_module_names[stage] != "none":
-            is_vis = (g >= vis0) & (g < vis_end)
-            kept_here = torch.zeros(L, dtype=torch.bool, device=dev)
-            kept_here[mine - start] = True
-            dropped_local = feats[is_vis & ~kept_here]
+            v_lo = [max(s0, vis0) for s0 in starts]
+            v_n = [max(0, min(e0, vis_end) - lo) for lo, e0 in zip(v_lo, ends)]       # vision rows per rank
+            n_drop = [n - k for n, k in zip(v_n, kept_per_rank)]
             mod = bb.merge_modules[stage]
-            kd = mod.k_proj(dropped_local)
-            vd = mod.v_proj(dropped_local)
-            kd = torch.cat(all_gather_varlen(kd, self.group))
-            vd = torch.cat(all_gather_varlen(vd, self.group))
-            if self.rank == self.world - 1:
-                n_text = int((g >= vis_end).sum())
+            kvd = mod.num_key_value_heads * mod.head_dim
+            if n_drop[self.rank]:
+                didx = K.dropped_indices(mine, v_lo[self.rank], v_n[self.rank]) - start
+                dropped_local = K.gather_rows(feats, didx)
+                kd, vd = mod.k_proj(dropped_local), mod.v_proj(dropped_local)
+            else:
+                kd = vd = feats.new_empty((0, kvd))
+            kd = torch.cat(all_gather_varlen(kd, self.group, n_drop))
+            vd = torch.cat(all_gather_varlen(vd, self.group, n_drop))
+            if self.rank == self.world - 1 and n_text:
                 text = new[new.shape[0] - n_text:]
                 qd = mod.q_proj(text).view(1, n_text, mod.num_heads, mod.head_dim)
                 o = K.flash_attn_func(qd, kd.view(1, -1, mod.num_key_value_heads, mod.head_dim),
                                       vd.view(1, -1, mod.num_key_value_heads, mod.head_dim), causal=False)
                 merged = mod.o_proj(o.reshape(n_text, mod.num_heads * mod.head_dim))
                 new[new.shape[0] - n_text:] = text + bb.alpha[stage].tanh() * merged
-        # new global start = number of surviving rows on earlier ranks
-        n_new = torch.tensor([new.shape[0]], device=dev, dtype=torch.int64)
-        ns = [torch.zeros_like(n_new) for _ in range(self.world)]
-        dist.all_gather(ns, n_new, group=self.group)
-        self.shard_lens = [int(v) for v in ns]                 # every rank's new shard length
+        new_lens = [max(0, min(e0, vis0) - s0) + kept_per_rank[r] + max(0, e0 - max(s0, vis_end))
+                    for r, (s0, e0) in enumerate(zip(starts, ends))]
+        assert new_lens[self.rank] == new.shape[0], (new_lens, new.shape)
+        self.shard_lens = new_lens
         new_start = sum(self.shard_lens[: self.rank])
         return new.unsqueeze(0), new_start, top
+
+    def _starts(self) -> List[int]:
+        out, acc = [], 0
+        for n in self.shard_lens:
+            out.append(acc)
+            acc += n
+        return out
 
     # ---------------------------------------------------------------- forward
     @torch.no_grad()
@@ -358,6 +398,15 @@ class SequenceParallelTimeViper:
         assert hidden.shape[1] == end - start
         meta = {"num_vision_tokens": n_frames * tpf, "vision_index": n_before,
                 "text_prompt_len": n_before + n_after}
+        logits = self.run_layers(hidden, start, meta)
+        self.shard_lens = None
+        return logits
+
+    def run_layers(self, hidden, start: int, meta):
+        """The 56-layer loop on this rank's shard.  Outside `_pdrop` it reads nothing back from the
+        device: shard lengths live on the host, every collective has host-known sizes
+        (tests/test_distributed_cpu.py counts the host reads)."""
+        bb = self.bb
         self.trace = []
         delta = None
         for i, block in enumerate(bb.layers):
@@ -382,5 +431,4 @@ class SequenceParallelTimeViper:
         if self.rank == self.world - 1:
             logits = self.llm.lm_head(hidden[:, -1:]).float()
         dist.broadcast(logits, src=_global_rank(self.group, self.world - 1), group=self.group)
-        self.shard_lens = None
         return logits

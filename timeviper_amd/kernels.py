@@ -451,6 +451,36 @@ def attn_rank_scores(q_row: torch.Tensor, k: torch.Tensor, n_keys: int, vis_star
     return scores
 
 
+def attn_rank_logits(q_row: torch.Tensor, k: torch.Tensor, scale: Optional[float] = None) -> torch.Tensor:
+    """First half of `attn_rank_scores` for a sequence shard: logits (n_keys, Hq) fp32 of this
+    rank's keys k (n_keys, Hkv, D) against the broadcast query row, with the reference's roundings."""
+    _gpu(q_row, k)
+    Hq, D = q_row.shape
+    n, Hkv, _ = k.shape
+    q_row = q_row.contiguous()
+    if k.stride(-1) != 1:
+        k = k.contiguous()
+    scale = 1.0 / math.sqrt(D) if scale is None else float(scale)
+    out = torch.empty((n, Hq), dtype=torch.float32, device=k.device)
+    check(_capi.lib().tv_attn_rank_logits(_p(q_row), _p(k), _p(out), int(n), Hq, Hkv, D, k.stride(0),
+                                          k.stride(1), scale, _dt(k), _stream()), "tv_attn_rank_logits")
+    return out
+
+
+def attn_rank_scores_from_logits(logits: torch.Tensor, vis_start: int, n_vis: int, dtype) -> torch.Tensor:
+    """Second half: softmax over ALL keys per head, mean over heads (roundings in `dtype`, the
+    activation dtype), slice [vis_start, vis_start + n_vis).  logits (n_keys, Hq) fp32."""
+    _gpu(logits)
+    logits = logits.contiguous()
+    n, Hq = logits.shape
+    ws = torch.empty(2 * Hq, dtype=torch.float32, device=logits.device)
+    scores = torch.empty((n_vis,), dtype=torch.float32, device=logits.device)
+    check(_capi.lib().tv_attn_rank_scores_from_logits(_p(logits), _p(scores), int(n), Hq, int(vis_start),
+                                                      int(n_vis), _DT[dtype], _p(ws), ws.numel() * 4,
+                                                      _stream()), "tv_attn_rank_scores_from_logits")
+    return scores
+
+
 # ---------------------------------------------------------------- patch embed
 def apply_rotary_pos_emb_(q, k, cos, sin):
     """In-place rotary embedding of q (B, L, Hq, D) and k (B, L, Hkv, D) (views with a
