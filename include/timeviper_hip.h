@@ -205,6 +205,29 @@ int tv_flash_attn_fwd(const void* q, const void* k, const void* v, void* o,
                       int64_t o_stride_l, int64_t o_stride_h,
                       float softmax_scale, int causal, int dtype, void* stream);
 
+/* The same operator with the QK^T and PV products on the FP8 matrix path of CDNA4
+ * (v_mfma_f32_32x32x64_f8f6f4, OCP e4m3 operands, fp32 accumulation, fp32 softmax): BASELINE
+ * config 5 ("fp8 MFMA attention path"; call sites modeling_qwen2.py:196-244,
+ * modeling_nano.py:1198-1209).  The reference's arithmetic is bf16, so this variant is opt-in and
+ * judged by tolerance: q, k, v are quantised per (batch, head) to max |x| = 440, P per row to
+ * 2^8 p; inputs, output and lse keep the layout, dtype and meaning of tv_flash_attn_fwd.
+ * headdim <= 128 (multiple of 8).  workspace: tv_flash_attn_fp8_workspace_bytes() bytes,
+ * 256-byte aligned (the quantised copies: ~1 byte per q / k / v element, head_dim padded to
+ * 128); nothing persists in it between calls. */
+size_t tv_flash_attn_fp8_workspace_bytes(int batch, int seqlen_q, int seqlen_k,
+                                         int nheads_q, int nheads_kv);
+int tv_flash_attn_fp8_fwd(const void* q, const void* k, const void* v, void* o,
+                          void* lse, int batch, int seqlen_q, int seqlen_k,
+                          int nheads_q, int nheads_kv, int headdim,
+                          int64_t q_stride_b, int64_t q_stride_l,
+                          int64_t q_stride_h, int64_t k_stride_b,
+                          int64_t k_stride_l, int64_t k_stride_h,
+                          int64_t v_stride_b, int64_t v_stride_l,
+                          int64_t v_stride_h, int64_t o_stride_b,
+                          int64_t o_stride_l, int64_t o_stride_h,
+                          float softmax_scale, int causal, int dtype,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------
  * T2  pdrop "attn" ranking.  Replaces modeling_nano.py:1822-1857,:1914-1939
  * without the (L,L) mask: one query row (the last prompt token) against all

@@ -186,6 +186,21 @@ def attention_ref(q, k, v, causal, scale=None):
     return (p @ vf).permute(0, 2, 1, 3), lse
 
 
+def fp8_quantise_ref(x, qmax: float = 440.0):
+    """What the fp8 attention variant (BASELINE config 5; tv_flash_attn_fp8_fwd) does to q, k and
+    v before the MFMAs: one scale per (batch, head) so that max |x| -> qmax, rounding to OCP
+    e4m3 (torch.float8_e4m3fn, round to nearest even), and the matching dequantisation.
+    x (B, L, H, D) -> fp32 tensor of the values the kernel multiplies.  The reference has no fp8
+    path (its attention is bf16, modeling_qwen2.py:196-244): this restates the QUANTISER of the
+    opt-in variant so that its MFMA / softmax arithmetic can be checked separately from the
+    quantisation error."""
+    xf = x.float()
+    amax = xf.abs().amax(dim=(1, 3), keepdim=True)
+    qs = torch.where(amax > 0, qmax / amax, torch.ones_like(amax))
+    q8 = (xf * qs).to(torch.float8_e4m3fn).float()
+    return q8 / qs
+
+
 # --------------------------------------------------------------------------- T1
 def uniform_keep_indices_ref(n_tokens: int, keep: int) -> torch.Tensor:
     """`torch.linspace(0, image_tokens-1, keep_length, dtype=torch.long)` (:1946-1953)

@@ -1,0 +1,499 @@
+// A1 (BASELINE config 5): fused softmax attention forward with FP8 (OCP e4m3) MFMA operands.
+//
+// The reference's attention arithmetic is bf16 (flash-attn / SDPA: modeling_qwen2.py:196-244,
+// modeling_nano.py:1198-1209); BASELINE.json's fifth configuration asks for the QK^T / PV
+// products on the fp8 matrix path of CDNA4, v_mfma_f32_32x32x64_f8f6f4 (K = 64 per instruction,
+// twice the bf16 rate).  This is that variant: opt-in, fp32 accumulation and fp32 softmax,
+// inputs and output stay bf16 at the boundary.
+//
+//   pre-pass (3 small kernels, ~1 % of the attention time at 131 k tokens):
+//     amax   per (batch, head) max |x| of q, k, v  ->  one scale per head and tensor
+//     quant  q, k -> e4m3 rows of 128 bytes (head_dim zero-padded to 128); K in 64-key tiles
+//            whose 16-byte chunks are already XOR-swizzled for the conflict-free row reads
+//     quant  v -> e4m3, TRANSPOSED per 64-key tile ([d][key], 64-byte rows) with the keys of a
+//            tile permuted into the order the P^T accumulator registers hold them, so that the
+//            A operand of O^T += V^T P^T is a plain 32-byte row read (no transposing LDS read
+//            exists for the byte layout the accumulators dictate)
+//   main kernel: 8 waves x 32 query rows, S^T = K Q^T with keys on the MFMA rows (softmax
+//     statistics per lane), P^T accumulators -> e4m3 in registers (v_cvt_pk_fp8_f32) as the B
+//     operand of the PV product; K / V^T stages of 128 keys by LDS-DMA (linear 1 KiB pieces: the
+//     pre-pass wrote the LDS image) into a ring of 3, counted vmcnt, one barrier per stage.
+//   P is scaled by 2^8 before the e4m3 rounding (max 256 < 448; values down to 2^-17 of the row
+//   maximum survive), the row sum is kept in fp32 of the unrounded values.
+#include "ssd_common.hpp"
+
+namespace {
+
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int F8_DP = 128;                        // bytes per quantised q / k row (padded head_dim)
+constexpr int F8_TILE = 64;                       // keys per tile = one K=64 MFMA step of PV
+constexpr int F8_TPS = 2;                         // tiles per LDS stage
+constexpr int F8_KTILE_B = F8_TILE * F8_DP;       // 8 KiB  [64 keys][128 B]
+constexpr int F8_VTILE_B = F8_DP * F8_TILE;       // 8 KiB  [128 d][64 keys]
+constexpr int F8_STAGE_KEYS = F8_TPS * F8_TILE;   // 128
+constexpr float F8_QMAX = 440.f;                  // quantisation target of max |x| (e4m3 max 448)
+
+__device__ __forceinline__ float f8_quant_scale(float amax) { return amax > 0.f ? F8_QMAX / amax : 1.f; }
+__device__ __forceinline__ float f8_dequant_scale(float amax) { return amax > 0.f ? amax / F8_QMAX : 1.f; }
+
+__device__ __forceinline__ f32x16 mfma_f8(i32x8 a, i32x8 b, f32x16 c) {
+  // scale operands 0 select the plain (unscaled) v_mfma_f32_32x32x64_f8f6f4; cbsz = blgp = 0: e4m3
+  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 0, 0, 0);
+}
+
+// ------------------------------------------------------------------ pre-pass: amax
+// grid (ceil(L/64), H, B); 256 threads = 16 rows x 16 chunks of 8 elements, 4 row groups
+template <typename T>
+__global__ __launch_bounds__(256) void fp8_amax_kernel(const T* __restrict__ x, unsigned* __restrict__ amax,
+                                                       int L, int H, int D, int64_t sb, int64_t sl,
+                                                       int64_t sh) {
+  typedef typename Vec16<T>::type vec_t;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int chunk = threadIdx.x & 15, r0 = threadIdx.x >> 4;
+  const T* base = x + (int64_t)b * sb + (int64_t)h * sh;
+  float m = 0.f;
+  if (chunk * 8 < D) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = blockIdx.x * 64 + i * 16 + r0;
+      if (row < L) {
+        const vec_t v = *(const vec_t*)(base + (int64_t)row * sl + chunk * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(to_f32(v[j])));
+      }
+    }
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(&amax[(int64_t)b * H + h], __float_as_uint(m));
+}
+
+__device__ __forceinline__ int pack4_fp8(float a, float b, float c, float d) {
+  int w = 0;
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+  return w;
+}
+
+// 32 consecutive elements [32 part, 32 part + 32) of one row -> 32 e4m3 bytes (zeros past D / past L)
+template <typename T>
+__device__ __forceinline__ void quant32(const T* __restrict__ row, bool valid, int part, int D, float qs,
+                                        i32x4& lo, i32x4& hi) {
+  typedef typename Vec16<T>::type vec_t;
+  float f[32];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int d0 = 32 * part + 8 * c;
+    if (valid && d0 < D) {
+      const vec_t v = *(const vec_t*)(row + d0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[8 * c + j] = to_f32(v[j]) * qs;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[8 * c + j] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    lo[w] = pack4_fp8(f[4 * w], f[4 * w + 1], f[4 * w + 2], f[4 * w + 3]);
+    hi[w] = pack4_fp8(f[16 + 4 * w], f[16 + 4 * w + 1], f[16 + 4 * w + 2], f[16 + 4 * w + 3]);
+  }
+}
+
+// ------------------------------------------------------------------ pre-pass: q / k rows
+// grid (ceil(L/64), H, B), 256 threads: thread = (row r of the 64-row block, 32-element part).
+// TILED = false: out[b][h][row][128]  (q).
+// TILED = true : out[b][h][tile][r][128] with 16-byte chunk c of row r stored at chunk
+//                c ^ ((r >> 1) & 7), rows past L zero (k; `ntile` tiles per head).
+template <typename T, bool TILED>
+__global__ __launch_bounds__(256) void fp8_quant_rows_kernel(const T* __restrict__ x,
+                                                             const unsigned* __restrict__ amax,
+                                                             unsigned char* __restrict__ out, int L, int H,
+                                                             int Hmax, int D, int ntile, int64_t sb,
+                                                             int64_t sl, int64_t sh) {
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int r = threadIdx.x >> 2, part = threadIdx.x & 3;
+  const int row = blockIdx.x * 64 + r;
+  const float qs = f8_quant_scale(__uint_as_float(amax[(int64_t)b * Hmax + h]));
+  i32x4 lo, hi;
+  quant32<T>(x + (int64_t)b * sb + (int64_t)h * sh + (int64_t)row * sl, row < L, part, D, qs, lo, hi);
+  if (TILED) {
+    unsigned char* t = out + ((((int64_t)b * H + h) * ntile + blockIdx.x) * F8_TILE + r) * F8_DP;
+    const int sw = (r >> 1) & 7;
+    *(i32x4*)(t + (((2 * part) ^ sw) << 4)) = lo;
+    *(i32x4*)(t + (((2 * part + 1) ^ sw) << 4)) = hi;
+  } else if (row < L) {
+    unsigned char* t = out + (((int64_t)b * H + h) * L + row) * F8_DP + 32 * part;
+    *(i32x4*)t = lo;
+    *(i32x4*)(t + 16) = hi;
+  }
+}
+
+// ------------------------------------------------------------------ pre-pass: v, transposed
+// grid (ntile, H, B), 256 threads.  out[b][h][tile][d][64]: byte 32 hh + i of row d holds
+// V[key(hh, i)][d], key(hh, i) = 32 (i >> 4) + 4 hh + (i & 3) + 8 ((i & 15) >> 2) — the key order of
+// the P^T accumulator registers of lane half hh; 16-byte chunk c of row d sits at c ^ ((d >> 2) & 3).
+template <typename T>
+__global__ __launch_bounds__(256) void fp8_quant_vt_kernel(const T* __restrict__ v,
+                                                           const unsigned* __restrict__ amax,
+                                                           unsigned char* __restrict__ out, int L, int H,
+                                                           int Hmax, int D, int ntile, int64_t sb,
+                                                           int64_t sl, int64_t sh) {
+  __shared__ __attribute__((aligned(16))) unsigned char tr[F8_DP * F8_TILE];
+  const int b = blockIdx.z, h = blockIdx.y, tile = blockIdx.x;
+  const int kk = threadIdx.x >> 2, part = threadIdx.x & 3;
+  const int key = tile * F8_TILE + kk;
+  const float qs = f8_quant_scale(__uint_as_float(amax[(int64_t)b * Hmax + h]));
+  i32x4 lo, hi;
+  quant32<T>(v + (int64_t)b * sb + (int64_t)h * sh + (int64_t)key * sl, key < L, part, D, qs, lo, hi);
+  // position of this key inside a V^T row
+  const int w = kk & 31;
+  const int pos = 32 * ((w >> 2) & 1) + 16 * (kk >> 5) + (w & 3) + 4 * (w >> 3);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    tr[(32 * part + j) * F8_TILE + pos] = (unsigned char)(lo[j >> 2] >> (8 * (j & 3)));
+    tr[(32 * part + 16 + j) * F8_TILE + pos] = (unsigned char)(hi[j >> 2] >> (8 * (j & 3)));
+  }
+  __syncthreads();
+  // 32 bytes per thread: row d = tid / 2, chunks 2 (tid % 2), +1
+  const int d = threadIdx.x >> 1, c0 = 2 * (threadIdx.x & 1);
+  unsigned char* t = out + ((((int64_t)b * H + h) * ntile + tile) * F8_DP + d) * F8_TILE;
+  const int sw = (d >> 2) & 3;
+  *(i32x4*)(t + ((c0 ^ sw) << 4)) = *(const i32x4*)(tr + d * F8_TILE + c0 * 16);
+  *(i32x4*)(t + (((c0 + 1) ^ sw) << 4)) = *(const i32x4*)(tr + d * F8_TILE + (c0 + 1) * 16);
+}
+
+// ------------------------------------------------------------------ main kernel
+struct Fp8Args {
+  const unsigned char *qq, *kq, *vt;
+  const unsigned* amax;      // [3][B][Hmax] float bits: q, k, v
+  void* o;
+  float* lse;
+  int B, Lq, Lk, Hq, Hkv, Hmax, D, nst;
+  int64_t osb, osl, osh;
+  float scale_log2;          // softmax_scale * log2(e)
+  int causal;
+};
+
+template <typename T, int DT, int NW>
+__global__ __launch_bounds__(NW * 64) void flash_fwd_fp8_kernel(Fp8Args a) {
+  constexpr int NS = 3;
+  constexpr int KPART = F8_TPS * F8_KTILE_B;         // 16 KiB
+  constexpr int VPART = F8_TPS * F8_VTILE_B;         // 16 KiB
+  constexpr int STAGE_B = KPART + VPART;             // 32 KiB
+  constexpr int NPC = STAGE_B / 1024;                // 1 KiB DMA pieces per stage
+  constexpr int PPW = NPC / NW;
+  static_assert(NPC % NW == 0, "pieces must divide over the waves");
+  constexpr int QB = NW * 32;
+  typedef typename Vec16<T>::type vec_t;
+  extern __shared__ __attribute__((aligned(16))) unsigned char f8_smem[];
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int r = lane & 31, hh = lane >> 5;
+  const int qblk = a.causal ? (gridDim.x - 1 - blockIdx.x) : blockIdx.x;   // causal: heaviest first
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int hk = h / (a.Hq / a.Hkv);
+  const int q0 = qblk * QB + wave * 32;
+  const int qrow = q0 + r;
+  const int shift = a.Lk - a.Lq;                     // bottom-right causal alignment
+
+  const float aq = __uint_as_float(a.amax[((int64_t)0 * a.B + b) * a.Hmax + h]);
+  const float ak = __uint_as_float(a.amax[((int64_t)1 * a.B + b) * a.Hmax + hk]);
+  const float av = __uint_as_float(a.amax[((int64_t)2 * a.B + b) * a.Hmax + hk]);
+  const float c = a.scale_log2 * f8_dequant_scale(aq) * f8_dequant_scale(ak);   // raw accumulator -> log2 domain
+
+  // Q^T fragments (B operand): lane (r, hh) holds q~[qrow][64 s + 32 hh + 0..31]
+  i32x8 qf[2];
+  {
+    const unsigned char* qp = a.qq + (((int64_t)b * a.Hq + h) * a.Lq + min(qrow, a.Lq - 1)) * F8_DP + 32 * hh;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      i32x4 lo = {0, 0, 0, 0}, hi = lo;
+      if (qrow < a.Lq) {
+        lo = *(const i32x4*)(qp + 64 * s);
+        hi = *(const i32x4*)(qp + 64 * s + 16);
+      }
+      qf[s] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+  }
+
+  f32x16 oacc[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) oacc[dt][i] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int wg_q_last = min(qblk * QB + QB, a.Lq) - 1;
+  int k_end = a.causal ? min(a.Lk, wg_q_last + shift + 1) : a.Lk;
+  if (k_end < 0) k_end = 0;
+  const int nstages = (k_end + F8_STAGE_KEYS - 1) / F8_STAGE_KEYS;
+
+  const unsigned char* kbase_g = a.kq + ((int64_t)b * a.Hkv + hk) * a.nst * KPART;
+  const unsigned char* vbase_g = a.vt + ((int64_t)b * a.Hkv + hk) * a.nst * VPART;
+  auto issue_stage = [&](int st) {
+    const int slot = st % NS;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int pc = wave + NW * i;               // wave-uniform
+      const bool isK = pc < KPART / 1024;
+      const void* src = ssdk::uniform_ptr(isK ? (const void*)(kbase_g + (int64_t)st * KPART + pc * 1024)
+                                              : (const void*)(vbase_g + (int64_t)st * VPART + (pc - KPART / 1024) * 1024));
+      ssdk::glds16(src, (unsigned)(lane * 16), ssdk::lds_addr_of(f8_smem + slot * STAGE_B + pc * 1024));
+    }
+  };
+
+  // fragment read offsets inside a stage
+  const int k_rd = r * F8_DP;                       // + 32-key subtile * 4096, chunk (4 s + 2 hh + e) ^ ksw
+  const int ksw = (r >> 1) & 7;
+  const int v_rd = r * F8_TILE;                     // + d-tile * 2048, chunk (2 hh + e) ^ vsw
+  const int vsw = (r >> 2) & 3;
+
+  if (nstages > 0) issue_stage(0);
+  if (nstages > 1) issue_stage(1);
+  if (nstages > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  for (int st = 0; st < nstages; ++st) {
+    const bool ahead = st + 2 < nstages;
+    if (ahead) issue_stage(st + 2);                 // slot (st - 1) % 3: every wave has left it
+    const unsigned char* sK = f8_smem + (st % NS) * STAGE_B;
+    const unsigned char* sV = sK + KPART;
+#pragma unroll
+    for (int u = 0; u < F8_TPS; ++u) {
+      const int kbase = st * F8_STAGE_KEYS + u * F8_TILE;
+      // wave-uniform skips: past the keys this workgroup needs / above this wave's causal diagonal
+      const bool active = kbase < k_end && !(a.causal && kbase > q0 + 31 + shift);
+      if (!active) continue;
+      const unsigned char* cK = sK + u * F8_KTILE_B;
+      const unsigned char* cV = sV + u * F8_VTILE_B;
+      // ---- S^T = K~ . Q~^T: two 32-key subtiles x two 64-wide k-steps
+      i32x8 kf[2][2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const unsigned char* p = cK + t * (32 * F8_DP) + k_rd;
+          const i32x4 lo = *(const i32x4*)(p + (((4 * s + 2 * hh) ^ ksw) << 4));
+          const i32x4 hi = *(const i32x4*)(p + (((4 * s + 2 * hh + 1) ^ ksw) << 4));
+          kf[t][s] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+      f32x16 sacc[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sacc[t][i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) sacc[t] = mfma_f8(kf[t][s], qf[s], sacc[t]);
+      }
+      // V^T fragments in flight under the softmax
+      i32x8 vf[DT];
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const unsigned char* p = cV + dt * (32 * F8_TILE) + v_rd;
+        const i32x4 lo = *(const i32x4*)(p + (((2 * hh) ^ vsw) << 4));
+        const i32x4 hi = *(const i32x4*)(p + (((2 * hh + 1) ^ vsw) << 4));
+        vf[dt] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+      // ---- mask, online softmax in the log2 domain (raw scores scaled by c > 0)
+      const bool need_mask = (kbase + F8_TILE > a.Lk) || (a.causal && kbase + F8_TILE - 1 > q0 + shift);
+      if (need_mask) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int key = kbase + 32 * t + (i & 3) + 8 * (i >> 2) + 4 * hh;
+            const bool ok = key < a.Lk && (!a.causal || key <= qrow + shift);
+            sacc[t][i] = ok ? sacc[t][i] : -INFINITY;
+          }
+      }
+      float tmax = -INFINITY;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) tmax = fmaxf(fmaxf(tmax, sacc[t][i]), sacc[t][i + 1]);
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float m_new = fmaxf(m_run, tmax * c);
+      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;   // nothing visible yet: any finite base
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+      const float off = 8.f - m_use;                            // p~ = 2^8 p: e4m3 keeps 2^-17 .. 1 of the row max
+      float psum = 0.f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[t][i], c, off));
+          sacc[t][i] = p;
+          psum += p;
+        }
+      l_run = l_run * alpha + psum;
+      if (__builtin_amdgcn_ballot_w64(m_new > m_run)) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) oacc[dt][i] *= alpha;
+      }
+      m_run = m_new;
+      // ---- P~^T -> e4m3: byte i of this lane = key 32 (i >> 4) + (i & 3) + 8 ((i & 15) >> 2) + 4 hh
+      i32x8 pf;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) {
+        const int t = w >> 2, j0 = 4 * (w & 3);
+        pf[w] = pack4_fp8(sacc[t][j0], sacc[t][j0 + 1], sacc[t][j0 + 2], sacc[t][j0 + 3]);
+      }
+      // ---- O^T += V~^T . P~^T, one K = 64 step per 32-row d-tile
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) oacc[dt] = mfma_f8(vf[dt], pf, oacc[dt]);
+    }
+    if (ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");   // stage st+1 landed, st+2 in flight
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+
+  // ---- epilogue: O = sv * O~ / l~ (the 2^8 of p~ cancels), bf16 rows
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = l_tot > 0.f ? f8_dequant_scale(av) / l_tot : 0.f;
+  if (qrow < a.Lq) {
+    typedef T v4 __attribute__((ext_vector_type(4)));
+    T* op = (T*)a.o + (int64_t)b * a.osb + (int64_t)qrow * a.osl + (int64_t)h * a.osh;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = dt * 32 + 8 * g + 4 * hh;
+        if (d0 < a.D) {
+          v4 pk;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) pk[j] = from_f32<T>(oacc[dt][4 * g + j] * inv);
+          *(v4*)(op + d0) = pk;
+        }
+      }
+    if (a.lse && hh == 0) {
+      // natural-log sum-exp of the scaled scores: m is in the log2 domain, l~ carries the factor 2^8
+      const float lse = l_tot > 0.f ? ((m_run - 8.f) * 0.6931471805599453f + logf(l_tot)) : -INFINITY;
+      a.lse[((int64_t)b * a.Hq + h) * a.Lq + qrow] = lse;
+    }
+  }
+}
+
+struct Fp8Layout {
+  size_t amax, qq, kq, vt, total;
+  int nst, hmax;
+};
+Fp8Layout fp8_layout(int B, int Lq, int Lk, int Hq, int Hkv) {
+  Fp8Layout l;
+  l.nst = (Lk + F8_STAGE_KEYS - 1) / F8_STAGE_KEYS;
+  l.hmax = Hq > Hkv ? Hq : Hkv;
+  auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+  l.amax = 0;
+  l.qq = up((size_t)3 * B * l.hmax * sizeof(unsigned));
+  l.kq = l.qq + up((size_t)B * Hq * Lq * F8_DP);
+  l.vt = l.kq + up((size_t)B * Hkv * l.nst * F8_TPS * F8_KTILE_B);
+  l.total = l.vt + up((size_t)B * Hkv * l.nst * F8_TPS * F8_VTILE_B);
+  return l;
+}
+
+template <typename T, int DT>
+int launch_fp8(const Fp8Args& a, hipStream_t st) {
+  constexpr int lds = 3 * F8_TPS * (F8_KTILE_B + F8_VTILE_B);   // 96 KiB
+  hipError_t e;
+  if (a.Lq > 128) {
+    e = hipFuncSetAttribute((const void*)flash_fwd_fp8_kernel<T, DT, 8>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess)
+      flash_fwd_fp8_kernel<T, DT, 8><<<dim3((a.Lq + 255) / 256, a.Hq, a.B), 512, lds, st>>>(a);
+  } else {
+    e = hipFuncSetAttribute((const void*)flash_fwd_fp8_kernel<T, DT, 4>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess)
+      flash_fwd_fp8_kernel<T, DT, 4><<<dim3((a.Lq + 127) / 128, a.Hq, a.B), 256, lds, st>>>(a);
+  }
+  if (e != hipSuccess) {
+    tv_set_error("flash_attn_fp8: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    return TV_ERR_LAUNCH;
+  }
+  TV_LAUNCH_CHECK();
+}
+
+template <typename T>
+int run_fp8(const void* q, const void* k, const void* v, Fp8Args a, int64_t qsb, int64_t qsl, int64_t qsh,
+            int64_t ksb, int64_t ksl, int64_t ksh, int64_t vsb, int64_t vsl, int64_t vsh,
+            unsigned char* ws, const Fp8Layout& lay, hipStream_t st) {
+  unsigned* amax = (unsigned*)(ws + lay.amax);
+  unsigned char* qq = ws + lay.qq;
+  unsigned char* kq = ws + lay.kq;
+  unsigned char* vt = ws + lay.vt;
+  (void)hipMemsetAsync(amax, 0, (size_t)3 * a.B * lay.hmax * sizeof(unsigned), st);
+  const size_t per = (size_t)a.B * lay.hmax;
+  const int ntile = lay.nst * F8_TPS;
+  fp8_amax_kernel<T><<<dim3((a.Lq + 63) / 64, a.Hq, a.B), 256, 0, st>>>((const T*)q, amax, a.Lq, lay.hmax, a.D, qsb, qsl, qsh);
+  fp8_amax_kernel<T><<<dim3((a.Lk + 63) / 64, a.Hkv, a.B), 256, 0, st>>>((const T*)k, amax + per, a.Lk, lay.hmax, a.D, ksb, ksl, ksh);
+  fp8_amax_kernel<T><<<dim3((a.Lk + 63) / 64, a.Hkv, a.B), 256, 0, st>>>((const T*)v, amax + 2 * per, a.Lk, lay.hmax, a.D, vsb, vsl, vsh);
+  fp8_quant_rows_kernel<T, false><<<dim3((a.Lq + 63) / 64, a.Hq, a.B), 256, 0, st>>>(
+      (const T*)q, amax, qq, a.Lq, a.Hq, lay.hmax, a.D, 0, qsb, qsl, qsh);
+  fp8_quant_rows_kernel<T, true><<<dim3(ntile, a.Hkv, a.B), 256, 0, st>>>(
+      (const T*)k, amax + per, kq, a.Lk, a.Hkv, lay.hmax, a.D, ntile, ksb, ksl, ksh);
+  fp8_quant_vt_kernel<T><<<dim3(ntile, a.Hkv, a.B), 256, 0, st>>>(
+      (const T*)v, amax + 2 * per, vt, a.Lk, a.Hkv, lay.hmax, a.D, ntile, vsb, vsl, vsh);
+  a.qq = qq; a.kq = kq; a.vt = vt; a.amax = amax; a.nst = lay.nst; a.Hmax = lay.hmax;
+  const int D = a.D;
+  if (D <= 64) return launch_fp8<T, 2>(a, st);
+  if (D <= 96) return launch_fp8<T, 3>(a, st);
+  return launch_fp8<T, 4>(a, st);
+}
+
+}  // namespace
+
+extern "C" size_t tv_flash_attn_fp8_workspace_bytes(int batch, int seqlen_q, int seqlen_k, int nheads_q,
+                                                    int nheads_kv) {
+  if (batch <= 0 || seqlen_q < 0 || seqlen_k < 0 || nheads_q <= 0 || nheads_kv <= 0) return 0;
+  return fp8_layout(batch, seqlen_q, seqlen_k, nheads_q, nheads_kv).total;
+}
+
+extern "C" int tv_flash_attn_fp8_fwd(const void* q, const void* k, const void* v, void* o, void* lse,
+                                     int batch, int seqlen_q, int seqlen_k, int nheads_q, int nheads_kv,
+                                     int headdim, int64_t q_stride_b, int64_t q_stride_l, int64_t q_stride_h,
+                                     int64_t k_stride_b, int64_t k_stride_l, int64_t k_stride_h,
+                                     int64_t v_stride_b, int64_t v_stride_l, int64_t v_stride_h,
+                                     int64_t o_stride_b, int64_t o_stride_l, int64_t o_stride_h,
+                                     float softmax_scale, int causal, int dtype, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  TV_CHECK_ARG((seqlen_q == 0 || (q && o)) && (seqlen_q == 0 || seqlen_k == 0 || (k && v)), "flash_attn_fp8: null pointer");
+  TV_CHECK_ARG(batch > 0 && seqlen_q >= 0 && seqlen_k >= 0 && nheads_q > 0 && nheads_kv > 0 &&
+                   nheads_q % nheads_kv == 0 && headdim > 0 && softmax_scale > 0.f,
+               "flash_attn_fp8: bad sizes (or non-positive softmax scale)");
+  if (dtype != TV_BF16 && dtype != TV_F16) TV_UNSUPPORTED("flash_attn_fp8: dtype must be bf16/f16");
+  if (headdim % 8 || headdim > 128) TV_UNSUPPORTED("flash_attn_fp8: headdim %d (multiple of 8, <= 128)", headdim);
+  const int64_t strides[] = {q_stride_b, q_stride_l, q_stride_h, k_stride_b, k_stride_l,
+                             k_stride_h, v_stride_b, v_stride_l, v_stride_h};
+  for (int64_t s : strides)
+    if (s % 8) TV_UNSUPPORTED("flash_attn_fp8: q/k/v strides must be multiples of 8 elements");
+  if (o_stride_b % 4 || o_stride_l % 4 || o_stride_h % 4 || ((uintptr_t)o & 7))
+    TV_UNSUPPORTED("flash_attn_fp8: o strides must be multiples of 4 elements");
+  if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15))
+    TV_UNSUPPORTED("flash_attn_fp8: q/k/v must be 16-byte aligned");
+  if (seqlen_q == 0) return TV_OK;
+  if (seqlen_k == 0) TV_UNSUPPORTED("flash_attn_fp8: no keys");
+  const Fp8Layout lay = fp8_layout(batch, seqlen_q, seqlen_k, nheads_q, nheads_kv);
+  if (!workspace || workspace_bytes < lay.total || ((uintptr_t)workspace & 255)) {
+    tv_set_error("flash_attn_fp8: workspace of %zu bytes (256-byte aligned) required, got %zu", lay.total,
+                 workspace_bytes);
+    return TV_ERR_WORKSPACE;
+  }
+  Fp8Args a;
+  a.o = o; a.lse = (float*)lse;
+  a.B = batch; a.Lq = seqlen_q; a.Lk = seqlen_k; a.Hq = nheads_q; a.Hkv = nheads_kv; a.D = headdim;
+  a.osb = o_stride_b; a.osl = o_stride_l; a.osh = o_stride_h;
+  a.scale_log2 = softmax_scale * 1.4426950408889634f;
+  a.causal = causal;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TV_BF16)
+    return run_fp8<bf16_t>(q, k, v, a, q_stride_b, q_stride_l, q_stride_h, k_stride_b, k_stride_l, k_stride_h,
+                           v_stride_b, v_stride_l, v_stride_h, (unsigned char*)workspace, lay, st);
+  return run_fp8<f16_t>(q, k, v, a, q_stride_b, q_stride_l, q_stride_h, k_stride_b, k_stride_l, k_stride_h,
+                        v_stride_b, v_stride_l, v_stride_h, (unsigned char*)workspace, lay, st);
+}

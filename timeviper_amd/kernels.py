@@ -334,6 +334,53 @@ def ssd_scan_set_impl(impl: int) -> None:
 
 
 # ------------------------------------------------------------------ attention
+_ATTN_FP8 = {"on": False, "min_keys": 256}
+
+
+class fp8_attention:
+    """Context manager / switch: inside it `flash_attn_func` (and everything built on it) runs the
+    QK^T / PV products on the FP8 MFMA path (`tv_flash_attn_fp8_fwd`) — BASELINE config 5.  Off by
+    default: the reference's attention arithmetic is bf16.  Short key sequences (< `min_keys`,
+    e.g. the single-query decode step) stay on the bf16 kernel."""
+
+    def __init__(self, on: bool = True, min_keys: int = 256):
+        self.new = {"on": bool(on), "min_keys": int(min_keys)}
+
+    def __enter__(self):
+        self.old = dict(_ATTN_FP8)
+        _ATTN_FP8.update(self.new)
+        return self
+
+    def __exit__(self, *exc):
+        _ATTN_FP8.update(self.old)
+
+
+def flash_attn_fp8_func(q, k, v, softmax_scale=None, causal=False, return_lse=False):
+    """`flash_attn_func` with e4m3 MFMA operands (per-head scales, fp32 accumulation / softmax)."""
+    _gpu(q, k, v)
+    B, Lq, Hq, D = q.shape
+    Lk, Hkv = k.shape[1], k.shape[2]
+    fix = lambda t: t if t.stride(-1) == 1 else t.contiguous()
+    q, k, v = fix(q), fix(k), fix(v)
+    if D % 8 or D > 128:
+        raise TimeViperHipError(f"flash_attn_fp8_func: head_dim {D} must be a multiple of 8, <= 128")
+    for t in (q, k, v):
+        if any(s % 8 for s in t.stride()[:3]) or t.data_ptr() % 16:
+            raise TimeViperHipError("flash_attn_fp8_func: strides must be multiples of 8 elements")
+    scale = 1.0 / math.sqrt(D) if softmax_scale is None else float(softmax_scale)
+    o = torch.empty((B, Lq, Hq, D), dtype=q.dtype, device=q.device)
+    lse = torch.empty((B, Hq, Lq), dtype=torch.float32, device=q.device) if return_lse else None
+    lib = _capi.lib()
+    ws_bytes = lib.tv_flash_attn_fp8_workspace_bytes(B, Lq, Lk, Hq, Hkv)
+    ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=q.device)
+    check(lib.tv_flash_attn_fp8_fwd(
+        _p(q), _p(k), _p(v), _p(o), _p(lse), B, Lq, Lk, Hq, Hkv, D,
+        q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
+        v.stride(0), v.stride(1), v.stride(2), o.stride(0), o.stride(1), o.stride(2),
+        scale, int(bool(causal)), _dt(q), _p(ws), ws_bytes, _stream()), "tv_flash_attn_fp8_fwd")
+    return (o, lse) if return_lse else o
+
+
 def flash_attn_func(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False,
                     return_lse=False):
     """q (B,Lq,Hq,D), k/v (B,Lk,Hkv,D) -> (B,Lq,Hq,D).  GQA without repeat_kv;
@@ -343,6 +390,8 @@ def flash_attn_func(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False,
     _gpu(q, k, v)
     B, Lq, Hq, D = q.shape
     Lk, Hkv = k.shape[1], k.shape[2]
+    if _ATTN_FP8["on"] and Lk >= _ATTN_FP8["min_keys"] and D <= 128 and q.dtype in (torch.bfloat16, torch.float16):
+        return flash_attn_fp8_func(q, k, v, softmax_scale, causal, return_lse)
     fix = lambda t: t if t.stride(-1) == 1 else t.contiguous()
     q, k, v = fix(q), fix(k), fix(v)
     if D % 8:
