@@ -164,6 +164,27 @@ int tv_ssd_scan_fwd(const void* x, const void* dt, const void* A,
                     int group_map, void* workspace, size_t workspace_bytes,
                     void* stream);
 
+/* Carried-in state correction ("sequence sharding"; the Y_off term of
+ * modeling_nano.py:833-836 with the decay taken from the range start): a shard — another GPU's
+ * tokens, or a later segment of one GPU's sequence — is scanned from a ZERO state by
+ * tv_ssd_scan_fwd; once the state entering it is known its outputs are completed in place,
+ *   y_t += exp(sum_{j<=t} dt_j A_h) * C_t . state_in[h]        (dt discretised as in tv_ssd_scan_fwd)
+ * y (B,L,H,P) `dtype`, read-modify-write; dt (B,L,H) raw; Cm (B,L,G,N) with a group stride;
+ * state_in (B,H,P,N) fp32 contiguous.  The factor reaches exactly 0 in fp32 after the head's
+ * decay horizon and the kernel stops there, so the cost is that horizon, not L.
+ * bf16, d_state 128, headdim % 8 == 0 (<= 128).  workspace:
+ * tv_ssd_state_correction_workspace_bytes() bytes (per-chunk log-decays and their prefix). */
+size_t tv_ssd_state_correction_workspace_bytes(int batch, int seqlen, int nheads);
+int tv_ssd_state_correction(void* y, const void* dt, const void* A, const void* Cm,
+                            const void* dt_bias, const void* state_in, int batch,
+                            int seqlen, int nheads, int headdim, int ngroups,
+                            int dstate, int64_t y_stride_b, int64_t y_stride_l,
+                            int64_t dt_stride_b, int64_t dt_stride_l,
+                            int64_t c_stride_b, int64_t c_stride_l,
+                            int64_t c_stride_g, int dtype, int dt_softplus,
+                            float dt_min, float dt_max, int group_map,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
 /* Force a particular implementation (testing/benchmarking):
  * 0 = auto (the slice march where it applies and a workspace is given, else the
  *     chunk march, else the generic kernel),

@@ -40,6 +40,23 @@ def _scan(x, dt, A, B, C, chunk_size=None, D=None, z=None, dt_bias=None, initial
     return out[0] if len(out) == 1 else out
 
 
+def _state_corr(y, dt, A, C, state_in, dt_bias=None, dt_softplus=False, dt_limit=(0.0, float("inf")),
+                group_map="block"):
+    """y_t += exp(cs_t) C_t . S_in, from the definition"""
+    Bsz, L, H, P = y.shape
+    G = C.shape[2]
+    d = dt.float() + (0.0 if dt_bias is None else dt_bias.float())
+    if dt_softplus:
+        d = torch.nn.functional.softplus(d)
+    d = d.clamp(dt_limit[0], dt_limit[1])
+    cs = torch.cumsum(d * A.float(), dim=1)                                   # (B, L, H)
+    gidx = (torch.arange(H) % G) if group_map == "tile" else (torch.arange(H) // (H // G))
+    Ch = C.float()[:, :, gidx]                                                # (B, L, H, N)
+    corr = torch.einsum("blhn,bhpn->blhp", Ch, state_in.float()) * torch.exp(cs)[..., None]
+    y.copy_((y.float() + corr).to(y.dtype))
+    return y
+
+
 def _rms(x, weight, eps, residual=None, return_sum=False):
     s = x if residual is None else (x + residual)
     y = R.rmsnorm_ref(s, weight, eps).to(x.dtype)
@@ -155,6 +172,7 @@ def cpu_kernels():
         "tome_merge_round": RV.tome_merge_round_ref,
         "relu2": lambda x, inplace=False: torch.square(torch.relu(x)),
         "causal_conv1d_update": _conv_update, "selective_state_update": _state_update,
+        "ssd_state_correction": _state_corr,
     }
     saved = {k: getattr(K, k) for k in patches}
     for k, v in patches.items():

@@ -108,7 +108,7 @@ def test_fp8_switch_routes_flash_attn_func(K):
     k = torch.randn(1, 512, 2, 128, device=DEV, generator=g).bfloat16()
     v = torch.randn(1, 512, 2, 128, device=DEV, generator=g).bfloat16()
     o16 = K.flash_attn_func(q, k, v, causal=True)
-    with K.fp8_attention():
+    with K.fp8_attention(min_keys=256):
         o8 = K.flash_attn_func(q, k, v, causal=True)
         assert torch.equal(o8, K.flash_attn_fp8_func(q, k, v, causal=True))
         short = K.flash_attn_func(q[:, :1], k[:, :100], v[:, :100], causal=True)     # 100 keys < min_keys: bf16

@@ -268,6 +268,38 @@ def test_selective_state_update(K):
     close(sd, fin_ref, 1e-4, 1e-5)
 
 
+@pytest.mark.parametrize("L,H,P,G,slow", [(300, 8, 40, 2, False), (1000, 16, 80, 8, True), (64, 4, 64, 1, True),
+                                          (5, 8, 80, 4, False), (2000, 8, 80, 8, False)])
+def test_ssd_state_correction_completes_a_zero_state_scan(K, L, H, P, G, slow):
+    """y(scan from S_in) = y(scan from 0) + exp(cs_t) C_t . S_in: the in-place
+    correction on top of the zero-state scan against the oracle recurrence started from S_in.
+    `slow`: heads that barely decay (the term stays alive over the whole range); otherwise most heads
+    forget within a few chunks and the kernel's early exit is what runs."""
+    g = torch.Generator().manual_seed(L + H)
+    N = 128
+    x = torch.randn(1, L, H, P, generator=g).bfloat16()
+    dt = (torch.randn(1, L, H, generator=g) * 0.5 - (4.0 if slow else 0.0)).bfloat16()
+    A = -(torch.rand(H, generator=g) * (0.5 if slow else 15) + (0.01 if slow else 1))
+    Bm = (torch.randn(1, L, G, N, generator=g) * 0.5).bfloat16()
+    Cm = (torch.randn(1, L, G, N, generator=g) * 0.5).bfloat16()
+    D = torch.rand(H, generator=g) + 0.5
+    dtb = torch.full((H,), -1.0)
+    S0 = torch.randn(1, H, P, N, generator=g)
+    y_ref, _, _ = R.ssd_recurrence_ref(x.float(), dt.float(), A, Bm.float(), Cm.float(), D=D, dt_bias=dtb,
+                                       initial_states=S0)
+    d = lambda t: t.to(DEV)
+    y0 = K.mamba_chunk_scan_combined(d(x), d(dt), d(A), d(Bm), d(Cm), chunk_size=64, D=d(D), dt_bias=d(dtb),
+                                     dt_softplus=True)
+    y_direct = K.mamba_chunk_scan_combined(d(x), d(dt), d(A), d(Bm), d(Cm), chunk_size=64, D=d(D), dt_bias=d(dtb),
+                                           dt_softplus=True, initial_states=d(S0))
+    y = K.ssd_state_correction(y0.clone(), d(dt), d(A), d(Cm), d(S0), dt_bias=d(dtb), dt_softplus=True)
+    assert y.data_ptr() != y0.data_ptr()
+    close(y, y_ref, 2e-2, 4e-2, "corrected zero-state scan vs oracle from S_in")
+    close(y, y_direct.float(), 2e-2, 4e-2, "corrected zero-state scan vs the kernel started from S_in")
+    if not slow and L >= 1000:      # far past every head's horizon nothing may change, bit for bit
+        assert torch.equal(y[:, 600:], y0[:, 600:])
+
+
 # ---------------------------------------------------------------- attention
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("B,Lq,Lk,Hq,Hkv,D,causal", [

@@ -1,0 +1,232 @@
+// S3 companion: carried-in state correction of a scan that started from a zero state.
+//
+//   y_t += exp(cs_t) * C_t . S_in        cs_t = sum_{j <= t} dt_j A_h  (inclusive, from the range start)
+//
+// — SURVEY.md Appendix A's "sequence sharding" identity: a shard (another GPU's, or the second
+// segment of one GPU's sequence) scans from a zero state, and once the state that enters it is
+// known the outputs are completed by this term.  It is the Y_off term of modeling_nano.py:833-836
+// with the chunk-local decay replaced by the decay from the range start.
+//
+// The factor exp(cs_t) only shrinks along the sequence (dt >= 0, A < 0) and reaches exactly 0 in
+// fp32 once cs_t * log2(e) < -150: from there on the correction is exactly zero and the kernel
+// stops (the reference's fp32 state passing underflows the same way).  Heads that forget within a
+// few hundred tokens cost a few chunks; a head that never forgets costs the full range.
+//
+// Three launches: per-chunk log-decays (from dt), their exclusive prefix per head, and the
+// correction itself: work-groups (slot k of 8, head, batch) walk the chunks k, k+8, ... of their
+// head until the prefix underflows; per 64-token chunk C . S_in^T on MFMA 16x16x32 (S_in as bf16
+// B fragments in registers for the whole walk, like the march's state snapshot), scaled rows
+// through LDS, 16-byte read-modify-write of y.
+#include "ssd_common.hpp"
+
+namespace {
+using namespace ssdk;
+
+constexpr int CQ = 64;            // tokens per chunk
+constexpr int CN = 128;           // d_state
+constexpr int CSLOTS = 8;         // work-groups per (batch, head)
+constexpr float C_UNDERFLOW = -160.f;   // log2 of a factor that is exactly 0 in fp32, with margin
+
+struct CorrArgs {
+  bf16_t* y;
+  const bf16_t *dt, *Cm;
+  const float *A, *dt_bias, *state;
+  float *tot, *pre;
+  int L, H, P, G, nchunks;
+  int64_t ysb, ysl, dsb, dsl, csb, csl, csg;
+  int softplus, group_map;
+  float dt_min, dt_max;
+};
+
+__device__ __forceinline__ float disc_dt(const CorrArgs& a, float raw, int h) {
+  float d = raw + (a.dt_bias ? a.dt_bias[h] : 0.f);
+  if (a.softplus) d = softplus_fast(d);
+  return fminf(fmaxf(d, a.dt_min), a.dt_max);
+}
+
+// grid (nchunks, B), block = H rounded up to 64: tot[b][h][c] = log2(e) * sum_{t in chunk} dt_t A_h
+__global__ void ssd_chunk_decay_kernel(CorrArgs a) {
+  const int c = blockIdx.x, b = blockIdx.y, h = threadIdx.x;
+  if (h >= a.H) return;
+  const bf16_t* dp = a.dt + (int64_t)b * a.dsb + h;
+  float s = 0.f;
+  const int t0 = c * CQ, t1 = min(t0 + CQ, a.L);
+  for (int t = t0; t < t1; ++t) s += disc_dt(a, (float)dp[(int64_t)t * a.dsl], h);
+  a.tot[((int64_t)b * a.H + h) * a.nchunks + c] = s * a.A[h] * 1.4426950408889634f;
+}
+
+// grid (H, B), one wave: pre[b][h][c] = sum_{c' < c} tot[b][h][c']
+__global__ __launch_bounds__(64) void ssd_decay_prefix_kernel(CorrArgs a) {
+  const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  const float* t = a.tot + ((int64_t)b * a.H + h) * a.nchunks;
+  float* p = a.pre + ((int64_t)b * a.H + h) * a.nchunks;
+  float carry = 0.f;
+  for (int c0 = 0; c0 < a.nchunks; c0 += 64) {
+    const float v = c0 + lane < a.nchunks ? t[c0 + lane] : 0.f;
+    const float inc = wave_incl_scan_dpp(v);
+    if (c0 + lane < a.nchunks) p[c0 + lane] = carry + inc - v;
+    carry += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inc), 63));
+  }
+}
+
+// grid (CSLOTS, H, B), 256 threads.  PT = ceil(P / 16) column tiles.
+template <int PT>
+__global__ __launch_bounds__(256) void ssd_correct_kernel(CorrArgs a) {
+  constexpr int LDW = PT * 16 + 4;                  // padded fp32 row of the staging tile
+  __shared__ float ef[CQ];
+  __shared__ __attribute__((aligned(16))) float tile[CQ * LDW];
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lc = lane & 15, kq = lane >> 4;
+  const int hpg = a.H / a.G;
+  const int g = a.group_map ? (h % a.G) : (h / hpg);
+  const float* pre = a.pre + ((int64_t)b * a.H + h) * a.nchunks;
+  if (pre[blockIdx.x < a.nchunks ? blockIdx.x : 0] < C_UNDERFLOW || (int)blockIdx.x >= a.nchunks) return;
+
+  // S_in as B operand: lane (col lc, kq) of tile ct, k-step ks holds S[p = 16 ct + lc][n = 32 ks + 8 kq + 0..7]
+  bf16x8 sf[PT][4];
+  const float* sp = a.state + ((int64_t)b * a.H + h) * a.P * CN;
+#pragma unroll
+  for (int ct = 0; ct < PT; ++ct) {
+    const int p = 16 * ct + lc;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 v = {};
+      if (p < a.P) {
+        const f32x4 lo = *(const f32x4*)(sp + (int64_t)p * CN + 32 * ks + 8 * kq);
+        const f32x4 hi = *(const f32x4*)(sp + (int64_t)p * CN + 32 * ks + 8 * kq + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = (bf16_t)lo[j]; v[4 + j] = (bf16_t)hi[j]; }
+      }
+      sf[ct][ks] = v;
+    }
+  }
+  const float Ah = a.A[h] * 1.4426950408889634f;
+  const bf16_t* dp = a.dt + (int64_t)b * a.dsb + h;
+  const bf16_t* cp = a.Cm + (int64_t)b * a.csb + (int64_t)g * a.csg;
+  bf16_t* yp = a.y + (int64_t)b * a.ysb + (int64_t)h * a.P;
+  const int nvec = a.P / 8;                          // 16-byte pieces per y row
+
+  for (int c = blockIdx.x; c < a.nchunks; c += CSLOTS) {
+    const float p0 = pre[c];
+    if (p0 < C_UNDERFLOW) break;                     // the prefix only decreases: nothing left for this head
+    const int t0 = c * CQ;
+    if (wave == 0) {
+      const int t = t0 + lane;
+      const float d = t < a.L ? disc_dt(a, (float)dp[(int64_t)t * a.dsl], h) : 0.f;
+      const float cs = wave_incl_scan_dpp(d * Ah);
+      ef[lane] = __builtin_amdgcn_exp2f(p0 + cs);
+    }
+    // C rows of this wave's 16 tokens as A operand (rows past the end repeat the last row: finite)
+    const int trow = min(t0 + 16 * wave + lc, a.L - 1);
+    bf16x8 cf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) cf[ks] = *(const bf16x8*)(cp + (int64_t)trow * a.csl + 32 * ks + 8 * kq);
+    f32x4 acc[PT];
+#pragma unroll
+    for (int ct = 0; ct < PT; ++ct) {
+      acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) acc[ct] = mfma16(cf[ks], sf[ct][ks], acc[ct]);
+    }
+    __syncthreads();                                 // ef ready; previous iteration's tile reads done
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * wave + 4 * kq + r;
+      const float e = ef[row];
+#pragma unroll
+      for (int ct = 0; ct < PT; ++ct) tile[row * LDW + 16 * ct + lc] = acc[ct][r] * e;
+    }
+    __syncthreads();
+    for (int i = tid; i < CQ * nvec; i += 256) {
+      const int row = i / nvec, ch = i % nvec;
+      if (t0 + row < a.L) {
+        bf16_t* q = yp + (int64_t)(t0 + row) * a.ysl + 8 * ch;
+        bf16x8 v = *(const bf16x8*)q;
+        const f32x4 lo = *(const f32x4*)(tile + row * LDW + 8 * ch);
+        const f32x4 hi = *(const f32x4*)(tile + row * LDW + 8 * ch + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[j] = (bf16_t)((float)v[j] + lo[j]);
+          v[4 + j] = (bf16_t)((float)v[4 + j] + hi[j]);
+        }
+        *(bf16x8*)q = v;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+size_t tv_ssd_correct_workspace_bytes(int batch, int seqlen, int nheads) {
+  const size_t nchunks = (size_t)(seqlen + CQ - 1) / CQ;
+  return 2 * (size_t)batch * nheads * nchunks * sizeof(float);
+}
+
+bool tv_ssd_correct_supported(int headdim, int dstate, int dtype, int nheads) {
+  return dtype == TV_BF16 && dstate == CN && headdim % 8 == 0 && headdim <= 128 && nheads <= 1024;
+}
+
+int tv_ssd_correct_launch(void* y, const void* dt, const void* A, const void* Cm, const void* dt_bias,
+                          const void* state_in, int batch, int seqlen, int nheads, int headdim,
+                          int ngroups, int64_t ysb, int64_t ysl, int64_t dsb, int64_t dsl, int64_t csb,
+                          int64_t csl, int64_t csg, int dt_softplus, float dt_min, float dt_max,
+                          int group_map, void* workspace, hipStream_t st) {
+  CorrArgs a;
+  a.y = (bf16_t*)y; a.dt = (const bf16_t*)dt; a.Cm = (const bf16_t*)Cm;
+  a.A = (const float*)A; a.dt_bias = (const float*)dt_bias; a.state = (const float*)state_in;
+  a.L = seqlen; a.H = nheads; a.P = headdim; a.G = ngroups;
+  a.nchunks = (seqlen + CQ - 1) / CQ;
+  a.tot = (float*)workspace;
+  a.pre = a.tot + (size_t)batch * nheads * a.nchunks;
+  a.ysb = ysb; a.ysl = ysl; a.dsb = dsb; a.dsl = dsl; a.csb = csb; a.csl = csl; a.csg = csg;
+  a.softplus = dt_softplus; a.group_map = group_map; a.dt_min = dt_min; a.dt_max = dt_max;
+  ssd_chunk_decay_kernel<<<dim3(a.nchunks, batch), (nheads + 63) / 64 * 64, 0, st>>>(a);
+  ssd_decay_prefix_kernel<<<dim3(nheads, batch), 64, 0, st>>>(a);
+  const dim3 grid(CSLOTS, nheads, batch);
+  switch ((headdim + 15) / 16) {
+    case 1: ssd_correct_kernel<1><<<grid, 256, 0, st>>>(a); break;
+    case 2: ssd_correct_kernel<2><<<grid, 256, 0, st>>>(a); break;
+    case 3: ssd_correct_kernel<3><<<grid, 256, 0, st>>>(a); break;
+    case 4: ssd_correct_kernel<4><<<grid, 256, 0, st>>>(a); break;
+    case 5: ssd_correct_kernel<5><<<grid, 256, 0, st>>>(a); break;
+    case 6: ssd_correct_kernel<6><<<grid, 256, 0, st>>>(a); break;
+    case 7: ssd_correct_kernel<7><<<grid, 256, 0, st>>>(a); break;
+    default: ssd_correct_kernel<8><<<grid, 256, 0, st>>>(a); break;
+  }
+  TV_LAUNCH_CHECK();
+}
+
+extern "C" size_t tv_ssd_state_correction_workspace_bytes(int batch, int seqlen, int nheads) {
+  if (batch <= 0 || seqlen <= 0 || nheads <= 0) return 0;
+  return tv_ssd_correct_workspace_bytes(batch, seqlen, nheads);
+}
+
+extern "C" int tv_ssd_state_correction(void* y, const void* dt, const void* A, const void* Cm,
+                                       const void* dt_bias, const void* state_in, int batch, int seqlen,
+                                       int nheads, int headdim, int ngroups, int dstate,
+                                       int64_t y_stride_b, int64_t y_stride_l, int64_t dt_stride_b,
+                                       int64_t dt_stride_l, int64_t c_stride_b, int64_t c_stride_l,
+                                       int64_t c_stride_g, int dtype, int dt_softplus, float dt_min,
+                                       float dt_max, int group_map, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+  TV_CHECK_ARG(batch > 0 && seqlen >= 0 && nheads > 0 && headdim > 0 && ngroups > 0 && dstate > 0 &&
+                   nheads % ngroups == 0, "ssd_state_correction: bad sizes");
+  if (seqlen == 0) return TV_OK;
+  TV_CHECK_ARG(y && dt && A && Cm && state_in, "ssd_state_correction: null pointer");
+  if (!tv_ssd_correct_supported(headdim, dstate, dtype, nheads))
+    TV_UNSUPPORTED("ssd_state_correction: bf16, d_state 128, head_dim %% 8 == 0 and <= 128 only (got dtype %d, N %d, P %d)",
+                   dtype, dstate, headdim);
+  if (y_stride_l % 8 || y_stride_b % 8 || c_stride_l % 8 || c_stride_g % 8 || c_stride_b % 8 ||
+      ((uintptr_t)y & 15) || ((uintptr_t)Cm & 15) || ((uintptr_t)state_in & 15))
+    TV_UNSUPPORTED("ssd_state_correction: y / C rows must be 16-byte aligned");
+  const size_t need = tv_ssd_correct_workspace_bytes(batch, seqlen, nheads);
+  if (!workspace || workspace_bytes < need) {
+    tv_set_error("ssd_state_correction: workspace of %zu bytes required, got %zu", need, workspace_bytes);
+    return TV_ERR_WORKSPACE;
+  }
+  return tv_ssd_correct_launch(y, dt, A, Cm, dt_bias, state_in, batch, seqlen, nheads, headdim, ngroups,
+                               y_stride_b, y_stride_l, dt_stride_b, dt_stride_l, c_stride_b, c_stride_l,
+                               c_stride_g, dt_softplus, dt_min, dt_max, group_map, workspace,
+                               (hipStream_t)stream);
+}

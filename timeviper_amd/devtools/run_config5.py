@@ -1,6 +1,10 @@
-"""BASELINE config 4 at its named size on one GPU (dev run, not the bench line): Qwen2.5-7B geometry
-+ DINOv2-L / InternVideo2-1B dual encoder, 224 px, 32 tokens per frame.
-usage: python timeviper_amd/devtools/run_config4.py [frames=4096] [steps=2]"""
+"""BASELINE config 5 (BASELINE.json `configs[4]`) at its named size on one GPU — a dev run, not the bench
+line: Qwen2.5-7B geometry + DINOv2-L / InternVideo2-1B dual encoder, 224 px, 32 tokens per frame, with the
+attention products on the bf16 or the fp8 MFMA path.
+usage: python timeviper_amd/devtools/run_config5.py [frames=4096] [steps=2] [fp8=1]
+Prints one JSON line (kept under profiles/ per round)."""
+import contextlib
+import json
 import sys
 import time
 
@@ -12,6 +16,8 @@ from timeviper_amd.model.llm.qwen2 import Qwen2Config  # noqa: E402
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+fp8 = bool(int(sys.argv[3])) if len(sys.argv) > 3 else True
+from timeviper_amd import kernels as K  # noqa: E402
 dev = torch.device("cuda", 0)
 pd = "uni_7_0.8-uni_14_0.6-uni_21_0.4"
 vlm = build_synthetic_timeviper(Qwen2Config.qwen2_5_7b(), "dinov2-vit-l+internvideo2-1b-16-224px",
@@ -23,6 +29,9 @@ ids = torch.cat([torch.randint(3, 1000, (20,), device=dev, generator=g), torch.f
                  torch.randint(3, 1000, (80,), device=dev, generator=g)])[None]
 pix = torch.randn(T, 3, 224, 224, device=dev, dtype=torch.bfloat16, generator=g)
 with torch.inference_mode():
+    ref = vlm(input_ids=ids, pixel_values_videos=pix).logits          # bf16 attention
+ctx = K.fp8_attention() if fp8 else contextlib.nullcontext()
+with torch.inference_mode(), ctx:
     out = vlm(input_ids=ids, pixel_values_videos=pix).logits
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -39,6 +48,11 @@ with torch.inference_mode():
     ev[2].record()
     torch.cuda.synchronize()
 assert torch.isfinite(out.float()).all()
-print(f"config4: {T} frames, {T * 32 + 100} tokens, {dt * 1e3:.0f} ms/forward = {T / dt:.0f} frames/s; "
-      f"vision {ev[0].elapsed_time(ev[1]):.0f} ms, LM {ev[1].elapsed_time(ev[2]):.0f} ms; "
-      f"peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+err = ((out.float() - ref.float()).norm() / ref.float().norm()).item()
+print(json.dumps({"config": "BASELINE configs[4]: Qwen2.5-7B geometry, DINOv2-L + InternVideo2-1B, pdrop " + pd + " + TransV",
+                  "attention": "fp8 e4m3 MFMA" if fp8 else "bf16 MFMA", "frames": T, "tokens": T * 32 + 100,
+                  "ms_per_forward": round(dt * 1e3, 1), "frames_per_s": round(T / dt, 1),
+                  "vision_ms": round(ev[0].elapsed_time(ev[1]), 1), "lm_ms": round(ev[1].elapsed_time(ev[2]), 1),
+                  "logits_rel_err_vs_bf16_attention": round(err, 5),
+                  "same_argmax_as_bf16": bool(out.argmax() == ref.argmax()),
+                  "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2**30, 1)}))

@@ -13,7 +13,8 @@ the 8 GPUs with RCCL all-gather of the SSM states over xGMI".  One process per G
     (74 KB halo); the scan runs on the shard from a zero state, the ranks all-gather their
     final states S_r (H,P,N fp32 = 5.2 MB) and total log-decays L_r (H), every rank chains
       In_0 = 0,  In_r = exp(L_{r-1}) In_{r-1} + S_{r-1}
-    locally and ranks > 0 rescan their shard from In_r (the scan is ~1 % of a step).
+    locally and ranks > 0 add the carried-in term exp(cs_t) C_t . In_r to their outputs in place
+    (tv_ssd_state_correction; it stops at each head's decay horizon).
   * attention (4 layers): K/V all-gather (variable shard lengths), causal attention of the
     local queries against the keys up to the shard's end (bottom-right aligned mask).
   * TransV / pdrop: "uni" indices are computed identically on every rank; "attn" scores
@@ -243,9 +244,18 @@ class SequenceParallelTimeViper:
         y, S, dec = K.mamba_chunk_scan_combined(xh, dt, A, Bm, Cm, return_total_decay=True, **kw)
         S_all = all_gather_stack(S, self.group)
         d_all = all_gather_stack(dec, self.group)
-        if self.rank > 0:
+        if self.rank > 0 and L > 0:
+            # the state entering this shard, then the carried-in term y_t += exp(cs_t) C_t . In_r added
+            # in place — not a second scan: the term dies out after each head's
+            # decay horizon and the kernel stops there
             inc = chain_states(S_all, d_all, self.rank)
-            y, _ = K.mamba_chunk_scan_combined(xh, dt, A, Bm, Cm, initial_states=inc, **kw)
+            dtl = {} if "dt_limit" not in kw else {"dt_limit": kw["dt_limit"]}
+            if y.dtype == torch.bfloat16 and mixer.ssm_state_size == 128 and mixer.head_dim % 8 == 0 \
+                    or not y.is_cuda:
+                y = K.ssd_state_correction(y, dt, A, Cm, inc, dt_bias=mixer.dt_bias, dt_softplus=True,
+                                           group_map=mixer.group_map, **dtl)
+            else:       # shapes outside the correction kernel (fp32 / other d_state): scan again from In_r
+                y, _ = K.mamba_chunk_scan_combined(xh, dt, A, Bm, Cm, initial_states=inc, **kw)
         y = mixer.norm(y.view(Bsz, L, d_in), gate)
         return mixer.out_proj(y)
 
