@@ -28,17 +28,34 @@
 #include <type_traits>
 #include "ssd_common.hpp"
 
+// ssd_correct.hip
+size_t tv_ssd_correct_workspace_bytes(int batch, int seqlen, int nheads);
+int tv_ssd_correct_launch(void* y, const void* dt, const void* A, const void* Cm, const void* dt_bias,
+                          const void* state_in, int batch, int seqlen, int nheads, int headdim,
+                          int ngroups, int64_t ysb, int64_t ysl, int64_t dsb, int64_t dsl, int64_t csb,
+                          int64_t csl, int64_t csg, int dt_softplus, float dt_min, float dt_max,
+                          int group_map, void* workspace, hipStream_t st);
+
 namespace {
 using namespace ssdk;
 
 constexpr int SQ = 64;           // tokens per chunk
 constexpr int SN = 128;          // d_state
 constexpr int STHREADS = 768;    // 12 waves
-constexpr int NB = 3;            // B/C ring slots (prefetch distance 2 chunks)
-constexpr int DXS = 4;           // x prefetch distance (chunks); dt runs one chunk further
-constexpr int NXS = DXS + 1;     // x ring slots
-constexpr int NDT = NXS + 2;     // raw-dt ring slots
 constexpr int NV = 3;            // cs / ecs / dt / weight vector buffers
+// Ring depths by slice width.  Up to 48 columns (two work-groups per head, round 1's layout):
+// B/C ring of 3 (prefetch distance 2 chunks), x issued 4 chunks ahead.  Whole-head work-groups
+// (up to 80 columns, 5 slice-waves): 160 KiB of LDS only holds a B/C ring of 2 (distance 1) and x
+// issued 2 chunks ahead — x must then land within the step that issues it, so a helper wave
+// touches its cache lines two steps earlier (the copy hits L2).
+template <int PW> struct Rings {
+  static constexpr bool WIDE = PW > 48;
+  static constexpr int NB = WIDE ? 2 : 3;      // B/C ring slots
+  static constexpr int BD = NB - 1;            // B/C prefetch distance (chunks)
+  static constexpr int DXS = WIDE ? 2 : 4;     // x prefetch distance; dt runs one chunk further
+  static constexpr int NXS = DXS + 1;          // x ring slots
+  static constexpr int NDT = NXS + 2;          // raw-dt ring slots
+};
 constexpr int NFRAG = 6;         // causal (t-tile, s-pair) fragments of a 64x64 chunk
 constexpr int CB_ELEMS = NFRAG * 512;   // bf16 elements per (chunk, group)
 
@@ -119,6 +136,11 @@ struct SliceArgs {
   const float *A, *D, *dt_bias, *init;
   bf16_t* y;
   float *final_state, *total_decay;
+  // sequence segments (blockIdx.z): segment s marches chunks [s * seg_chunks, ...) from a zero state
+  // (segment 0 from `init`) and leaves its final state / total log-decay in seg_state / seg_decay;
+  // nseg == 1: one march over the whole sequence, final_state / total_decay written directly
+  float *seg_state, *seg_decay;
+  int nseg, seg_chunks;
   int L, H, P, G, nslices, pw, nchunks;
   int64_t xsb, xsl, dsb, dsl, bsb, bsl, bsg, csb, csl, csg, ysb, ysl;
   int softplus, group_map;
@@ -138,6 +160,7 @@ struct SliceArgs {
 template <int PW>
 struct __attribute__((aligned(16))) SliceSmem {
   static constexpr int XSLOT = SQ * PW + 16;   // + finite guard (the last tile reads <= 16 B past PW)
+  static constexpr int NB = Rings<PW>::NB, NXS = Rings<PW>::NXS, NDT = Rings<PW>::NDT;
   bf16_t bt[NB][SQ * SN];     // B tiles [t][n], 16-byte chunk index ^ 4(t & 3) (ds_read_b64_tr)
   bf16_t ct[NB][SQ * SN];     // C tiles [t][n], chunks XOR-swizzled for row reads
   bf16_t xr[NXS][XSLOT];      // x tiles [t][PW]
@@ -166,14 +189,22 @@ __device__ __forceinline__ int xad(int a, int k, int b) {
   return d;
 }
 
-// wave roles
-constexpr int W_XIO = 3;                         // x / dt DMA + y stores
-// (waves w, w+4, w+8 share a SIMD: the two mask waves, the heaviest VALU helpers, sit on
-// different SIMDs; SIMD 3 has no slice-wave)
-__device__ __forceinline__ int bc_index(int w) { return w == 4 ? 0 : w == 5 ? 1 : w == 6 ? 2 : w == 11 ? 3 : -1; }
-__device__ __forceinline__ int mask_index(int w) { return w == 7 ? 0 : w == 8 ? 1 : -1; }
-constexpr int W_PREP = 9;                        // dt -> softplus -> prefix sum, mask factors
-constexpr int W_SCALE = 10;                      // x~ pieces the four B/C waves do not take
+// wave roles (waves w, w+4, w+8 share a SIMD).
+//   narrow (<= 3 slice-waves): 0-2 slices, 3 x/dt/y, 4-6 + 11 B/C, 7-8 mask, 9 prep, 10 x~ pieces —
+//     the two mask waves, the heaviest VALU helpers, sit on different SIMDs; SIMD 3 has no slice-wave;
+//   wide (5 slice-waves, whole head): 0-4 slices, 5 x/dt/y + prep, 6-9 B/C + all x~ pieces, 10-11 mask.
+template <int PT> struct Roles {
+  static constexpr bool WIDE = PT > 3;
+  static constexpr int XIO = WIDE ? 5 : 3;         // x / dt DMA + y stores
+  static constexpr int PREP = WIDE ? 5 : 9;        // dt -> softplus -> prefix sum, mask factors
+  static constexpr int SCALE = WIDE ? -1 : 10;     // x~ pieces the four B/C waves do not take
+  static __device__ __forceinline__ int bc(int w) {
+    return WIDE ? ((w >= 6 && w <= 9) ? w - 6 : -1) : (w == 4 ? 0 : w == 5 ? 1 : w == 6 ? 2 : w == 11 ? 3 : -1);
+  }
+  static __device__ __forceinline__ int mask(int w) {
+    return WIDE ? (w == 10 ? 0 : w == 11 ? 1 : -1) : (w == 7 ? 0 : w == 8 ? 1 : -1);
+  }
+};
 
 // -DTV_SLICE_STAMP: every wave of workgroup 0 sums the cycles it spends parked at the step
 // barrier (s_memtime); tv_ssd_slice_debug_stamps() returns {wait[16], total[16]}.
@@ -200,6 +231,9 @@ __device__ unsigned long long g_slice_phases[8];
 template <int PT, int PW>
 __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
   typedef SliceSmem<PW> Smem;
+  typedef Rings<PW> RG;
+  typedef Roles<PT> RL;
+  constexpr int NB = RG::NB, BD = RG::BD, DXS = RG::DXS, NXS = RG::NXS, NDT = RG::NDT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   Smem& sm = *reinterpret_cast<Smem*>(smem_raw);
   constexpr int NPC = PW / 8;          // 16-byte pieces per x / y row
@@ -214,7 +248,12 @@ __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
   const int hig = rest / a.nslices, slice = rest % a.nslices;
   const int h = a.group_map ? (hig * a.G + g) : (g * hpg + hig);
   const int p_base = slice * PW;
-  const int L = a.L, nchunks = a.nchunks;
+  // this work-group's segment of the sequence: chunks [c_first, c_first + nchunks), tokens [t_first, t_first + L)
+  const int seg = blockIdx.z;
+  const int c_first = seg * a.seg_chunks;
+  const int t_first = c_first * SQ;
+  const int nchunks = min(a.seg_chunks, a.nchunks - c_first);
+  const int L = min(a.L - t_first, nchunks * SQ);
 
 #ifdef TV_SLICE_STAMP
   unsigned long long stamp_wait = 0;
@@ -248,6 +287,41 @@ __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
     }
     *(bf16x8*)(reinterpret_cast<unsigned char*>(sm.xs[c & 1]) + i * 16) = o;
   };
+  // dt -> discretised dt, chunk-local cumulative log-decay and everything derived from it (one wave,
+  // lane = token): run by the prep wave, or by the x/dt/y wave of a whole-head work-group
+  const float Ah = a.A[h];
+  const float bias = a.dt_bias ? a.dt_bias[h] : 0.f;
+  float decay_total = 0.f;
+  auto prep = [&](int c) {             // one wave: lane = token
+    const int vb = c % NV;
+    const int t = c * SQ + lane;
+    float d = 0.f;
+    if (t < L) {
+      const unsigned w = sm.dtr[c % NDT][lane];
+      d = ((h & 1) ? bf16_hi(w) : bf16_lo(w)) + bias;
+      if (a.softplus) d = softplus_fast(d);
+      d = fminf(fmaxf(d, a.dt_min), a.dt_max);
+    }
+    const float cs = wave_incl_scan_dpp(d * Ah);
+    const float cl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs), 63));
+    const float cs2 = cs * 1.4426950408889634f, cl2 = cl * 1.4426950408889634f;
+    sm.cs[vb][lane] = cs2;                                    // log2 domain (v_exp_f32 is 2^x)
+    sm.ecs[vb][lane] = __builtin_amdgcn_exp2f(cs2);
+    sm.dtv[vb][lane] = d;
+    sm.wts[vb][lane] = __builtin_amdgcn_exp2f(cl2 - cs2) * d;
+    if (lane == 0) sm.dl[vb][0] = __builtin_amdgcn_exp2f(cl2);
+    // separable factors of the off-diagonal mask blocks (pivot = first token of a t-tile)
+    const float p1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs2), 16));
+    const float p2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs2), 32));
+    const float p3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs2), 48));
+    const float p0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs2), 0));
+    const float pv = lane < 16 ? p0 : lane < 32 ? p1 : lane < 48 ? p2 : p3;
+    sm.ut[c & 1][lane] = __builtin_amdgcn_exp2f(fminf(cs2 - pv, 0.f));
+    if (lane < 16) sm.ws[c & 1][lane] = __builtin_amdgcn_exp2f(fminf(p1 - cs2, 0.f)) * d;
+    if (lane < 32) sm.ws[c & 1][16 + lane] = __builtin_amdgcn_exp2f(fminf(p2 - cs2, 0.f)) * d;
+    if (lane < 48) sm.ws[c & 1][48 + lane] = __builtin_amdgcn_exp2f(fminf(p3 - cs2, 0.f)) * d;
+    decay_total += cl;
+  };
   if (wave < PT) {
     // ============================================================ slice-wave (16 columns)
     const int j = wave;
@@ -257,7 +331,7 @@ __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
     for (int i = 0; i < 8; ++i) xacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int pcol = 16 * j + lc;
     const bool pvalid = pcol < PW;
-    if (a.init && pvalid) {
+    if (a.init && seg == 0 && pvalid) {
 #pragma unroll
       for (int i = 0; i < 8; ++i)
         xacc[i] = *(const f32x4*)(a.init + (((int64_t)b * a.H + h) * a.P + p_base + pcol) * SN + 32 * (i >> 1) + 8 * kq + 4 * (i & 1));
@@ -436,17 +510,18 @@ __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
       for (int i = 0; i < 8; ++i) g_slice_phases[i] = ph_acc[i];
 #endif
     write_y(nchunks - 1);
-    if (a.final_state && pvalid) {
+    float* fin = a.nseg > 1 ? a.seg_state + (int64_t)seg * gridDim.y * a.H * a.P * SN : a.final_state;
+    if (fin && pvalid) {
 #pragma unroll
       for (int i = 0; i < 8; ++i)
-        *(f32x4*)(a.final_state + (((int64_t)b * a.H + h) * a.P + p_base + pcol) * SN + 32 * (i >> 1) + 8 * kq + 4 * (i & 1)) = xacc[i];
+        *(f32x4*)(fin + (((int64_t)b * a.H + h) * a.P + p_base + pcol) * SN + 32 * (i >> 1) + 8 * kq + 4 * (i & 1)) = xacc[i];
     }
     SLICE_BARRIER();   // final (y of the last chunk is stored after it)
-  } else if (wave == W_XIO) {
+  } else if (wave == RL::XIO) {
     // ============================================================ x / dt DMA, y stores
-    const bf16_t* xg = a.x + (int64_t)b * a.xsb + (int64_t)h * a.P + p_base;
-    const bf16_t* dtg = a.dt + (int64_t)b * a.dsb + (h & ~1);
-    bf16_t* yg = a.y + (int64_t)b * a.ysb + (int64_t)h * a.P + p_base;
+    const bf16_t* xg = a.x + (int64_t)b * a.xsb + (int64_t)t_first * a.xsl + (int64_t)h * a.P + p_base;
+    const bf16_t* dtg = a.dt + (int64_t)b * a.dsb + (int64_t)t_first * a.dsl + (h & ~1);
+    bf16_t* yg = a.y + (int64_t)b * a.ysb + (int64_t)t_first * a.ysl + (int64_t)h * a.P + p_base;
     unsigned x_off[NPI];
     int64_t y_off[NPI];
     int prow[NPI];
@@ -487,8 +562,18 @@ __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
     for (int c = 0; c <= DXS; ++c) issue_dt(c);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     SLICE_BARRIER();   // P1
+    if (RL::WIDE) {    // this wave is the prep wave too
+      prep(0);
+      if (nchunks > 1) prep(1);
+    }
     SLICE_BARRIER();   // P2
     SLICE_BARRIER();   // P3
+    // x of chunk c+2 and dt of chunk c+3 must have landed at the end of step c (the helpers build
+    // x~_{c+2} at step c+1).  Narrow: they were issued two steps ago, and since then this wave issued
+    // 2 x (NPI stores + NPI + 1 copies) — two steps of flight time.  Wide (x issued 2 chunks ahead):
+    // they are this step's own copies, everything is waited for; the lines were touched two steps
+    // earlier by a mask wave, so the copies come from L2.
+    constexpr int FLY = (DXS - 2) * (2 * NPI + 1);
     for (int c = 0; c < nchunks; ++c) {
       if (c > 1 && !SDBG(a, 4)) store_y(c - 2);   // written by the slice-waves at the start of step c-1
       const bool issued = c + DXS < nchunks && !SDBG(a, 4);
@@ -496,20 +581,27 @@ __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
         issue_x(c + DXS);
         issue_dt(c + DXS + 1);
       }
-      // x of chunk c+2 and dt of chunk c+3 (issued two steps ago) must have landed: since
-      // then this wave issued 2 x (NPI stores + NPI + 1 copies) — two steps of flight time
-      if (issued && c > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (2 * NPI + 1)) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (RL::WIDE && c + 2 < nchunks && !SDBG(a, 16)) prep(c + 2);
+      if constexpr (FLY > 0) {
+        if (issued && c > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FLY) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       SLICE_BARRIER();
     }
     if (nchunks > 1) store_y(nchunks - 2);
     SLICE_BARRIER();   // final: the slice-waves have flushed the last chunk's y tile
     store_y(nchunks - 1);
-  } else if (bc_index(wave) >= 0) {
+    if (RL::WIDE) {
+      float* td = a.nseg > 1 ? a.seg_decay + (int64_t)seg * gridDim.y * a.H : a.total_decay;
+      if (td && slice == 0 && lane == 0) td[(int64_t)b * a.H + h] = decay_total;
+    }
+  } else if (RL::bc(wave) >= 0) {
     // ============================================================ B / C DMA
-    const int q = bc_index(wave);
-    const bf16_t* Bg = a.Bm + (int64_t)b * a.bsb + (int64_t)g * a.bsg;
-    const bf16_t* Cg = a.Cm + (int64_t)b * a.csb + (int64_t)g * a.csg;
+    const int q = RL::bc(wave);
+    const bf16_t* Bg = a.Bm + (int64_t)b * a.bsb + (int64_t)g * a.bsg + (int64_t)t_first * a.bsl;
+    const bf16_t* Cg = a.Cm + (int64_t)b * a.csb + (int64_t)g * a.csg + (int64_t)t_first * a.csl;
     int brow[4];
     unsigned off_b[4], off_c[4];
     int cg_b[4], cg_c[4];
@@ -540,23 +632,35 @@ __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
         glds16(sc, oc, lds_addr_of(sm.ct[slot] + (4 * q + k) * 512));
       }
     };
+    // x~ pieces of this wave: one of the first four (narrow: the W_SCALE wave takes the rest), or
+    // every fourth piece (wide: no W_SCALE wave)
+    auto scale_mine = [&](int c) {
+      if (RL::WIDE) {
+#pragma unroll
+        for (int k = 0; k < (NPI + 3) / 4; ++k)
+          if (q + 4 * k < NPI) scale_piece(c, q + 4 * k);
+      } else if (q < NPI) {
+        scale_piece(c, q);
+      }
+    };
     issue_bc(0);
-    if (nchunks > 1) issue_bc(1);
+    if (BD > 1 && nchunks > 1) issue_bc(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     SLICE_BARRIER();   // P1
     SLICE_BARRIER();   // P2
-    if (q < NPI) scale_piece(0, q);
+    scale_mine(0);
     SLICE_BARRIER();   // P3
     for (int c = 0; c < nchunks; ++c) {
-      const bool issued = c + 2 < nchunks && !SDBG(a, 2);
-      if (issued) issue_bc(c + 2);
-      if (q < NPI && c + 1 < nchunks && !SDBG(a, 16)) scale_piece(c + 1, q);
-      if (issued) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // chunk c+1 landed, c+2 in flight
+      const bool issued = c + BD < nchunks && !SDBG(a, 2);
+      if (issued) issue_bc(c + BD);
+      if (c + 1 < nchunks && !SDBG(a, 16)) scale_mine(c + 1);
+      // chunk c+1 must have landed; with a ring of 3 chunk c+2 (this step's 8 copies) stays in flight
+      if (BD > 1 && issued) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       SLICE_BARRIER();
     }
     SLICE_BARRIER();   // final
-  } else if (mask_index(wave) >= 0) {
+  } else if (RL::mask(wave) >= 0) {
     // ============================================================ decay mask M = CB .* L
     // M[t][s] = CB[t][s] 2^(cs2_t - cs2_s) dt_s for s <= t (cs2 = cs log2 e), else 0, built
     // in five wave-wide units of 16x16 blocks so that every lane of an instruction does the
@@ -570,7 +674,7 @@ __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
     auto run_mask = [&](auto MI) {
       constexpr int mi = decltype(MI)::value;
       constexpr int NS = mi == 0 ? 2 : 1;           // separable units of this wave
-      const bf16_t* cbg = a.cb + (((int64_t)b * a.G + g) * nchunks) * CB_ELEMS;
+      const bf16_t* cbg = a.cb + (((int64_t)b * a.G + g) * a.nchunks + c_first) * CB_ELEMS;
       typedef __attribute__((ext_vector_type(2))) float f32x2;
       typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
       const int hi = kq >> 1;
@@ -667,9 +771,9 @@ __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
       }
       SLICE_BARRIER();   // final
     };
-    if (mask_index(wave) == 0) run_mask(std::integral_constant<int, 0>{});
+    if (RL::mask(wave) == 0) run_mask(std::integral_constant<int, 0>{});
     else run_mask(std::integral_constant<int, 1>{});
-  } else if (wave == W_SCALE) {
+  } else if (wave == RL::SCALE) {
     // ============================================================ remaining x~ pieces
     SLICE_BARRIER();   // P1
     SLICE_BARRIER();   // P2
@@ -684,41 +788,8 @@ __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
       SLICE_BARRIER();
     }
     SLICE_BARRIER();   // final
-  } else if (wave == W_PREP) {
+  } else if (!RL::WIDE && wave == RL::PREP) {
     // ============================================================ dt / cumsum prep
-    const float Ah = a.A[h];
-    const float bias = a.dt_bias ? a.dt_bias[h] : 0.f;
-    float decay_total = 0.f;
-    auto prep = [&](int c) {             // one wave: lane = token
-      const int vb = c % NV;
-      const int t = c * SQ + lane;
-      float d = 0.f;
-      if (t < L) {
-        const unsigned w = sm.dtr[c % NDT][lane];
-        d = ((h & 1) ? bf16_hi(w) : bf16_lo(w)) + bias;
-        if (a.softplus) d = softplus_fast(d);
-        d = fminf(fmaxf(d, a.dt_min), a.dt_max);
-      }
-      const float cs = wave_incl_scan_dpp(d * Ah);
-      const float cl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs), 63));
-      const float cs2 = cs * 1.4426950408889634f, cl2 = cl * 1.4426950408889634f;
-      sm.cs[vb][lane] = cs2;                                    // log2 domain (v_exp_f32 is 2^x)
-      sm.ecs[vb][lane] = __builtin_amdgcn_exp2f(cs2);
-      sm.dtv[vb][lane] = d;
-      sm.wts[vb][lane] = __builtin_amdgcn_exp2f(cl2 - cs2) * d;
-      if (lane == 0) sm.dl[vb][0] = __builtin_amdgcn_exp2f(cl2);
-      // separable factors of the off-diagonal mask blocks (pivot = first token of a t-tile)
-      const float p1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs2), 16));
-      const float p2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs2), 32));
-      const float p3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs2), 48));
-      const float p0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs2), 0));
-      const float pv = lane < 16 ? p0 : lane < 32 ? p1 : lane < 48 ? p2 : p3;
-      sm.ut[c & 1][lane] = __builtin_amdgcn_exp2f(fminf(cs2 - pv, 0.f));
-      if (lane < 16) sm.ws[c & 1][lane] = __builtin_amdgcn_exp2f(fminf(p1 - cs2, 0.f)) * d;
-      if (lane < 32) sm.ws[c & 1][16 + lane] = __builtin_amdgcn_exp2f(fminf(p2 - cs2, 0.f)) * d;
-      if (lane < 48) sm.ws[c & 1][48 + lane] = __builtin_amdgcn_exp2f(fminf(p3 - cs2, 0.f)) * d;
-      decay_total += cl;
-    };
     SLICE_BARRIER();   // P1
     prep(0);
     if (nchunks > 1) prep(1);
@@ -729,7 +800,8 @@ __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
       SLICE_BARRIER();
     }
     SLICE_BARRIER();   // final
-    if (a.total_decay && slice == 0 && lane == 0) a.total_decay[(int64_t)b * a.H + h] = decay_total;
+    float* td = a.nseg > 1 ? a.seg_decay + (int64_t)seg * gridDim.y * a.H : a.total_decay;
+    if (td && slice == 0 && lane == 0) td[(int64_t)b * a.H + h] = decay_total;
   } else {
     // idle waves (slice-wave slots of narrower slices)
     SLICE_BARRIER();
@@ -746,7 +818,16 @@ __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
 #endif
 }
 
-bool pick_slices(int P, int* nslices, int* pw) {
+// wide = whole-head work-groups (one slice of up to 80 columns, 5 slice-waves)
+bool pick_slices(int P, int* nslices, int* pw, bool wide = false) {
+  if (wide) {
+    if (P > 48 && P <= 80 && P % 8 == 0) {
+      *nslices = 1;
+      *pw = P;
+      return true;
+    }
+    return false;
+  }
   for (int ns = 1; ns <= 8; ++ns) {
     if (P % ns) continue;
     const int w = P / ns;
@@ -770,6 +851,63 @@ hipError_t launch_slice(const SliceArgs& a, dim3 grid, hipStream_t st) {
   return hipSuccess;
 }
 
+// In how many segments a sequence is marched concurrently: whole-head work-groups need
+// batch * heads * segments of them to cover the 256 CUs (Nano-9B: 128 heads -> 2 segments).
+int pick_segments(int batch, int nheads, int nchunks) {
+  const int wg = batch * nheads;
+  int nseg = wg >= 192 ? 1 : 256 / wg;
+  if (nseg > 4) nseg = 4;
+  while (nseg > 1 && nchunks / nseg < 16) --nseg;      // short sequences: not worth the fix-up passes
+  return nseg < 1 ? 1 : nseg;
+}
+
+struct SegLayout {
+  size_t cb, seg_state, seg_decay, sin, corr, total;
+  int nseg, seg_chunks;
+};
+SegLayout seg_layout(int batch, int seqlen, int nheads, int headdim, int ngroups, bool wide) {
+  SegLayout l;
+  const size_t nchunks = (size_t)(seqlen + SQ - 1) / SQ;
+  auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+  l.nseg = wide ? pick_segments(batch, nheads, (int)nchunks) : 1;
+  l.seg_chunks = (int)((nchunks + l.nseg - 1) / l.nseg);
+  l.cb = 0;
+  l.seg_state = up((size_t)batch * ngroups * nchunks * CB_ELEMS * sizeof(bf16_t));
+  const size_t st = (size_t)batch * nheads * headdim * SN * sizeof(float);
+  l.seg_decay = l.seg_state + (l.nseg > 1 ? up(l.nseg * st) : 0);
+  l.sin = l.seg_decay + (l.nseg > 1 ? up((size_t)l.nseg * batch * nheads * sizeof(float)) : 0);
+  l.corr = l.sin + (l.nseg > 2 ? up((l.nseg - 1) * st) : 0);       // 2 segments: S_in(1) = seg_state[0]
+  l.total = l.corr + (l.nseg > 1 ? up(tv_ssd_correct_workspace_bytes(batch, l.seg_chunks * SQ, nheads)) : 0);
+  return l;
+}
+
+// S_in of every segment > 0, the final state and the total log-decay from the per-segment results:
+//   run = seg_state[0];  for s >= 1:  S_in(s) = run;  run = exp(decay[s]) run + seg_state[s]
+__global__ __launch_bounds__(256) void ssd_seg_combine_kernel(const float* __restrict__ seg_state,
+                                                              const float* __restrict__ seg_decay,
+                                                              float* __restrict__ sin, float* __restrict__ final_state,
+                                                              float* __restrict__ total_decay, int nseg,
+                                                              int64_t bh, int64_t per_head) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;      // float4 index
+  const int64_t n4 = bh * per_head / 4;
+  if (i < n4) {
+    const int64_t head = (i * 4) / per_head;
+    f32x4 run = ((const f32x4*)seg_state)[i];
+    for (int s = 1; s < nseg; ++s) {
+      if (sin && nseg > 2) ((f32x4*)sin)[(int64_t)(s - 1) * n4 + i] = run;
+      const float e = __expf(seg_decay[(int64_t)s * bh + head]);
+      const f32x4 cur = ((const f32x4*)seg_state)[(int64_t)s * n4 + i];
+      run = f32x4{e * run[0] + cur[0], e * run[1] + cur[1], e * run[2] + cur[2], e * run[3] + cur[3]};
+    }
+    if (final_state) ((f32x4*)final_state)[i] = run;
+  }
+  if (total_decay && i < bh) {
+    float t = 0.f;
+    for (int s = 0; s < nseg; ++s) t += seg_decay[(int64_t)s * bh + i];
+    total_decay[i] = t;
+  }
+}
+
 }  // namespace
 
 #ifdef TV_SLICE_STAMP
@@ -783,10 +921,10 @@ extern "C" int tv_ssd_slice_debug_stamps(unsigned long long* out) {
 bool tv_ssd_slice_supported(int seqlen, int nheads, int headdim, int ngroups, int dstate,
                             int dtype, int64_t xsl, int64_t bsl, int64_t bsg, int64_t csl,
                             int64_t csg, int64_t ysl, const void* x, const void* Bm,
-                            const void* Cm, const void* y) {
+                            const void* Cm, const void* y, bool wide) {
   int ns, pw;
   if (dtype != TV_BF16 || dstate != SN || seqlen < 1) return false;
-  if (!pick_slices(headdim, &ns, &pw)) return false;
+  if (!pick_slices(headdim, &ns, &pw, wide)) return false;
   if (xsl % 8 || bsl % 8 || csl % 8 || bsg % 8 || csg % 8 || ysl % 8 || nheads % 2) return false;
   if (((uintptr_t)x & 15) || ((uintptr_t)Bm & 15) || ((uintptr_t)Cm & 15) || ((uintptr_t)y & 15))
     return false;
@@ -796,9 +934,9 @@ bool tv_ssd_slice_supported(int seqlen, int nheads, int headdim, int ngroups, in
   return true;
 }
 
-size_t tv_ssd_slice_workspace_bytes(int batch, int seqlen, int, int, int ngroups, int) {
-  const size_t nchunks = (size_t)(seqlen + SQ - 1) / SQ;
-  return (size_t)batch * ngroups * nchunks * CB_ELEMS * sizeof(bf16_t);
+size_t tv_ssd_slice_workspace_bytes(int batch, int seqlen, int nheads, int headdim, int ngroups, int,
+                                    bool wide) {
+  return seg_layout(batch, seqlen, nheads, headdim, ngroups, wide).total;
 }
 
 int tv_ssd_slice_launch(const void* x, const void* dt, const void* A, const void* Bm,
@@ -809,9 +947,10 @@ int tv_ssd_slice_launch(const void* x, const void* dt, const void* A, const void
                         int64_t bsl, int64_t bsg, int64_t csb, int64_t csl, int64_t csg,
                         int64_t ysb, int64_t ysl, int dtype, int dt_softplus, float dt_min,
                         float dt_max, int group_map, void* workspace, size_t workspace_bytes,
-                        hipStream_t st) {
+                        bool wide, hipStream_t st) {
   (void)dtype; (void)dstate;
-  const size_t need = tv_ssd_slice_workspace_bytes(batch, seqlen, nheads, headdim, ngroups, dstate);
+  const SegLayout lay = seg_layout(batch, seqlen, nheads, headdim, ngroups, wide);
+  const size_t need = lay.total;
   TV_CHECK_ARG(workspace && workspace_bytes >= need && (((uintptr_t)workspace) & 15) == 0,
                "ssd_slice: workspace of %zu bytes (16-byte aligned) required, got %zu", need,
                workspace_bytes);
@@ -823,7 +962,11 @@ int tv_ssd_slice_launch(const void* x, const void* dt, const void* A, const void
   a.total_decay = (float*)total_decay;
   a.L = seqlen; a.H = nheads; a.P = headdim; a.G = ngroups;
   a.nchunks = (seqlen + SQ - 1) / SQ;
-  if (!pick_slices(headdim, &a.nslices, &a.pw)) TV_UNSUPPORTED("ssd_slice: head_dim %d", headdim);
+  if (!pick_slices(headdim, &a.nslices, &a.pw, wide)) TV_UNSUPPORTED("ssd_slice: head_dim %d", headdim);
+  unsigned char* wsb = (unsigned char*)workspace;
+  a.nseg = lay.nseg; a.seg_chunks = lay.seg_chunks;
+  a.seg_state = lay.nseg > 1 ? (float*)(wsb + lay.seg_state) : nullptr;
+  a.seg_decay = lay.nseg > 1 ? (float*)(wsb + lay.seg_decay) : nullptr;
   a.xsb = xsb; a.xsl = xsl; a.dsb = dsb; a.dsl = dsl; a.bsb = bsb; a.bsl = bsl; a.bsg = bsg;
   a.csb = csb; a.csl = csl; a.csg = csg; a.ysb = ysb; a.ysl = ysl;
   a.softplus = dt_softplus; a.group_map = group_map; a.dt_min = dt_min; a.dt_max = dt_max;
@@ -835,7 +978,7 @@ int tv_ssd_slice_launch(const void* x, const void* dt, const void* A, const void
   ca.bsb = bsb; ca.bsl = bsl; ca.bsg = bsg; ca.csb = csb; ca.csl = csl; ca.csg = csg;
   ssd_cb_kernel<<<dim3(a.nchunks, ngroups, batch), 192, 0, st>>>(ca);
 
-  dim3 grid(nheads * a.nslices, batch);
+  dim3 grid(nheads * a.nslices, batch, a.nseg);
   hipError_t e = hipSuccess;
   switch (a.pw) {
     case 8: e = launch_slice<1, 8>(a, grid, st); break;
@@ -843,11 +986,35 @@ int tv_ssd_slice_launch(const void* x, const void* dt, const void* A, const void
     case 24: e = launch_slice<2, 24>(a, grid, st); break;
     case 32: e = launch_slice<2, 32>(a, grid, st); break;
     case 40: e = launch_slice<3, 40>(a, grid, st); break;
+    case 56: e = launch_slice<4, 56>(a, grid, st); break;
+    case 64: e = launch_slice<4, 64>(a, grid, st); break;
+    case 72: e = launch_slice<5, 72>(a, grid, st); break;
+    case 80: e = launch_slice<5, 80>(a, grid, st); break;
     default: TV_UNSUPPORTED("ssd_slice: slice width %d", a.pw);
   }
   if (e != hipSuccess) {
     tv_set_error("ssd_slice: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     return TV_ERR_LAUNCH;
+  }
+  if (a.nseg > 1) {
+    // segments > 0 marched from a zero state: chain the segment states, then add the carried-in
+    // term to their outputs (it stops at each head's decay horizon)
+    const int64_t bh = (int64_t)batch * nheads, per_head = (int64_t)headdim * SN;
+    float* sin = a.nseg > 2 ? (float*)(wsb + lay.sin) : nullptr;
+    const int64_t n4 = bh * per_head / 4;
+    ssd_seg_combine_kernel<<<dim3((unsigned)((n4 + 255) / 256)), 256, 0, st>>>(
+        a.seg_state, a.seg_decay, sin, (float*)final_state, (float*)total_decay, a.nseg, bh, per_head);
+    for (int s = 1; s < a.nseg; ++s) {
+      const int64_t t0 = (int64_t)s * a.seg_chunks * SQ;
+      if (t0 >= seqlen) break;
+      const int len = (int)(seqlen - t0 < (int64_t)a.seg_chunks * SQ ? seqlen - t0 : (int64_t)a.seg_chunks * SQ);
+      const float* s_in = a.nseg > 2 ? sin + (int64_t)(s - 1) * bh * per_head : a.seg_state;
+      const int rc = tv_ssd_correct_launch((bf16_t*)y + t0 * ysl, (const bf16_t*)dt + t0 * dsl, A,
+                                           (const bf16_t*)Cm + t0 * csl, dt_bias, s_in, batch, len, nheads,
+                                           headdim, ngroups, ysb, ysl, dsb, dsl, csb, csl, csg, dt_softplus,
+                                           dt_min, dt_max, group_map, wsb + lay.corr, st);
+      if (rc != TV_OK) return rc;
+    }
   }
   TV_LAUNCH_CHECK();
 }

@@ -9,12 +9,16 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 from timeviper_amd import _capi, kernels as K  # noqa: E402
 
-ROLE = {0: "slice0", 1: "slice1", 2: "slice2", 3: "xio", 4: "bc0+sc", 5: "bc1+sc", 6: "bc2+sc", 11: "bc3+sc",
-        7: "mask0", 8: "mask1", 9: "prep", 10: "scale4"}
+ROLE3 = {0: "slice0", 1: "slice1", 2: "slice2", 3: "xio", 4: "bc0+sc", 5: "bc1+sc", 6: "bc2+sc", 11: "bc3+sc",
+         7: "mask0", 8: "mask1", 9: "prep", 10: "scale4"}
+ROLE4 = {0: "slice0", 1: "slice1", 2: "slice2", 3: "slice3", 4: "slice4", 5: "xio+prep", 6: "bc0+sc", 7: "bc1+sc",
+         8: "bc2+sc", 9: "bc3+sc", 10: "mask0", 11: "mask1"}
 
 
 def main():
     L = int(sys.argv[1]) if len(sys.argv) > 1 else 163940
+    impl = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    ROLE = ROLE4 if impl == 4 else ROLE3
     H, P, G, N = 128, 80, 8, 128
     dev = "cuda"
     g = torch.Generator(device=dev).manual_seed(0)
@@ -22,7 +26,7 @@ def main():
     x, dt, Bm, Cm = rn(1, L, H, P), rn(1, L, H), rn(1, G, L, N).transpose(1, 2), rn(1, G, L, N).transpose(1, 2)
     A = -(torch.rand(H, device=dev, generator=g) * 15 + 1)
     D, bias = torch.ones(H, device=dev), torch.zeros(H, device=dev)
-    K.ssd_scan_set_impl(3)
+    K.ssd_scan_set_impl(impl)
     for _ in range(2):
         K.mamba_chunk_scan_combined(x, dt, A, Bm, Cm, chunk_size=64, D=D, dt_bias=bias, dt_softplus=True)
     torch.cuda.synchronize()
@@ -33,6 +37,8 @@ def main():
     fn.argtypes = [ctypes.c_void_p]
     assert fn(out) == 0
     steps = (L + 63) // 64
+    if impl == 4:
+        steps = (steps + 1) // 2          # two concurrent segments at 128 heads
     for w in range(12):
         wait, total = out[w], out[16 + w]
         print(f"wave {w:2d} {ROLE.get(w, '?'):12s} total {total/steps:8.0f} ticks/step   busy {(total-wait)/steps:8.0f}   "
