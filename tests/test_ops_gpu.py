@@ -298,8 +298,12 @@ def test_ssd_state_correction_completes_a_zero_state_scan(K, L, H, P, G, slow):
                                            dt_softplus=True, initial_states=d(S0))
     y = K.ssd_state_correction(y0.clone(), d(dt), d(A), d(Cm), d(S0), dt_bias=d(dtb), dt_softplus=True)
     assert y.data_ptr() != y0.data_ptr()
-    close(y, y_ref, 2e-2, 4e-2, "corrected zero-state scan vs oracle from S_in")
-    close(y, y_direct.float(), 2e-2, 4e-2, "corrected zero-state scan vs the kernel started from S_in")
+    # y0 is rounded to bf16 before the carried-in term is added: where the two nearly cancel the
+    # result keeps that rounding (half a bf16 ulp of the larger term), so the absolute tolerance
+    # scales with the magnitude of the terms
+    at = max(4e-2, 8e-3 * float(y_ref.abs().max()))
+    close(y, y_ref, 2e-2, at, "corrected zero-state scan vs oracle from S_in")
+    close(y, y_direct.float(), 2e-2, at, "corrected zero-state scan vs the kernel started from S_in")
     if not slow and L >= 1000:      # far past every head's horizon nothing may change, bit for bit
         assert torch.equal(y[:, 600:], y0[:, 600:])
 

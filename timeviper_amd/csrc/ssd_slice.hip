@@ -41,18 +41,21 @@ using namespace ssdk;
 
 constexpr int SQ = 64;           // tokens per chunk
 constexpr int SN = 128;          // d_state
-constexpr int STHREADS = 768;    // 12 waves
 constexpr int NV = 3;            // cs / ecs / dt / weight vector buffers
-// Ring depths by slice width.  Up to 48 columns (two work-groups per head, round 1's layout):
-// B/C ring of 3 (prefetch distance 2 chunks), x issued 4 chunks ahead.  Whole-head work-groups
-// (up to 80 columns, 5 slice-waves): 160 KiB of LDS only holds a B/C ring of 2 (distance 1) and x
-// issued 2 chunks ahead — x must then land within the step that issues it, so a helper wave
-// touches its cache lines two steps earlier (the copy hits L2).
+// Two layouts of a work-group.
+//   narrow (slices of <= 48 columns, two work-groups per head at Nano dims; round 1): 12 waves, one
+//     16-column tile per slice-wave, B/C ring of 3 (prefetch distance 2), x issued 4 chunks ahead,
+//     x~ built by helper waves.
+//   wide (a whole head, <= 80 columns): 8 waves with up to 256 registers each; a slice-wave owns TWO
+//     16-column tiles and uses every C / B^T fragment it reads from LDS for both (the fragment reads
+//     were what bounded the narrow slice-waves: 39 KB per 16 columns and step); x~ = w_t x is formed by
+//     the slice-waves on their own fragments; B/C ring of 2 (distance 1: the y tiles need the LDS),
+//     x issued 3 chunks ahead.
 template <int PW> struct Rings {
   static constexpr bool WIDE = PW > 48;
   static constexpr int NB = WIDE ? 2 : 3;      // B/C ring slots
   static constexpr int BD = NB - 1;            // B/C prefetch distance (chunks)
-  static constexpr int DXS = WIDE ? 2 : 4;     // x prefetch distance; dt runs one chunk further
+  static constexpr int DXS = WIDE ? 3 : 4;     // x prefetch distance
   static constexpr int NXS = DXS + 1;          // x ring slots
   static constexpr int NDT = NXS + 2;          // raw-dt ring slots
 };
@@ -159,12 +162,13 @@ struct SliceArgs {
 
 template <int PW>
 struct __attribute__((aligned(16))) SliceSmem {
-  static constexpr int XSLOT = SQ * PW + 16;   // + finite guard (the last tile reads <= 16 B past PW)
+  static constexpr int XSLOT = SQ * PW + 32;   // + finite guard (column tiles past the slice width read <= 48 B past the last row)
   static constexpr int NB = Rings<PW>::NB, NXS = Rings<PW>::NXS, NDT = Rings<PW>::NDT;
   bf16_t bt[NB][SQ * SN];     // B tiles [t][n], 16-byte chunk index ^ 4(t & 3) (ds_read_b64_tr)
   bf16_t ct[NB][SQ * SN];     // C tiles [t][n], chunks XOR-swizzled for row reads
   bf16_t xr[NXS][XSLOT];      // x tiles [t][PW]
-  bf16_t xs[2][XSLOT];        // x~ = exp(cs_Q - cs_t) dt_t x
+  static constexpr bool WIDE = Rings<PW>::WIDE;
+  bf16_t xs[WIDE ? 1 : 2][WIDE ? 8 : XSLOT];        // x~ = exp(cs_Q - cs_t) dt_t x   (narrow layout only)
   bf16_t M[2][CB_ELEMS];      // decay-masked C.B^T fragments
   bf16_t yt[2][SQ * PW];      // y tiles [t][PW]
   unsigned dtr[NDT][SQ];      // raw dt of heads (h&~1, h|1)
@@ -190,19 +194,22 @@ __device__ __forceinline__ int xad(int a, int k, int b) {
 }
 
 // wave roles (waves w, w+4, w+8 share a SIMD).
-//   narrow (<= 3 slice-waves): 0-2 slices, 3 x/dt/y, 4-6 + 11 B/C, 7-8 mask, 9 prep, 10 x~ pieces —
+//   narrow: 0-2 slices, 3 x/dt/y, 4-6 + 11 B/C (+ one x~ piece each), 7-8 mask, 9 prep, 10 x~ pieces —
 //     the two mask waves, the heaviest VALU helpers, sit on different SIMDs; SIMD 3 has no slice-wave;
-//   wide (5 slice-waves, whole head): 0-4 slices, 5 x/dt/y + prep, 6-9 B/C + all x~ pieces, 10-11 mask.
-template <int PT> struct Roles {
-  static constexpr bool WIDE = PT > 3;
-  static constexpr int XIO = WIDE ? 5 : 3;         // x / dt DMA + y stores
-  static constexpr int PREP = WIDE ? 5 : 9;        // dt -> softplus -> prefix sum, mask factors
-  static constexpr int SCALE = WIDE ? -1 : 10;     // x~ pieces the four B/C waves do not take
+//   wide:   0-2 slices (two column tiles each), 3 x/dt copies + prep, 4-5 B/C copies + y stores, 6-7 mask.
+template <int PW> struct Roles {
+  static constexpr bool WIDE = PW > 48;
+  static constexpr int NWAVES = WIDE ? 8 : 12;
+  static constexpr int NC = WIDE ? 2 : 1;          // 16-column tiles per slice-wave
+  static constexpr int XIO = 3;                    // x / dt DMA (+ y stores, narrow; + prep, wide)
+  static constexpr int PREP = WIDE ? 3 : 9;        // dt -> softplus -> prefix sum, mask factors
+  static constexpr int SCALE = WIDE ? -1 : 10;     // x~ pieces the four B/C waves do not take (narrow)
+  static constexpr int NBCW = WIDE ? 2 : 4;        // B/C copy waves
   static __device__ __forceinline__ int bc(int w) {
-    return WIDE ? ((w >= 6 && w <= 9) ? w - 6 : -1) : (w == 4 ? 0 : w == 5 ? 1 : w == 6 ? 2 : w == 11 ? 3 : -1);
+    return WIDE ? ((w == 4 || w == 5) ? w - 4 : -1) : (w == 4 ? 0 : w == 5 ? 1 : w == 6 ? 2 : w == 11 ? 3 : -1);
   }
   static __device__ __forceinline__ int mask(int w) {
-    return WIDE ? (w == 10 ? 0 : w == 11 ? 1 : -1) : (w == 7 ? 0 : w == 8 ? 1 : -1);
+    return WIDE ? (w == 6 ? 0 : w == 7 ? 1 : -1) : (w == 7 ? 0 : w == 8 ? 1 : -1);
   }
 };
 
@@ -229,10 +236,11 @@ __device__ unsigned long long g_slice_phases[8];
 #endif
 
 template <int PT, int PW>
-__global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
+__global__ __launch_bounds__(Roles<PW>::NWAVES * 64) void ssd_slice_kernel(SliceArgs a) {
   typedef SliceSmem<PW> Smem;
   typedef Rings<PW> RG;
-  typedef Roles<PT> RL;
+  typedef Roles<PW> RL;
+  constexpr int STHREADS = RL::NWAVES * 64, NC = RL::NC;
   constexpr int NB = RG::NB, BD = RG::BD, DXS = RG::DXS, NXS = RG::NXS, NDT = RG::NDT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   Smem& sm = *reinterpret_cast<Smem*>(smem_raw);
@@ -323,18 +331,22 @@ __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
     decay_total += cl;
   };
   if (wave < PT) {
-    // ============================================================ slice-wave (16 columns)
-    const int j = wave;
+    // ============================================================ slice-wave (NC tiles of 16 columns)
     const float Dh = a.D ? a.D[h] : 0.f;
-    f32x4 xacc[8];
+    f32x4 xacc[NC][8];
+    int pcol[NC];
+    bool pvalid[NC];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) xacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int pcol = 16 * j + lc;
-    const bool pvalid = pcol < PW;
-    if (a.init && seg == 0 && pvalid) {
+    for (int ct = 0; ct < NC; ++ct) {
+      pcol[ct] = 16 * (wave * NC + ct) + lc;
+      pvalid[ct] = pcol[ct] < PW;
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
-        xacc[i] = *(const f32x4*)(a.init + (((int64_t)b * a.H + h) * a.P + p_base + pcol) * SN + 32 * (i >> 1) + 8 * kq + 4 * (i & 1));
+      for (int i = 0; i < 8; ++i) xacc[ct][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (a.init && seg == 0 && pvalid[ct]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          xacc[ct][i] = *(const f32x4*)(a.init + (((int64_t)b * a.H + h) * a.P + p_base + pcol[ct]) * SN + 32 * (i >> 1) + 8 * kq + 4 * (i & 1));
+      }
     }
     // State tiles 2m / 2m+1 hold the state rows n = 32m + 8kq + r / + 4 + r (r = accumulator
     // register), so the pair is, as a B operand, the k slots n = 32m + 8kq + 0..7 — the order
@@ -345,18 +357,23 @@ __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
     // chunk (4m + p4) ^ 4(t & 3), half = tile parity  ->  ((m ^ q4) << 6) + 16 p4 + 8 odd
     const int bsw = q4 << 6;
     const int b_lo = (8 * kq + q4) * 256 + p4 * 16;
-    // transposing reads of x / x~ (B operand: k = token) and of x in accumulator layout
-    const int trx = ((8 * kq + q4) * PW + 4 * p4) * 2 + j * 32;
-    const int trd = ((4 * kq + q4) * PW + 4 * p4) * 2 + j * 32;
-    unsigned ypk[4][2] = {};
+    // transposing reads of x / x~ (B operand: k = token) and of x in accumulator layout; column tile
+    // ct of this wave adds 32 ct bytes.  (A tile past the slice width reads finite neighbouring data —
+    // the x slots carry a guard — and its results are never written.)
+    const int trx = ((8 * kq + q4) * PW + 4 * p4) * 2 + wave * NC * 32;
+    const int trd = ((4 * kq + q4) * PW + 4 * p4) * 2 + wave * NC * 32;
+    unsigned ypk[NC][4][2] = {};
     auto write_y = [&](int c) {     // y tile of chunk c: ds_write_b16 / _d16_hi of the packed halves
-      if (!pvalid) return;
 #pragma unroll
-      for (int ti = 0; ti < 4; ++ti) {
-        const unsigned ya = lds_lane_addr(sm.yt[c & 1] + (16 * ti + 4 * kq) * PW + pcol);
-        asm volatile("ds_write_b16 %0, %1\n\tds_write_b16_d16_hi %0, %1 offset:%3\n\t"
-                     "ds_write_b16 %0, %2 offset:%4\n\tds_write_b16_d16_hi %0, %2 offset:%5"
-                     :: "v"(ya), "v"(ypk[ti][0]), "v"(ypk[ti][1]), "n"(PW * 2), "n"(PW * 4), "n"(PW * 6) : "memory");
+      for (int ct = 0; ct < NC; ++ct) {
+        if (!pvalid[ct]) continue;
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) {
+          const unsigned ya = lds_lane_addr(sm.yt[c & 1] + (16 * ti + 4 * kq) * PW + pcol[ct]);
+          asm volatile("ds_write_b16 %0, %1\n\tds_write_b16_d16_hi %0, %1 offset:%3\n\t"
+                       "ds_write_b16 %0, %2 offset:%4\n\tds_write_b16_d16_hi %0, %2 offset:%5"
+                       :: "v"(ya), "v"(ypk[ct][ti][0]), "v"(ypk[ct][ti][1]), "n"(PW * 2), "n"(PW * 4), "n"(PW * 6) : "memory");
+        }
       }
     };
     SLICE_BARRIER();   // P1
@@ -367,18 +384,18 @@ __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
       const unsigned char* Bt = reinterpret_cast<const unsigned char*>(sm.bt[c % NB]);
       const unsigned char* Ct = reinterpret_cast<const unsigned char*>(sm.ct[c % NB]);
       const unsigned char* xt = reinterpret_cast<const unsigned char*>(sm.xr[c % NXS]);
-      const unsigned char* xw = reinterpret_cast<const unsigned char*>(sm.xs[c & 1]);
+      const unsigned char* xw = reinterpret_cast<const unsigned char*>(sm.xs[RL::WIDE ? 0 : (c & 1)]);
       const unsigned char* Mf = reinterpret_cast<const unsigned char*>(sm.M[c & 1]);
       if (SDBG(a, 1)) { SLICE_BARRIER(); continue; }
       typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
       typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
       typedef __attribute__((ext_vector_type(2))) float f32x2;
       // Software pipeline in quarters.  Quarter q takes the 32 state rows n in [32q, 32q+32)
-      // (accumulator tiles 2q, 2q+1): it snapshots them as a bf16 B operand, adds their
-      // share C[:, block q] . X[block q] to the four Yoff tiles, then advances them with
+      // (accumulator tiles 2q, 2q+1) of every column tile: it snapshots them as bf16 B operands,
+      // adds their share C[:, block q] . X[block q] to the Yoff tiles, then advances them with
       // B^T x~.  The C columns and B tiles of quarter q+1 are read while quarter q computes
-      // (LDS returns in order, waits are counted); the scheduling fences keep hipcc from
-      // sinking those reads back next to their uses.
+      // (LDS returns in order, waits are counted) and serve all column tiles of the wave; the
+      // scheduling fences keep hipcc from sinking those reads back next to their uses.
       auto read_cq = [&](int q, bf16x8 (&cf)[4]) {     // [t-tile]
         const unsigned char* cp = Ct + xad(c_z, 64 * q, c_lo);
 #pragma unroll
@@ -394,45 +411,70 @@ __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
             dst[ii][2 * ks + 1] = tr4(bp + ii * 8 + ks * 8192 + 1024);
           }
       };
-      f32x4 yo[4];
+      f32x4 yo[NC][4];
 #pragma unroll
-      for (int ti = 0; ti < 4; ++ti) yo[ti] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int ct = 0; ct < NC; ++ct)
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) yo[ct][ti] = f32x4{0.f, 0.f, 0.f, 0.f};
       auto quarter = [&](int q, const bf16x8 (&cf)[4], const bf16x4 (&bt2)[2][4],
-                         const bf16x8 (&xwf)[2], float dl) {
-        bf16x8 sbq;
+                         const bf16x8 (&xwf)[NC][2], float dl) {
+        bf16x8 sbq[NC];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          sbq[r] = (bf16_t)xacc[2 * q][r];
-          sbq[4 + r] = (bf16_t)xacc[2 * q + 1][r];
-        }
+        for (int ct = 0; ct < NC; ++ct)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            sbq[ct][r] = (bf16_t)xacc[ct][2 * q][r];
+            sbq[ct][4 + r] = (bf16_t)xacc[ct][2 * q + 1][r];
+          }
         if (!SDBG(a, 64))
 #pragma unroll
-        for (int ti = 0; ti < 4; ++ti) yo[ti] = mfma16(cf[ti], sbq, yo[ti]);
+        for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+          for (int ct = 0; ct < NC; ++ct) yo[ct][ti] = mfma16(cf[ti], sbq[ct], yo[ct][ti]);
         if (SDBG(a, 32)) return;
         const f32x2 dl2 = {dl, dl};
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii) {   // v_pk_mul_f32: two state values per instruction
-          f32x2 a0 = {xacc[2 * q + ii][0], xacc[2 * q + ii][1]}, a1 = {xacc[2 * q + ii][2], xacc[2 * q + ii][3]};
-          a0 *= dl2;
-          a1 *= dl2;
-          xacc[2 * q + ii] = f32x4{a0[0], a0[1], a1[0], a1[1]};
-        }
+        for (int ct = 0; ct < NC; ++ct)
+#pragma unroll
+          for (int ii = 0; ii < 2; ++ii) {   // v_pk_mul_f32: two state values per instruction
+            f32x2 a0 = {xacc[ct][2 * q + ii][0], xacc[ct][2 * q + ii][1]}, a1 = {xacc[ct][2 * q + ii][2], xacc[ct][2 * q + ii][3]};
+            a0 *= dl2;
+            a1 *= dl2;
+            xacc[ct][2 * q + ii] = f32x4{a0[0], a0[1], a1[0], a1[1]};
+          }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-          for (int ii = 0; ii < 2; ++ii)
-            xacc[2 * q + ii] = mfma16(cat4(bt2[ii][2 * ks], bt2[ii][2 * ks + 1]), xwf[ks], xacc[2 * q + ii]);
+          for (int ii = 0; ii < 2; ++ii) {
+            const bf16x8 bfrag = cat4(bt2[ii][2 * ks], bt2[ii][2 * ks + 1]);
+#pragma unroll
+            for (int ct = 0; ct < NC; ++ct) xacc[ct][2 * q + ii] = mfma16(bfrag, xwf[ct][ks], xacc[ct][2 * q + ii]);
+          }
       };
       bf16x8 cq[2][4];
       bf16x4 bq[2][2][4];
       PSTAMP(7);
       // ---- first reads
       read_cq(0, cq[0]);
-      bf16x4 xq[2][2], xwq[2][2];
+      bf16x4 xq[NC][2][2], xwq[NC][2][2];
+      f32x4 wq[2][2];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        xwq[ks][0] = tr4(xw + trx + ks * (32 * PW * 2));
-        xwq[ks][1] = tr4(xw + trx + ks * (32 * PW * 2) + 4 * PW * 2);
+        if (RL::WIDE) {      // raw x fragments (kept for Ydiag) and the weights of their eight tokens
+#pragma unroll
+          for (int ct = 0; ct < NC; ++ct) {
+            xq[ct][ks][0] = tr4(xt + trx + 32 * ct + ks * (32 * PW * 2));
+            xq[ct][ks][1] = tr4(xt + trx + 32 * ct + ks * (32 * PW * 2) + 4 * PW * 2);
+          }
+          wq[ks][0] = *(const f32x4*)(&sm.wts[vb][32 * ks + 8 * kq]);
+          wq[ks][1] = *(const f32x4*)(&sm.wts[vb][32 * ks + 8 * kq + 4]);
+        } else {
+#pragma unroll
+          for (int ct = 0; ct < NC; ++ct) {
+            xwq[ct][ks][0] = tr4(xw + trx + 32 * ct + ks * (32 * PW * 2));
+            xwq[ct][ks][1] = tr4(xw + trx + 32 * ct + ks * (32 * PW * 2) + 4 * PW * 2);
+          }
+        }
       }
       const float dl = sm.dl[vb][0];
       read_b2(0, bq[0]);
@@ -441,7 +483,27 @@ __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
       PSTAMP(0);
       read_cq(1, cq[1]);
       read_b2(2, bq[1]);
-      const bf16x8 xwf[2] = {cat4(xwq[0][0], xwq[0][1]), cat4(xwq[1][0], xwq[1][1])};
+      bf16x8 xwf[NC][2];
+#pragma unroll
+      for (int ct = 0; ct < NC; ++ct) {
+        if (RL::WIDE) {
+          // x~ = w_t x on this wave's own fragments: element j of fragment ks is token 32 ks + 8 kq + j
+          // (same products and roundings as the helper waves' scale_piece of the narrow layout)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+              const u32x2 u = __builtin_bit_cast(u32x2, xq[ct][ks][hf]);
+              xwf[ct][ks][4 * hf + 0] = (bf16_t)(bf16_lo(u[0]) * wq[ks][hf][0]);
+              xwf[ct][ks][4 * hf + 1] = (bf16_t)(bf16_hi(u[0]) * wq[ks][hf][1]);
+              xwf[ct][ks][4 * hf + 2] = (bf16_t)(bf16_lo(u[1]) * wq[ks][hf][2]);
+              xwf[ct][ks][4 * hf + 3] = (bf16_t)(bf16_hi(u[1]) * wq[ks][hf][3]);
+            }
+        } else {
+          xwf[ct][0] = cat4(xwq[ct][0][0], xwq[ct][0][1]);
+          xwf[ct][1] = cat4(xwq[ct][1][0], xwq[ct][1][1]);
+        }
+      }
       quarter(0, cq[0], bq[0], xwf, dl);
       __builtin_amdgcn_sched_barrier(0);
       PSTAMP(1);
@@ -460,46 +522,54 @@ __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
 #pragma unroll
       for (int f = 0; f < NFRAG; ++f) mf[f] = ld8(Mf + f * 1024 + lane * 16);
       f32x4 ev[4];
-      bf16x4 xv[4];
+      bf16x4 xv[NC][4];
 #pragma unroll
       for (int ti = 0; ti < 4; ++ti) {
         ev[ti] = *(const f32x4*)(&sm.ecs[vb][16 * ti + 4 * kq]);
-        xv[ti] = tr4(xt + trd + ti * (16 * PW * 2));
-      }
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        xq[ks][0] = tr4(xt + trx + ks * (32 * PW * 2));
-        xq[ks][1] = tr4(xt + trx + ks * (32 * PW * 2) + 4 * PW * 2);
+        for (int ct = 0; ct < NC; ++ct) xv[ct][ti] = tr4(xt + trd + 32 * ct + ti * (16 * PW * 2));
+      }
+      if (!RL::WIDE) {       // (wide: the raw fragments were read at the top of the step)
+#pragma unroll
+        for (int ct = 0; ct < NC; ++ct)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            xq[ct][ks][0] = tr4(xt + trx + 32 * ct + ks * (32 * PW * 2));
+            xq[ct][ks][1] = tr4(xt + trx + 32 * ct + ks * (32 * PW * 2) + 4 * PW * 2);
+          }
       }
       quarter(3, cq[1], bq[1], xwf, dl);
       __builtin_amdgcn_sched_barrier(0);
       PSTAMP(4);
       // ---- y = exp(cs_t) Yoff + M x + D x  (Ydiag accumulates onto the scaled Yoff)
-      const bf16x8 xf[2] = {cat4(xq[0][0], xq[0][1]), cat4(xq[1][0], xq[1][1])};
       if (!SDBG(a, 128)) {
         const f32x2 dh2 = {Dh, Dh};
 #pragma unroll
-        for (int ti = 0; ti < 4; ++ti) {
-          const unsigned x01 = __builtin_bit_cast(u32x2, xv[ti])[0], x23 = __builtin_bit_cast(u32x2, xv[ti])[1];
-          f32x2 y0 = {yo[ti][0], yo[ti][1]}, y1 = {yo[ti][2], yo[ti][3]};
-          y0 = __builtin_elementwise_fma(y0, f32x2{ev[ti][0], ev[ti][1]}, dh2 * f32x2{bf16_lo(x01), bf16_hi(x01)});
-          y1 = __builtin_elementwise_fma(y1, f32x2{ev[ti][2], ev[ti][3]}, dh2 * f32x2{bf16_lo(x23), bf16_hi(x23)});
-          yo[ti] = f32x4{y0[0], y0[1], y1[0], y1[1]};
-        }
+        for (int ct = 0; ct < NC; ++ct) {
+          const bf16x8 xf[2] = {cat4(xq[ct][0][0], xq[ct][0][1]), cat4(xq[ct][1][0], xq[ct][1][1])};
 #pragma unroll
-        for (int ti = 0; ti < 4; ++ti) {
-          const int f0 = ti == 0 ? 0 : ti == 1 ? 1 : ti == 2 ? 2 : 4;
-          yo[ti] = mfma16(mf[f0], xf[0], yo[ti]);
-          if (ti >= 2) yo[ti] = mfma16(mf[f0 + 1], xf[1], yo[ti]);
-        }
-        // packed bf16 results stay in registers across the barrier; they are written to the y
-        // tile at the start of the next step, beside that step's first fragment reads
+          for (int ti = 0; ti < 4; ++ti) {
+            const unsigned x01 = __builtin_bit_cast(u32x2, xv[ct][ti])[0], x23 = __builtin_bit_cast(u32x2, xv[ct][ti])[1];
+            f32x2 y0 = {yo[ct][ti][0], yo[ct][ti][1]}, y1 = {yo[ct][ti][2], yo[ct][ti][3]};
+            y0 = __builtin_elementwise_fma(y0, f32x2{ev[ti][0], ev[ti][1]}, dh2 * f32x2{bf16_lo(x01), bf16_hi(x01)});
+            y1 = __builtin_elementwise_fma(y1, f32x2{ev[ti][2], ev[ti][3]}, dh2 * f32x2{bf16_lo(x23), bf16_hi(x23)});
+            yo[ct][ti] = f32x4{y0[0], y0[1], y1[0], y1[1]};
+          }
 #pragma unroll
-        for (int ti = 0; ti < 4; ++ti) {
-          typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-          const bf16x2 p01 = {(bf16_t)yo[ti][0], (bf16_t)yo[ti][1]}, p23 = {(bf16_t)yo[ti][2], (bf16_t)yo[ti][3]};
-          ypk[ti][0] = __builtin_bit_cast(unsigned, p01);
-          ypk[ti][1] = __builtin_bit_cast(unsigned, p23);
+          for (int ti = 0; ti < 4; ++ti) {
+            const int f0 = ti == 0 ? 0 : ti == 1 ? 1 : ti == 2 ? 2 : 4;
+            yo[ct][ti] = mfma16(mf[f0], xf[0], yo[ct][ti]);
+            if (ti >= 2) yo[ct][ti] = mfma16(mf[f0 + 1], xf[1], yo[ct][ti]);
+          }
+          // packed bf16 results stay in registers across the barrier; they are written to the y
+          // tile at the start of the next step, beside that step's first fragment reads
+#pragma unroll
+          for (int ti = 0; ti < 4; ++ti) {
+            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+            const bf16x2 p01 = {(bf16_t)yo[ct][ti][0], (bf16_t)yo[ct][ti][1]}, p23 = {(bf16_t)yo[ct][ti][2], (bf16_t)yo[ct][ti][3]};
+            ypk[ct][ti][0] = __builtin_bit_cast(unsigned, p01);
+            ypk[ct][ti][1] = __builtin_bit_cast(unsigned, p23);
+          }
         }
       }
       PSTAMP(5);
@@ -511,11 +581,13 @@ __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
 #endif
     write_y(nchunks - 1);
     float* fin = a.nseg > 1 ? a.seg_state + (int64_t)seg * gridDim.y * a.H * a.P * SN : a.final_state;
-    if (fin && pvalid) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
-        *(f32x4*)(fin + (((int64_t)b * a.H + h) * a.P + p_base + pcol) * SN + 32 * (i >> 1) + 8 * kq + 4 * (i & 1)) = xacc[i];
-    }
+    for (int ct = 0; ct < NC; ++ct)
+      if (fin && pvalid[ct]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          *(f32x4*)(fin + (((int64_t)b * a.H + h) * a.P + p_base + pcol[ct]) * SN + 32 * (i >> 1) + 8 * kq + 4 * (i & 1)) = xacc[ct][i];
+      }
     SLICE_BARRIER();   // final (y of the last chunk is stored after it)
   } else if (wave == RL::XIO) {
     // ============================================================ x / dt DMA, y stores
@@ -558,30 +630,32 @@ __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
       for (int k = 0; k < NPI; ++k)
         if (full || t0 + prow[k] < L) *(bf16x8*)(yc + y_off[k]) = *(const bf16x8*)(ytb + (lane + 64 * k) * 16);
     };
+    constexpr int DDT = RL::WIDE ? DXS + 2 : DXS + 1;      // dt copy distance (chunks)
     for (int c = 0; c < DXS; ++c) issue_x(min(c, nchunks - 1));
-    for (int c = 0; c <= DXS; ++c) issue_dt(c);
+    for (int c = 0; c < DDT; ++c) issue_dt(c);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     SLICE_BARRIER();   // P1
-    if (RL::WIDE) {    // this wave is the prep wave too
+    if (RL::WIDE) {    // wide: this wave prepares the vectors too (no y stores here)
       prep(0);
       if (nchunks > 1) prep(1);
     }
     SLICE_BARRIER();   // P2
     SLICE_BARRIER();   // P3
-    // x of chunk c+2 and dt of chunk c+3 must have landed at the end of step c (the helpers build
-    // x~_{c+2} at step c+1).  Narrow: they were issued two steps ago, and since then this wave issued
-    // 2 x (NPI stores + NPI + 1 copies) — two steps of flight time.  Wide (x issued 2 chunks ahead):
-    // they are this step's own copies, everything is waited for; the lines were touched two steps
-    // earlier by a mask wave, so the copies come from L2.
-    constexpr int FLY = (DXS - 2) * (2 * NPI + 1);
+    // Narrow: x of chunk c+2 and dt of chunk c+3 must have landed at the end of step c (the helpers
+    // build x~_{c+2} at step c+1); they were issued two steps ago, and since then this wave issued
+    // 2 x (NPI stores + NPI + 1 copies) — two steps of flight time.  Wide (no x~ helpers, x issued 3
+    // chunks ahead): x of chunk c+1 must have landed at the end of step c (the slice-waves read it at
+    // step c+1) and dt of chunk c+3 (prep runs two chunks ahead); both were issued two steps ago (x 3
+    // and dt 5 chunks ahead), the 2 (NPI + 1) copies issued since then may still be in flight.
+    constexpr int FLY = RL::WIDE ? (DXS - 1) * (NPI + 1) : (DXS - 2) * (2 * NPI + 1);
     for (int c = 0; c < nchunks; ++c) {
-      if (c > 1 && !SDBG(a, 4)) store_y(c - 2);   // written by the slice-waves at the start of step c-1
+      if (!RL::WIDE && c > 1 && !SDBG(a, 4)) store_y(c - 2);   // written by the slice-waves at the start of step c-1
       const bool issued = c + DXS < nchunks && !SDBG(a, 4);
       if (issued) {
         issue_x(c + DXS);
-        issue_dt(c + DXS + 1);
+        issue_dt(c + DDT);
       }
-      if (RL::WIDE && c + 2 < nchunks && !SDBG(a, 16)) prep(c + 2);
+      if (RL::WIDE && c + 2 < nchunks && !SDBG(a, 16)) prep(c + 2);     // under the copies just issued
       if constexpr (FLY > 0) {
         if (issued && c > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FLY) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -590,9 +664,9 @@ __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
       }
       SLICE_BARRIER();
     }
-    if (nchunks > 1) store_y(nchunks - 2);
+    if (!RL::WIDE && nchunks > 1) store_y(nchunks - 2);
     SLICE_BARRIER();   // final: the slice-waves have flushed the last chunk's y tile
-    store_y(nchunks - 1);
+    if (!RL::WIDE) store_y(nchunks - 1);
     if (RL::WIDE) {
       float* td = a.nseg > 1 ? a.seg_decay + (int64_t)seg * gridDim.y * a.H : a.total_decay;
       if (td && slice == 0 && lane == 0) td[(int64_t)b * a.H + h] = decay_total;
@@ -602,12 +676,13 @@ __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
     const int q = RL::bc(wave);
     const bf16_t* Bg = a.Bm + (int64_t)b * a.bsb + (int64_t)g * a.bsg + (int64_t)t_first * a.bsl;
     const bf16_t* Cg = a.Cm + (int64_t)b * a.csb + (int64_t)g * a.csg + (int64_t)t_first * a.csl;
-    int brow[4];
-    unsigned off_b[4], off_c[4];
-    int cg_b[4], cg_c[4];
+    constexpr int KP = 16 / RL::NBCW;        // 1 KiB pieces (4 token rows) of B per wave and chunk; as many of C
+    int brow[KP];
+    unsigned off_b[KP], off_c[KP];
+    int cg_b[KP], cg_c[KP];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int row = 16 * q + 4 * k + (lane >> 4);
+    for (int k = 0; k < KP; ++k) {
+      const int row = 4 * KP * q + 4 * k + (lane >> 4);
       brow[k] = row;
       cg_b[k] = (lane & 15) ^ (4 * (row & 3));
       cg_c[k] = (lane & 15) ^ (row & 15);
@@ -621,26 +696,36 @@ __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
       const void* sc = uniform_ptr(Cg + (int64_t)t0 * a.csl);
       const bool full = t0 + SQ <= L;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < KP; ++k) {
         unsigned ob = off_b[k], oc = off_c[k];
         if (!full) {
           const int rr = min(brow[k], L - 1 - t0);
           ob = (unsigned)((rr * a.bsl + cg_b[k] * 8) * 2);
           oc = (unsigned)((rr * a.csl + cg_c[k] * 8) * 2);
         }
-        glds16(sb, ob, lds_addr_of(sm.bt[slot] + (4 * q + k) * 512));
-        glds16(sc, oc, lds_addr_of(sm.ct[slot] + (4 * q + k) * 512));
+        glds16(sb, ob, lds_addr_of(sm.bt[slot] + (KP * q + k) * 512));
+        glds16(sc, oc, lds_addr_of(sm.ct[slot] + (KP * q + k) * 512));
       }
     };
-    // x~ pieces of this wave: one of the first four (narrow: the W_SCALE wave takes the rest), or
-    // every fourth piece (wide: no W_SCALE wave)
+    // x~ pieces (narrow layout only): this wave takes one of the first four, the W_SCALE wave the rest
     auto scale_mine = [&](int c) {
-      if (RL::WIDE) {
+      if (!RL::WIDE && q < NPI) scale_piece(c, q);
+    };
+    // wide: the two B/C waves store the y tiles (every other 1 KiB piece each).  (Measured: moved to
+    // the lighter mask wave the stores' completion sits in front of that wave's compiler-placed waits
+    // and makes it the pole of the step: 4 380 against 3 930 ticks.)
+    bf16_t* ygw = a.y + (int64_t)b * a.ysb + (int64_t)t_first * a.ysl + (int64_t)h * a.P + p_base;
+    auto store_y_half = [&](int c) {
+      if (!RL::WIDE) return;
+      const int t0 = c * SQ;
+      const unsigned char* ytb = reinterpret_cast<const unsigned char*>(sm.yt[c & 1]);
+      bf16_t* yc = ygw + (int64_t)t0 * a.ysl;
 #pragma unroll
-        for (int k = 0; k < (NPI + 3) / 4; ++k)
-          if (q + 4 * k < NPI) scale_piece(c, q + 4 * k);
-      } else if (q < NPI) {
-        scale_piece(c, q);
+      for (int k = 0; k < (NPI + 1) / 2; ++k) {
+        const int i = lane + 64 * (2 * k + q);
+        const int row = i / NPC;
+        if (2 * k + q < NPI && t0 + row < L)
+          *(bf16x8*)(yc + (int64_t)row * a.ysl + (i % NPC) * 8) = *(const bf16x8*)(ytb + i * 16);
       }
     };
     issue_bc(0);
@@ -653,13 +738,16 @@ __global__ __launch_bounds__(STHREADS) void ssd_slice_kernel(SliceArgs a) {
     for (int c = 0; c < nchunks; ++c) {
       const bool issued = c + BD < nchunks && !SDBG(a, 2);
       if (issued) issue_bc(c + BD);
+      if (c > 1 && !SDBG(a, 4)) store_y_half(c - 2);   // written by the slice-waves at the start of step c-1
       if (c + 1 < nchunks && !SDBG(a, 16)) scale_mine(c + 1);
-      // chunk c+1 must have landed; with a ring of 3 chunk c+2 (this step's 8 copies) stays in flight
-      if (BD > 1 && issued) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      // chunk c+1 must have landed; chunk c+2 (this step's 2 KP copies) stays in flight
+      if (BD > 1 && issued) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * KP) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       SLICE_BARRIER();
     }
-    SLICE_BARRIER();   // final
+    if (nchunks > 1) store_y_half(nchunks - 2);
+    SLICE_BARRIER();   // final: the slice-waves have flushed the last chunk's y tile
+    store_y_half(nchunks - 1);
   } else if (RL::mask(wave) >= 0) {
     // ============================================================ decay mask M = CB .* L
     // M[t][s] = CB[t][s] 2^(cs2_t - cs2_s) dt_s for s <= t (cs2 = cs log2 e), else 0, built
@@ -847,7 +935,7 @@ hipError_t launch_slice(const SliceArgs& a, dim3 grid, hipStream_t st) {
   hipError_t e = hipFuncSetAttribute((const void*)ssd_slice_kernel<PT, PW>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  ssd_slice_kernel<PT, PW><<<grid, STHREADS, lds, st>>>(a);
+  ssd_slice_kernel<PT, PW><<<grid, Roles<PW>::NWAVES * 64, lds, st>>>(a);
   return hipSuccess;
 }
 
@@ -986,10 +1074,10 @@ int tv_ssd_slice_launch(const void* x, const void* dt, const void* A, const void
     case 24: e = launch_slice<2, 24>(a, grid, st); break;
     case 32: e = launch_slice<2, 32>(a, grid, st); break;
     case 40: e = launch_slice<3, 40>(a, grid, st); break;
-    case 56: e = launch_slice<4, 56>(a, grid, st); break;
-    case 64: e = launch_slice<4, 64>(a, grid, st); break;
-    case 72: e = launch_slice<5, 72>(a, grid, st); break;
-    case 80: e = launch_slice<5, 80>(a, grid, st); break;
+    case 56: e = launch_slice<2, 56>(a, grid, st); break;      // wide: PT slice-waves x 2 column tiles
+    case 64: e = launch_slice<2, 64>(a, grid, st); break;
+    case 72: e = launch_slice<3, 72>(a, grid, st); break;
+    case 80: e = launch_slice<3, 80>(a, grid, st); break;
     default: TV_UNSUPPORTED("ssd_slice: slice width %d", a.pw);
   }
   if (e != hipSuccess) {

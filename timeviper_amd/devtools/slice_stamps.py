@@ -11,8 +11,8 @@ from timeviper_amd import _capi, kernels as K  # noqa: E402
 
 ROLE3 = {0: "slice0", 1: "slice1", 2: "slice2", 3: "xio", 4: "bc0+sc", 5: "bc1+sc", 6: "bc2+sc", 11: "bc3+sc",
          7: "mask0", 8: "mask1", 9: "prep", 10: "scale4"}
-ROLE4 = {0: "slice0", 1: "slice1", 2: "slice2", 3: "slice3", 4: "slice4", 5: "xio+prep", 6: "bc0+sc", 7: "bc1+sc",
-         8: "bc2+sc", 9: "bc3+sc", 10: "mask0", 11: "mask1"}
+ROLE4 = {0: "slice0 (2 tiles)", 1: "slice1 (2 tiles)", 2: "slice2 (1 tile)", 3: "x/dt copies + prep", 4: "bc0 + y", 5: "bc1 + y",
+         6: "mask0", 7: "mask1"}
 
 
 def main():
@@ -39,7 +39,7 @@ def main():
     steps = (L + 63) // 64
     if impl == 4:
         steps = (steps + 1) // 2          # two concurrent segments at 128 heads
-    for w in range(12):
+    for w in range(8 if impl == 4 else 12):
         wait, total = out[w], out[16 + w]
         print(f"wave {w:2d} {ROLE.get(w, '?'):12s} total {total/steps:8.0f} ticks/step   busy {(total-wait)/steps:8.0f}   "
               f"parked {wait/total:6.1%}")
