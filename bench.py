@@ -12,7 +12,9 @@ that causal attention does not leave the last rank behind) and the total work is
 
 roofline: the SSD selective-scan kernel — algorithmic bytes (45 312 B per
 token per Mamba layer at Nano dims, bf16) / its launch durations measured live with
-events on the launch stream inside the timed steps.
+events on the launch stream inside the timed steps.  rooflines: the same for the ViT
+attention, the causal LLM attention (useful FLOPs against the dense bf16 MFMA peak) and the
+patch-embedding GEMM (MFMA and HBM).
 cpu_baseline: the CPU oracle (eager PyTorch fp32 restatement of the reference path),
 timed on this box's host cores on a bounded sample and scaled to frames/s.
 """
@@ -35,52 +37,139 @@ TOK_PER_FRAME = 16                                         # arch_specifier tome
 HBM_PEAK_GBS = 8000.0                                      # MI355X_MICROARCH.md
 
 
+MFMA_BF16_PEAK_TFLOPS = 2500.0                             # dense bf16, MI355X_MICROARCH.md
+SCAN_SOURCES = ("ssd_slice.hip", "ssd_correct.hip", "ssd_scan.hip", "ssd_common.hpp")
+
+
 def scan_bytes_per_token(cfg) -> int:
     H, P, G, N = cfg.mamba_num_heads, cfg.mamba_head_dim, cfg.n_groups, cfg.ssm_state_size
     return 2 * H * P + 2 * H + 2 * 2 * G * N + 2 * H * P   # x, dt, B+C read; y written (bf16)
 
 
-class ScanTimer:
-    """Wraps kernels.mamba_chunk_scan_combined with start/stop events on the launch stream."""
+def scan_source_id() -> str:
+    """Hash of the scan kernels' sources: the PMC traffic file is only valid for the kernels it was
+    taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in SCAN_SOURCES:
+        h.update((ROOT / "timeviper_amd" / "csrc" / name).read_bytes())
+    return h.hexdigest()[:16]
+
+
+class OpTimers:
+    """Event-timed wrappers (events on the launch stream, inside the timed steps) around the operators
+    whose roofline the bench line carries: the SSD scan (HBM), the ViT and the causal LLM attention
+    (MFMA), the patch-embedding GEMM (MFMA and HBM)."""
 
     def __init__(self, K):
-        self.K, self.orig, self.rec, self.on = K, K.mamba_chunk_scan_combined, [], False
+        self.K, self.on, self.rec, self.saved = K, False, {}, {}
 
-    def __enter__(self):
-        def timed(x, *a, **kw):
-            if not self.on:
-                return self.orig(x, *a, **kw)
+    def _wrap(self, name, classify):
+        orig = getattr(self.K, name)
+        self.saved[name] = orig
+
+        def timed(*a, **kw):
+            key = classify(*a, **kw) if self.on else None
+            if key is None:
+                return orig(*a, **kw)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            out = self.orig(x, *a, **kw)
+            out = orig(*a, **kw)
             e1.record()
-            self.rec.append((e0, e1, x.shape[0] * x.shape[1]))
+            self.rec.setdefault(key[0], []).append((e0, e1, key[1]))
             return out
-        self.K.mamba_chunk_scan_combined = timed
+        setattr(self.K, name, timed)
+
+    def __enter__(self):
+        def scan(x, *a, **kw):
+            return ("scan", x.shape[0] * x.shape[1])                       # tokens
+
+        def attn(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False, return_lse=False):
+            B, Lq, Hq, D = q.shape
+            Lk = k.shape[1]
+            if causal and Lq > 1:
+                pairs = Lq * Lk - Lq * (Lq - 1) // 2                       # bottom-right aligned mask
+                return ("attn_causal", 4.0 * B * Hq * D * pairs)
+            if not causal and Lq == Lk and Lq <= 1025:                      # ViT frames / tubes
+                return ("attn_vit", 4.0 * B * Hq * D * Lq * Lk)
+            return None                                                      # TransV cross-attention, decode
+
+        def patch(pixels, weight, *a, **kw):
+            F_, Cin, Hh, Ww = pixels.shape
+            pp = weight.shape[-1]
+            n = (Hh // pp) * (Ww // pp)
+            flops = 2.0 * F_ * n * Cin * pp * pp * weight.shape[0]
+            byts = F_ * (Cin * Hh * Ww + n * weight.shape[0]) * pixels.element_size()
+            return ("patch_embed", (flops, byts))
+        self._wrap("mamba_chunk_scan_combined", scan)
+        self._wrap("flash_attn_func", attn)
+        self._wrap("patch_embed", patch)
         return self
 
     def __exit__(self, *exc):
-        self.K.mamba_chunk_scan_combined = self.orig
+        for name, orig in self.saved.items():
+            setattr(self.K, name, orig)
 
-    def summary(self, bytes_per_token):
-        if not self.rec:
+    def _ms(self, key):
+        r = self.rec.get(key, [])
+        return sum(e0.elapsed_time(e1) for e0, e1, _ in r), r
+
+    def scan_roofline(self, bytes_per_token):
+        ms, r = self._ms("scan")
+        if not r:
             return None
-        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.rec)
-        tokens = sum(n for _, _, n in self.rec)
+        tokens = sum(n for _, _, n in r)
         gbs = tokens * bytes_per_token / (ms * 1e-3) / 1e9
-        # HBM bytes actually moved per algorithmic byte: rocprofv3 PMC passes (FETCH_SIZE x2,
-        # WRITE_SIZE) on this op, committed under profiles/ (PMC cannot be collected from here)
-        traffic, src = None, None
-        tf = Path(__file__).resolve().parent / "profiles" / "r01_ssd_scan_traffic.json"
-        if tf.exists():
-            ratio = json.loads(tf.read_text())["hbm_over_algorithmic"]
-            traffic, src = round(gbs * ratio, 1), f"profiles/{tf.name}: HBM bytes = {ratio:.3f} x algorithmic"
-        return {"bound": "hbm", "kernel": "ssd_scan (tv_ssd_scan_fwd: ssd_cb_kernel + ssd_slice_kernel)",
-                "achieved": round(gbs, 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                "traffic": traffic, "traffic_source": src, "launches": len(self.rec),
-                "avg_launch_us": round(ms * 1e3 / len(self.rec), 1),
-                "bytes_per_token": bytes_per_token}
+        # HBM bytes actually moved per algorithmic byte: rocprofv3 PMC passes (FETCH_SIZE x2, WRITE_SIZE,
+        # MI355X_MICROARCH.md) on this op, committed under profiles/ (PMC cannot be collected from
+        # here).  The file names the kernel sources it was taken on: a ratio from other kernels is
+        # refused, not silently reused.
+        traffic, src = None, "no profiles/r*_ssd_scan_traffic.json"
+        files = sorted((ROOT / "profiles").glob("r*_ssd_scan_traffic.json"))
+        if files:
+            tf = json.loads(files[-1].read_text())
+            if tf.get("scan_source_id") == scan_source_id():
+                ratio = tf["hbm_over_algorithmic"]
+                traffic = round(gbs * ratio, 1)
+                src = f"profiles/{files[-1].name} ({tf.get('kernel')}): HBM bytes = {ratio:.3f} x algorithmic"
+            else:
+                src = (f"profiles/{files[-1].name} was taken on other scan kernels (source id "
+                       f"{tf.get('scan_source_id')}, tree {scan_source_id()}): re-run devtools/pmc_scan.sh")
+        return {"bound": "hbm", "kernel": "ssd_scan (tv_ssd_scan_fwd: ssd_cb_kernel + ssd_slice_kernel<3,80> x 2 "
+                                          "segments + ssd_seg_combine + ssd_correct kernels)",
+                "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                "traffic": traffic, "traffic_source": src, "launches": len(r),
+                "avg_launch_us": round(ms * 1e3 / len(r), 1), "bytes_per_token": bytes_per_token}
+
+    def mfma_roofline(self, key, kernel):
+        ms, r = self._ms(key)
+        if not r:
+            return None
+        flops = sum(f for _, _, f in r)
+        tf = flops / (ms * 1e-3) / 1e12
+        return {"bound": "mfma", "kernel": kernel, "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                "launches": len(r), "avg_launch_us": round(ms * 1e3 / len(r), 1)}
+
+    def patch_rooflines(self):
+        ms, r = self._ms("patch_embed")
+        if not r:
+            return []
+        flops = sum(f[0] for _, _, f in r)
+        byts = sum(f[1] for _, _, f in r)
+        tf, gbs = flops / (ms * 1e-3) / 1e12, byts / (ms * 1e-3) / 1e9
+        base = {"kernel": "patch_embed_kernel (tv_patch_embed_fwd)", "launches": len(r),
+                "avg_launch_us": round(ms * 1e3 / len(r), 1), "traffic": None}
+        return [dict(base, bound="mfma", achieved=round(tf, 1), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
+                     frac=round(tf / MFMA_BF16_PEAK_TFLOPS, 4)),
+                dict(base, bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                     frac=round(gbs / HBM_PEAK_GBS, 4))]
+
+    def all_rooflines(self, bytes_per_token):
+        out = [self.scan_roofline(bytes_per_token),
+               self.mfma_roofline("attn_vit", "flash_fwd_kernel, ViT frames (non-causal, head_dim 72; useful FLOPs)"),
+               self.mfma_roofline("attn_causal", "flash_fwd_kernel, causal GQA (LLM attention layers; useful FLOPs)")]
+        return [o for o in out if o] + self.patch_rooflines()
 
 
 def cpu_baseline(cfg, frames_sample=256, vit_frames=16):
@@ -226,7 +315,7 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    with torch.inference_mode(), ScanTimer(K) as st:
+    with torch.inference_mode(), OpTimers(K) as st:
         for _ in range(args.warmup):
             step()
         barrier()
@@ -258,7 +347,10 @@ def main():
                        "frames": T, "tokens": L, "pdrop": pd, "merge_module": "CrossAttention" if pd else "no_merge",
                        "parallelism": "single GPU" if world == 1 else f"sequence-sharded x{world} (RCCL)",
                        "weights": "random init, seed 0"},
-            "roofline": st.summary(scan_bytes_per_token(cfg)),
+            # the kernel north_star names (dominant among the hand-written HBM-bound ones) ...
+            "roofline": st.scan_roofline(scan_bytes_per_token(cfg)),
+            # ... and every kernel with a stated roof, all event-timed inside the timed steps
+            "rooflines": st.all_rooflines(scan_bytes_per_token(cfg)),
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)

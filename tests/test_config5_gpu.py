@@ -100,11 +100,16 @@ def test_config5_dual_encoder_4096_frames_equals_members_run_alone():
             a = pj[bid_d](feats[bid_d], compress=True, local_num_frames=1)
             b = pj[bid_v](feats[bid_v], compress=True, local_num_frames=4)
             assert torch.equal(vis_clip[:, 0::2], a) and torch.equal(vis_clip[:, 1::2], b.reshape(256, 16, -1))
-            # the 4 096-frame call (eight clips per launch) against this clip on its own: the GEMM library
-            # picks kernels by shape, and ToMe's matching is discrete (a last-bit difference in a
-            # similarity can merge another pair), so a few tokens may differ: 95 % of the rows agree
-            e = ((vis[lo:lo + 256].float() - vis_clip.float()).norm(dim=-1) / vis_clip.float().norm(dim=-1)).flatten()
-            assert torch.quantile(e, 0.95) < 3e-2, torch.quantile(e, 0.95)
+        # eight clips per launch (what encode_vision feeds the towers) against the clips on their own, at the
+        # FEATURE level: the GEMM library picks kernels by shape, so the rows agree to bf16 noise, not bit for
+        # bit (after the projector the comparison would be dominated by ToMe's discrete matching, where a
+        # last-bit difference in a similarity merges another pair of tokens)
+        fused = vb(pix[:2048], is_video=True, clip_frames=256)
+        for cidx in (0, 7):
+            one = vb(pix[256 * cidx:256 * cidx + 256], is_video=True, clip_frames=256)
+            assert rel(fused[bid_d][256 * cidx:256 * cidx + 256].float(), one[bid_d].float()) < 2e-2
+            assert rel(fused[bid_v][64 * cidx:64 * cidx + 64].float(), one[bid_v].float()) < 2e-2
+        del fused, one
         tok = vlm.default_token_id
         ids = torch.cat([torch.arange(3, 23, device=DEV), torch.full((T,), tok, device=DEV),
                          torch.arange(30, 110, device=DEV)])[None]
