@@ -68,14 +68,7 @@ struct AttnArgs {
 // XOR-swizzled on the DMA source address so that the row reads of K (ds_read_b128, chunk ^
 // row%16) and the transposing reads of V (ds_read_b64_tr_b16, chunk ^ 4(row%4)) are bank
 // conflict free.  Chunks past head_dim are never copied (the K ones QK^T reads are zeroed once).
-// LAG (8-wave work-groups): waves 4-7 — the second wave of every SIMD — run half a tile behind their
-// partners: in the window of tile t they first finish tile t-1 (softmax + PV, scores kept in registers
-// across the barrier) and then compute the scores of tile t.  With every wave in the same phase after
-// each barrier, both waves of a SIMD issued their MFMAs together and their softmax together (matrix pipe
-// idle while both ran VALU: 25 % MFMA utilisation on the ViT shape); lagged, one wave's MFMAs run beside
-// the other's softmax.  The lagging half still reads V of tile t-1 while the copies of tile t+2 land,
-// so the ring has 4 stages (of 64 keys) instead of 3 (of 96).
-template <typename T, int KS, int DT, int NW, int KT, bool LAG>
+template <typename T, int KS, int DT, int NW, int KT>
 __global__ __launch_bounds__(NW * 64) void flash_fwd_kernel(AttnArgs a) {
   constexpr int FA_KB = 32 * KT;     // keys per tile
   constexpr int NPK = FA_KB / 4;     // 1 KiB DMA pieces (4 key rows) of K per tile; as many of V
@@ -84,7 +77,7 @@ __global__ __launch_bounds__(NW * 64) void flash_fwd_kernel(AttnArgs a) {
   constexpr int QB = NW * FA_QW;     // query rows per workgroup
   constexpr int ROWB = 256;          // LDS bytes per key row
   constexpr int TILEB = FA_KB * ROWB;
-  constexpr int NS = LAG ? 4 : 3;    // ring stages
+  constexpr int NS = 3;              // ring stages
   constexpr int PPW = 2 * NPK / NW;  // DMA pieces per wave and tile
   static_assert(2 * NPK % NW == 0, "pieces must divide over the waves");
   extern __shared__ __attribute__((aligned(16))) unsigned char fa_smem[];
@@ -215,138 +208,124 @@ __global__ __launch_bounds__(NW * 64) void flash_fwd_kernel(AttnArgs a) {
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
-  // the two halves of a tile's work, on the scores `sacc` of this wave
-  auto qk = [&](int kt, const bool ahead, f32x16 (&sacc)[KT]) {
-    const unsigned char* cK = sK + (kt % NS) * TILEB;
-    // ---- S^T = K . Q^T  (2 key sub-tiles of 32); all K fragment reads ahead of the MFMAs;
-    // the copies of tile kt+2 are issued between the MFMAs, whose pipe time hides them ----
-    v8 kf[KT][KS];
-#pragma unroll
-    for (int t = 0; t < KT; ++t)
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) kf[t][ks] = *(const v8*)(cK + t * (32 * ROWB) + k_rd[ks]);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int t = 0; t < KT; ++t) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) sacc[t][i] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        sacc[t] = Frag<T>::mfma(kf[t][ks], qf[ks], sacc[t]);
-        // PPW pieces spread over the 2*KS MFMAs
-        constexpr int every = (KT * KS) / PPW > 0 ? (KT * KS) / PPW : 1;
-        const int idx = t * KS + ks;
-        if (ahead && idx % every == 0 && idx / every < PPW) issue_piece(kt + 2, idx / every);
-      }
-    }
-    if (ahead) {      // pieces that did not fit the spacing (PPW > 2*KS)
-#pragma unroll
-      for (int i = (KT * KS) / ((KT * KS) / PPW > 0 ? (KT * KS) / PPW : 1); i < PPW; ++i) issue_piece(kt + 2, i);
-    }
-  };
-  auto softmax_pv = [&](int kt, f32x16 (&sacc)[KT]) {
-    const int kbase = kt * FA_KB;
-    const unsigned char* cV = sV + (kt % NS) * TILEB;
-    // ---- mask, running max on the raw scores (the scale is positive, so it commutes with
-    // max), then p = 2^(s*scale - m) as one FMA + v_exp per score; packed fp32 math ----
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    const bool need_mask = (kbase + FA_KB > a.Lk) || (a.causal && kbase + FA_KB - 1 > q0 + shift);
-    if (need_mask) {
-#pragma unroll
-      for (int t = 0; t < KT; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int key = kbase + t * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-          const bool ok = key < a.Lk && (!a.causal || key <= qrow + shift);
-          sacc[t][i] = ok ? sacc[t][i] : -INFINITY;
-        }
-    }
-    float tmax = -INFINITY;
-#pragma unroll
-    for (int t = 0; t < KT; ++t)
-#pragma unroll
-      for (int i = 0; i < 16; i += 2) tmax = fmaxf(fmaxf(tmax, sacc[t][i]), sacc[t][i + 1]);
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    const float m_new = fmaxf(m_run, tmax * a.scale_log2);
-    // rows with nothing visible yet keep m=-inf: use 0 as the exponent base
-    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);  // m_run=-inf -> 0
-    const f32x2 sc2 = {a.scale_log2, a.scale_log2}, nm2 = {-m_use, -m_use};
-    f32x2 ps2 = {0.f, 0.f};
-#pragma unroll
-    for (int t = 0; t < KT; ++t)
-#pragma unroll
-      for (int i = 0; i < 16; i += 2) {
-        const f32x2 e = __builtin_elementwise_fma(f32x2{sacc[t][i], sacc[t][i + 1]}, sc2, nm2);
-        const f32x2 pp = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
-        sacc[t][i] = pp[0];
-        sacc[t][i + 1] = pp[1];
-        ps2 += pp;
-      }
-    l_run = l_run * alpha + (ps2[0] + ps2[1]);
-    // the accumulators only need rescaling when some row's maximum moved (wave-uniform test)
-    if (__builtin_amdgcn_ballot_w64(m_new > m_run)) {
-      const f32x2 al2 = {alpha, alpha};
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int i = 0; i < 16; i += 2) {
-          const f32x2 v = f32x2{oacc[dt][i], oacc[dt][i + 1]} * al2;
-          oacc[dt][i] = v[0];
-          oacc[dt][i + 1] = v[1];
-        }
-    }
-    m_run = m_new;
-
-    // ---- O^T += V^T . P^T over 4 k-steps of 16 keys; the V^T fragments of k-step s+1 are in
-    // flight while k-step s multiplies ----
-    {
-      auto read_v = [&](int s_, v4 (&lo)[DT], v4 (&hi)[DT]) {
-        // element j of this lane is key row 16s + 8(j>>2) + 4hh + (j&3) of the tile
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-          lo[dt] = Frag<T>::tr_read((const T*)(cV + s_ * (16 * ROWB) + v_rd[dt]));
-          hi[dt] = Frag<T>::tr_read((const T*)(cV + s_ * (16 * ROWB) + 8 * ROWB + v_rd[dt]));
-        }
-      };
-      v4 vlo[2][DT], vhi[2][DT];
-      read_v(0, vlo[0], vhi[0]);
-#pragma unroll
-      for (int s_ = 0; s_ < 2 * KT; ++s_) {
-        if (s_ < 2 * KT - 1) read_v(s_ + 1, vlo[(s_ + 1) & 1], vhi[(s_ + 1) & 1]);
-        const int t = s_ >> 1, rb = (s_ & 1) * 8;
-        v8 pf;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) pf[j] = from_f32<T>(sacc[t][rb + j]);
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-          v8 vf;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { vf[j] = vlo[s_ & 1][dt][j]; vf[4 + j] = vhi[s_ & 1][dt][j]; }
-          oacc[dt] = Frag<T>::mfma(vf, pf, oacc[dt]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-  };
-  const bool lag = LAG && wave >= NW / 2;       // wave-uniform
-  f32x16 sacc[KT];
-  int pend = -1;                                // lagging waves: tile whose softmax + PV is still owed
   for (int kt = 0; kt < ntiles; ++kt) {
     const int kbase = kt * FA_KB;
     const bool ahead = kt + 2 < ntiles;
+    const unsigned char* cK = sK + (kt % NS) * TILEB;
+    const unsigned char* cV = sV + (kt % NS) * TILEB;
+
     // wave-uniform skip of tiles entirely above this wave's causal diagonal
     const int wave_q_last = q0 + FA_QW - 1;
     const bool active = !(a.causal && kbase > wave_q_last + shift);
-    if (lag && pend >= 0) {
-      softmax_pv(pend, sacc);
-      pend = -1;
-    }
     if (!active && ahead) issue_tile(kt + 2);
     if (active) {
-      qk(kt, ahead, sacc);
-      if (lag) pend = kt;
-      else softmax_pv(kt, sacc);
+      // ---- S^T = K . Q^T  (2 key sub-tiles of 32); all K fragment reads ahead of the MFMAs;
+      // the copies of tile kt+2 are issued between the MFMAs, whose pipe time hides them ----
+      f32x16 sacc[KT];
+      v8 kf[KT][KS];
+#pragma unroll
+      for (int t = 0; t < KT; ++t)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) kf[t][ks] = *(const v8*)(cK + t * (32 * ROWB) + k_rd[ks]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < KT; ++t) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sacc[t][i] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          sacc[t] = Frag<T>::mfma(kf[t][ks], qf[ks], sacc[t]);
+          // PPW pieces spread over the 2*KS MFMAs
+          constexpr int every = (KT * KS) / PPW > 0 ? (KT * KS) / PPW : 1;
+          const int idx = t * KS + ks;
+          if (ahead && idx % every == 0 && idx / every < PPW) issue_piece(kt + 2, idx / every);
+        }
+      }
+      if (ahead) {      // pieces that did not fit the spacing (PPW > 2*KS)
+#pragma unroll
+        for (int i = (KT * KS) / ((KT * KS) / PPW > 0 ? (KT * KS) / PPW : 1); i < PPW; ++i) issue_piece(kt + 2, i);
+      }
+      // ---- mask, running max on the raw scores (the scale is positive, so it commutes with
+      // max), then p = 2^(s*scale - m) as one FMA + v_exp per score; packed fp32 math ----
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      const bool need_mask = (kbase + FA_KB > a.Lk) || (a.causal && kbase + FA_KB - 1 > q0 + shift);
+      if (need_mask) {
+#pragma unroll
+        for (int t = 0; t < KT; ++t)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int key = kbase + t * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+            const bool ok = key < a.Lk && (!a.causal || key <= qrow + shift);
+            sacc[t][i] = ok ? sacc[t][i] : -INFINITY;
+          }
+      }
+      float tmax = -INFINITY;
+#pragma unroll
+      for (int t = 0; t < KT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) tmax = fmaxf(fmaxf(tmax, sacc[t][i]), sacc[t][i + 1]);
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float m_new = fmaxf(m_run, tmax * a.scale_log2);
+      // rows with nothing visible yet keep m=-inf: use 0 as the exponent base
+      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);  // m_run=-inf -> 0
+      const f32x2 sc2 = {a.scale_log2, a.scale_log2}, nm2 = {-m_use, -m_use};
+      f32x2 ps2 = {0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < KT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {
+          const f32x2 e = __builtin_elementwise_fma(f32x2{sacc[t][i], sacc[t][i + 1]}, sc2, nm2);
+          const f32x2 pp = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+          sacc[t][i] = pp[0];
+          sacc[t][i + 1] = pp[1];
+          ps2 += pp;
+        }
+      l_run = l_run * alpha + (ps2[0] + ps2[1]);
+      // the accumulators only need rescaling when some row's maximum moved (wave-uniform test)
+      if (__builtin_amdgcn_ballot_w64(m_new > m_run)) {
+        const f32x2 al2 = {alpha, alpha};
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+          for (int i = 0; i < 16; i += 2) {
+            const f32x2 v = f32x2{oacc[dt][i], oacc[dt][i + 1]} * al2;
+            oacc[dt][i] = v[0];
+            oacc[dt][i + 1] = v[1];
+          }
+      }
+      m_run = m_new;
+
+      // ---- O^T += V^T . P^T over 4 k-steps of 16 keys; the V^T fragments of k-step s+1 are in
+      // flight while k-step s multiplies ----
+      {
+        auto read_v = [&](int s_, v4 (&lo)[DT], v4 (&hi)[DT]) {
+          // element j of this lane is key row 16s + 8(j>>2) + 4hh + (j&3) of the tile
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            lo[dt] = Frag<T>::tr_read((const T*)(cV + s_ * (16 * ROWB) + v_rd[dt]));
+            hi[dt] = Frag<T>::tr_read((const T*)(cV + s_ * (16 * ROWB) + 8 * ROWB + v_rd[dt]));
+          }
+        };
+        v4 vlo[2][DT], vhi[2][DT];
+        read_v(0, vlo[0], vhi[0]);
+#pragma unroll
+        for (int s_ = 0; s_ < 2 * KT; ++s_) {
+          if (s_ < 2 * KT - 1) read_v(s_ + 1, vlo[(s_ + 1) & 1], vhi[(s_ + 1) & 1]);
+          const int t = s_ >> 1, rb = (s_ & 1) * 8;
+          v8 pf;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pf[j] = from_f32<T>(sacc[t][rb + j]);
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            v8 vf;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { vf[j] = vlo[s_ & 1][dt][j]; vf[4 + j] = vhi[s_ & 1][dt][j]; }
+            oacc[dt] = Frag<T>::mfma(vf, pf, oacc[dt]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
     }
     // tile kt+1 (issued an iteration ago) must have landed; this iteration's copies stay in flight
     if (ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
@@ -354,7 +333,6 @@ __global__ __launch_bounds__(NW * 64) void flash_fwd_kernel(AttnArgs a) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
-  if (lag && pend >= 0) softmax_pv(pend, sacc);
 
   // ---- epilogue: normalise and store O[q][d] ----
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -380,39 +358,41 @@ __global__ __launch_bounds__(NW * 64) void flash_fwd_kernel(AttnArgs a) {
   }
 }
 
-template <typename T, int KS, int DT, int NW, int KT, bool LAG>
-int launch_fa_cfg(const AttnArgs& a, int B, hipStream_t st) {
-  constexpr int lds = 2 * (LAG ? 4 : 3) * 32 * KT * 256;   // K and V rings: stages x 32 KT rows x 256 B
-  auto kern = flash_fwd_kernel<T, KS, DT, NW, KT, LAG>;
-  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+template <typename T, int KS, int DT>
+int launch_fa_d(const AttnArgs& a, int B, hipStream_t st) {
+  constexpr int KT = FA_KT;
+  constexpr int lds = 2 * 3 * 32 * KT * 256;   // K and V rings: 3 stages x 32 KT rows x 256 B
+  hipError_t e;
+  if (a.Lq > 128) {
+    e = hipFuncSetAttribute((const void*)flash_fwd_kernel<T, KS, DT, 8, KT>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess) {
+      const int nqb = (a.Lq + 255) / 256;
+      static const int xcd_ = [] { const char* v = getenv("TV_FA_XCD"); return v ? atoi(v) : 1; }();
+      if (xcd_ && !a.causal && nqb <= 8 && (int64_t)B * a.Hq >= 64) {
+        AttnArgs ax = a;
+        ax.nqb = nqb;
+        ax.nb = B;
+        const int64_t pairs = ((int64_t)B * a.Hq + 7) / 8 * 8;
+        flash_fwd_kernel<T, KS, DT, 8, KT><<<dim3((unsigned)(pairs * nqb), 1, 1), 512, lds, st>>>(ax);
+      } else {
+        dim3 grid(nqb, a.Hq, B);
+        flash_fwd_kernel<T, KS, DT, 8, KT><<<grid, 512, lds, st>>>(a);
+      }
+    }
+  } else {
+    e = hipFuncSetAttribute((const void*)flash_fwd_kernel<T, KS, DT, 4, KT>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess) {
+      dim3 grid((a.Lq + 127) / 128, a.Hq, B);
+      flash_fwd_kernel<T, KS, DT, 4, KT><<<grid, 256, lds, st>>>(a);
+    }
+  }
   if (e != hipSuccess) {
     tv_set_error("flash_attn: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     return TV_ERR_LAUNCH;
   }
-  constexpr int QB = NW * FA_QW;
-  const int nqb = (a.Lq + QB - 1) / QB;
-  static const int xcd_ = [] { const char* v = getenv("TV_FA_XCD"); return v ? atoi(v) : 1; }();
-  if (NW == 8 && xcd_ && !a.causal && nqb <= 8 && (int64_t)B * a.Hq >= 64) {
-    AttnArgs ax = a;
-    ax.nqb = nqb;
-    ax.nb = B;
-    const int64_t pairs = ((int64_t)B * a.Hq + 7) / 8 * 8;
-    kern<<<dim3((unsigned)(pairs * nqb), 1, 1), NW * 64, lds, st>>>(ax);
-  } else {
-    kern<<<dim3(nqb, a.Hq, B), NW * 64, lds, st>>>(a);
-  }
   TV_LAUNCH_CHECK();
-}
-
-template <typename T, int KS, int DT>
-int launch_fa_d(const AttnArgs& a, int B, hipStream_t st) {
-  // TV_FA_LAG=0 (dev): the round-1 structure, every wave in the same phase, ring of 3 x 96 keys
-  static const int lag_ = [] { const char* v = getenv("TV_FA_LAG"); return v ? atoi(v) : 1; }();
-  if (a.Lq > 128) {
-    if (lag_) return launch_fa_cfg<T, KS, DT, 8, 2, true>(a, B, st);
-    return launch_fa_cfg<T, KS, DT, 8, FA_KT, false>(a, B, st);
-  }
-  return launch_fa_cfg<T, KS, DT, 4, FA_KT, false>(a, B, st);
 }
 
 template <typename T>
