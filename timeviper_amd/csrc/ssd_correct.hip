@@ -13,7 +13,7 @@
 // few hundred tokens cost a few chunks; a head that never forgets costs the full range.
 //
 // Three launches: per-chunk log-decays (from dt), their exclusive prefix per head, and the
-// correction itself: work-groups (slot k of 8, head, batch) walk the chunks k, k+8, ... of their
+// correction itself: work-groups (slot k of 64, head, batch) walk the chunks k, k+64, ... of their
 // head until the prefix underflows; per 64-token chunk C . S_in^T on MFMA 16x16x32 (S_in as bf16
 // B fragments in registers for the whole walk, like the march's state snapshot), scaled rows
 // through LDS, 16-byte read-modify-write of y.
@@ -24,7 +24,8 @@ using namespace ssdk;
 
 constexpr int CQ = 64;            // tokens per chunk
 constexpr int CN = 128;           // d_state
-constexpr int CSLOTS = 8;         // work-groups per (batch, head)
+constexpr int CSLOTS = 64;        // work-groups per (batch, head): a head that never forgets is walked by all of them
+                                  // (measured with 8: the slowest heads set the launch time, 808 us in the 9B model)
 constexpr float C_UNDERFLOW = -160.f;   // log2 of a factor that is exactly 0 in fp32, with margin
 
 struct CorrArgs {
@@ -33,6 +34,7 @@ struct CorrArgs {
   const float *A, *dt_bias, *state;
   float *tot, *pre;
   int L, H, P, G, nchunks;
+  int64_t tot_stride;              // elements between the (b, h) rows of `tot`
   int64_t ysb, ysl, dsb, dsl, csb, csl, csg;
   int softplus, group_map;
   float dt_min, dt_max;
@@ -44,21 +46,22 @@ __device__ __forceinline__ float disc_dt(const CorrArgs& a, float raw, int h) {
   return fminf(fmaxf(d, a.dt_min), a.dt_max);
 }
 
-// grid (nchunks, B), block = H rounded up to 64: tot[b][h][c] = log2(e) * sum_{t in chunk} dt_t A_h
-__global__ void ssd_chunk_decay_kernel(CorrArgs a) {
-  const int c = blockIdx.x, b = blockIdx.y, h = threadIdx.x;
+// grid (nchunks, ceil(H / 4), B), 4 waves: wave = head, lane = token of the chunk
+// tot[b][h][c] = log2(e) * sum_{t in chunk} dt_t A_h
+__global__ __launch_bounds__(256) void ssd_chunk_decay_kernel(CorrArgs a) {
+  const int c = blockIdx.x, b = blockIdx.z;
+  const int h = blockIdx.y * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (h >= a.H) return;
-  const bf16_t* dp = a.dt + (int64_t)b * a.dsb + h;
-  float s = 0.f;
-  const int t0 = c * CQ, t1 = min(t0 + CQ, a.L);
-  for (int t = t0; t < t1; ++t) s += disc_dt(a, (float)dp[(int64_t)t * a.dsl], h);
-  a.tot[((int64_t)b * a.H + h) * a.nchunks + c] = s * a.A[h] * 1.4426950408889634f;
+  const int t = c * CQ + lane;
+  const float d = t < a.L ? disc_dt(a, (float)a.dt[(int64_t)b * a.dsb + (int64_t)t * a.dsl + h], h) : 0.f;
+  const float s = wave_sum(d);
+  if (lane == 0) a.tot[((int64_t)b * a.H + h) * a.nchunks + c] = s * a.A[h] * 1.4426950408889634f;
 }
 
 // grid (H, B), one wave: pre[b][h][c] = sum_{c' < c} tot[b][h][c']
 __global__ __launch_bounds__(64) void ssd_decay_prefix_kernel(CorrArgs a) {
   const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
-  const float* t = a.tot + ((int64_t)b * a.H + h) * a.nchunks;
+  const float* t = a.tot + ((int64_t)b * a.H + h) * a.tot_stride;
   float* p = a.pre + ((int64_t)b * a.H + h) * a.nchunks;
   float carry = 0.f;
   for (int c0 = 0; c0 < a.nchunks; c0 += 64) {
@@ -167,11 +170,14 @@ bool tv_ssd_correct_supported(int headdim, int dstate, int dtype, int nheads) {
   return dtype == TV_BF16 && dstate == CN && headdim % 8 == 0 && headdim <= 128 && nheads <= 1024;
 }
 
+// chunk_tot: per-chunk log2-decays (B, H, nchunks_total) already produced by the scan kernel for the
+// chunks [chunk0, chunk0 + nchunks) of this range (row stride chunk_tot_stride), or NULL: computed here.
 int tv_ssd_correct_launch(void* y, const void* dt, const void* A, const void* Cm, const void* dt_bias,
                           const void* state_in, int batch, int seqlen, int nheads, int headdim,
                           int ngroups, int64_t ysb, int64_t ysl, int64_t dsb, int64_t dsl, int64_t csb,
                           int64_t csl, int64_t csg, int dt_softplus, float dt_min, float dt_max,
-                          int group_map, void* workspace, hipStream_t st) {
+                          int group_map, void* workspace, const float* chunk_tot, int64_t chunk_tot_stride,
+                          hipStream_t st) {
   CorrArgs a;
   a.y = (bf16_t*)y; a.dt = (const bf16_t*)dt; a.Cm = (const bf16_t*)Cm;
   a.A = (const float*)A; a.dt_bias = (const float*)dt_bias; a.state = (const float*)state_in;
@@ -181,7 +187,13 @@ int tv_ssd_correct_launch(void* y, const void* dt, const void* A, const void* Cm
   a.pre = a.tot + (size_t)batch * nheads * a.nchunks;
   a.ysb = ysb; a.ysl = ysl; a.dsb = dsb; a.dsl = dsl; a.csb = csb; a.csl = csl; a.csg = csg;
   a.softplus = dt_softplus; a.group_map = group_map; a.dt_min = dt_min; a.dt_max = dt_max;
-  ssd_chunk_decay_kernel<<<dim3(a.nchunks, batch), (nheads + 63) / 64 * 64, 0, st>>>(a);
+  a.tot_stride = a.nchunks;
+  if (chunk_tot) {
+    a.tot = const_cast<float*>(chunk_tot);
+    a.tot_stride = chunk_tot_stride;
+  } else {
+    ssd_chunk_decay_kernel<<<dim3(a.nchunks, (nheads + 3) / 4, batch), 256, 0, st>>>(a);
+  }
   ssd_decay_prefix_kernel<<<dim3(nheads, batch), 64, 0, st>>>(a);
   const dim3 grid(CSLOTS, nheads, batch);
   switch ((headdim + 15) / 16) {
@@ -227,6 +239,6 @@ extern "C" int tv_ssd_state_correction(void* y, const void* dt, const void* A, c
   }
   return tv_ssd_correct_launch(y, dt, A, Cm, dt_bias, state_in, batch, seqlen, nheads, headdim, ngroups,
                                y_stride_b, y_stride_l, dt_stride_b, dt_stride_l, c_stride_b, c_stride_l,
-                               c_stride_g, dt_softplus, dt_min, dt_max, group_map, workspace,
+                               c_stride_g, dt_softplus, dt_min, dt_max, group_map, workspace, nullptr, 0,
                                (hipStream_t)stream);
 }

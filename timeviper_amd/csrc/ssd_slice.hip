@@ -34,7 +34,8 @@ int tv_ssd_correct_launch(void* y, const void* dt, const void* A, const void* Cm
                           const void* state_in, int batch, int seqlen, int nheads, int headdim,
                           int ngroups, int64_t ysb, int64_t ysl, int64_t dsb, int64_t dsl, int64_t csb,
                           int64_t csl, int64_t csg, int dt_softplus, float dt_min, float dt_max,
-                          int group_map, void* workspace, hipStream_t st);
+                          int group_map, void* workspace, const float* chunk_tot, int64_t chunk_tot_stride,
+                          hipStream_t st);
 
 namespace {
 using namespace ssdk;
@@ -143,6 +144,7 @@ struct SliceArgs {
   // (segment 0 from `init`) and leaves its final state / total log-decay in seg_state / seg_decay;
   // nseg == 1: one march over the whole sequence, final_state / total_decay written directly
   float *seg_state, *seg_decay;
+  float* chunk_tot;                // (B, H, nchunks) log2-decay of every chunk, for the correction's prefix (nseg > 1)
   int nseg, seg_chunks;
   int L, H, P, G, nslices, pw, nchunks;
   int64_t xsb, xsl, dsb, dsl, bsb, bsl, bsg, csb, csl, csg, ysb, ysl;
@@ -318,6 +320,7 @@ __global__ __launch_bounds__(Roles<PW>::NWAVES * 64) void ssd_slice_kernel(Slice
     sm.dtv[vb][lane] = d;
     sm.wts[vb][lane] = __builtin_amdgcn_exp2f(cl2 - cs2) * d;
     if (lane == 0) sm.dl[vb][0] = __builtin_amdgcn_exp2f(cl2);
+    if (a.chunk_tot && slice == 0 && lane == 0) a.chunk_tot[((int64_t)b * a.H + h) * a.nchunks + c_first + c] = cl2;
     // separable factors of the off-diagonal mask blocks (pivot = first token of a t-tile)
     const float p1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs2), 16));
     const float p2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cs2), 32));
@@ -950,7 +953,7 @@ int pick_segments(int batch, int nheads, int nchunks) {
 }
 
 struct SegLayout {
-  size_t cb, seg_state, seg_decay, sin, corr, total;
+  size_t cb, seg_state, seg_decay, sin, corr, ctot, total;
   int nseg, seg_chunks;
 };
 SegLayout seg_layout(int batch, int seqlen, int nheads, int headdim, int ngroups, bool wide) {
@@ -965,7 +968,8 @@ SegLayout seg_layout(int batch, int seqlen, int nheads, int headdim, int ngroups
   l.seg_decay = l.seg_state + (l.nseg > 1 ? up(l.nseg * st) : 0);
   l.sin = l.seg_decay + (l.nseg > 1 ? up((size_t)l.nseg * batch * nheads * sizeof(float)) : 0);
   l.corr = l.sin + (l.nseg > 2 ? up((l.nseg - 1) * st) : 0);       // 2 segments: S_in(1) = seg_state[0]
-  l.total = l.corr + (l.nseg > 1 ? up(tv_ssd_correct_workspace_bytes(batch, l.seg_chunks * SQ, nheads)) : 0);
+  l.ctot = l.corr + (l.nseg > 1 ? up(tv_ssd_correct_workspace_bytes(batch, l.seg_chunks * SQ, nheads)) : 0);
+  l.total = l.ctot + (l.nseg > 1 ? up((size_t)batch * nheads * nchunks * sizeof(float)) : 0);
   return l;
 }
 
@@ -1055,6 +1059,7 @@ int tv_ssd_slice_launch(const void* x, const void* dt, const void* A, const void
   a.nseg = lay.nseg; a.seg_chunks = lay.seg_chunks;
   a.seg_state = lay.nseg > 1 ? (float*)(wsb + lay.seg_state) : nullptr;
   a.seg_decay = lay.nseg > 1 ? (float*)(wsb + lay.seg_decay) : nullptr;
+  a.chunk_tot = lay.nseg > 1 ? (float*)(wsb + lay.ctot) : nullptr;
   a.xsb = xsb; a.xsl = xsl; a.dsb = dsb; a.dsl = dsl; a.bsb = bsb; a.bsl = bsl; a.bsg = bsg;
   a.csb = csb; a.csl = csl; a.csg = csg; a.ysb = ysb; a.ysl = ysl;
   a.softplus = dt_softplus; a.group_map = group_map; a.dt_min = dt_min; a.dt_max = dt_max;
@@ -1100,7 +1105,8 @@ int tv_ssd_slice_launch(const void* x, const void* dt, const void* A, const void
       const int rc = tv_ssd_correct_launch((bf16_t*)y + t0 * ysl, (const bf16_t*)dt + t0 * dsl, A,
                                            (const bf16_t*)Cm + t0 * csl, dt_bias, s_in, batch, len, nheads,
                                            headdim, ngroups, ysb, ysl, dsb, dsl, csb, csl, csg, dt_softplus,
-                                           dt_min, dt_max, group_map, wsb + lay.corr, st);
+                                           dt_min, dt_max, group_map, wsb + lay.corr,
+                                           a.chunk_tot + (int64_t)s * a.seg_chunks, a.nchunks, st);
       if (rc != TV_OK) return rc;
     }
   }
