@@ -99,9 +99,12 @@ int tv_rmsnorm_fwd(const void* x, const void* delta, const void* weight,
 
 /* ViT blocks (V1/V2): LayerNorm with the residual add of the previous sub-layer fused in
  * (timm Block: x = x + attn(norm1(x)); x = x + mlp(norm2(x))), and the exact (erf) GELU of
- * the MLP.  s = x (+ delta) rounded to dtype -> sum_out; y = (s-mean)*rsqrt(var+eps)*w + b. */
+ * the MLP.  s = x (+ delta) rounded to dtype -> sum_out; y = (s-mean)*rsqrt(var+eps)*w + b.
+ * row_bias (dim) fp32, optional: one row added to every s before the statistics (not to
+ * sum_out) — the biases of the preceding projections when the caller lets the GEMM
+ * accumulate straight into the residual stream (D = A W^T + C) and carries them beside it. */
 int tv_layernorm_fwd(const void* x, const void* delta, const void* weight,
-                     const void* bias, void* sum_out, void* y, int64_t rows, int dim,
+                     const void* bias, const void* row_bias, void* sum_out, void* y, int64_t rows, int dim,
                      int64_t x_stride, int64_t delta_stride, int64_t sum_stride,
                      int64_t y_stride, float eps, int dtype, void* stream);
 int tv_gelu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream);

@@ -63,9 +63,10 @@ def _rms(x, weight, eps, residual=None, return_sum=False):
     return (y, s) if return_sum else y
 
 
-def _ln(x, weight, bias, eps, residual=None, return_sum=False):
+def _ln(x, weight, bias, eps, residual=None, return_sum=False, row_bias=None):
     s = x if residual is None else (x + residual)
-    y = torch.nn.functional.layer_norm(s.float(), (s.shape[-1],), weight.float(),
+    sf = s.float() if row_bias is None else s.float() + row_bias.float()
+    y = torch.nn.functional.layer_norm(sf, (s.shape[-1],), weight.float(),
                                        None if bias is None else bias.float(), eps).to(x.dtype)
     return (y, s) if return_sum else y
 

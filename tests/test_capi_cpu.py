@@ -23,7 +23,10 @@ def test_library_builds_and_exports_header_symbols():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/timeviper_hip.h but not exported"
     assert set(_capi.SIGNATURES) == set(syms)
-    assert lib.tv_abi_version() == _capi.ABI_VERSION == 3
+    src = (ROOT / "timeviper_amd" / "csrc" / "capi.cpp").read_text()
+    assert lib.tv_abi_version() == _capi.ABI_VERSION == int(re.search(r"tv_abi_version\(void\) \{ return (\d+); \}", src).group(1))
+    # the binary carries the hash of the sources it was built from: a kernel edit cannot run through a stale library
+    assert lib.tv_build_id().decode() == build.source_id()
 
 
 def test_bad_arguments_fail_loudly_without_gpu():

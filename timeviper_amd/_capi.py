@@ -27,7 +27,7 @@ SIGNATURES = {
     "tv_causal_conv1d_xbc_fwd": (_i, [_p] * 7 + [_i] * 6 + [_l, _l, _i, _i, _p]),
     "tv_causal_conv1d_update": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "tv_rmsnorm_fwd": (_i, [_p, _p, _p, _p, _p, _l, _i, _l, _l, _l, _l, _f, _i, _i, _p]),
-    "tv_layernorm_fwd": (_i, [_p] * 6 + [_l, _i, _l, _l, _l, _l, _f, _i, _p]),
+    "tv_layernorm_fwd": (_i, [_p] * 7 + [_l, _i, _l, _l, _l, _l, _f, _i, _p]),
     "tv_gelu_fwd": (_i, [_p, _p, _l, _i, _p]),
     "tv_relu2_fwd": (_i, [_p, _p, _l, _i, _p]),
     "tv_rmsnorm_gated_fwd": (_i, [_p, _p, _p, _p, _l, _i, _i, _l, _l, _l, _f, _i, _i, _p]),
@@ -61,7 +61,7 @@ class TimeViperHipError(RuntimeError):
     pass
 
 
-ABI_VERSION = 4      # tv_abi_version() of the library these SIGNATURES describe (csrc/capi.cpp)
+ABI_VERSION = 5      # tv_abi_version() of the library these SIGNATURES describe (csrc/capi.cpp)
 
 
 def lib_path() -> Path:

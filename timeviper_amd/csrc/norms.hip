@@ -97,8 +97,8 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_kernel(
 template <typename T>
 __global__ __launch_bounds__(NORM_THREADS) void layernorm_kernel(
     const T* __restrict__ x, const T* __restrict__ delta, const T* __restrict__ w,
-    const T* __restrict__ bias, T* __restrict__ sum_out, T* __restrict__ y, int D, int64_t xs,
-    int64_t ds, int64_t ss, int64_t ys, float eps) {
+    const T* __restrict__ bias, const float* __restrict__ row_bias, T* __restrict__ sum_out,
+    T* __restrict__ y, int D, int64_t xs, int64_t ds, int64_t ss, int64_t ys, float eps) {
   constexpr int V = Vec16<T>::N;
   typedef typename Vec16<T>::type vec_t;
   __shared__ float red[2][NORM_THREADS / 64];
@@ -125,6 +125,10 @@ __global__ __launch_bounds__(NORM_THREADS) void layernorm_kernel(
       } else {
 #pragma unroll
         for (int i = 0; i < V; ++i) vals[k][i] = to_f32(v[i]);
+      }
+      if (row_bias) {      // a constant row added before the statistics (sub-layer biases carried beside the stream)
+#pragma unroll
+        for (int i = 0; i < V; ++i) vals[k][i] += row_bias[(int64_t)iv * V + i];
       }
 #pragma unroll
       for (int i = 0; i < V; ++i) s1 += vals[k][i];
@@ -176,8 +180,8 @@ __global__ __launch_bounds__(NORM_THREADS) void layernorm_kernel(
 template <typename T>
 __global__ __launch_bounds__(NORM_THREADS) void layernorm_wave_kernel(
     const T* __restrict__ x, const T* __restrict__ delta, const T* __restrict__ w,
-    const T* __restrict__ bias, T* __restrict__ sum_out, T* __restrict__ y, int64_t rows, int D,
-    int64_t xs, int64_t ds, int64_t ss, int64_t ys, float eps) {
+    const T* __restrict__ bias, const float* __restrict__ row_bias, T* __restrict__ sum_out,
+    T* __restrict__ y, int64_t rows, int D, int64_t xs, int64_t ds, int64_t ss, int64_t ys, float eps) {
   constexpr int V = Vec16<T>::N;
   typedef typename Vec16<T>::type vec_t;
   const int64_t row = (int64_t)blockIdx.x * (NORM_THREADS / 64) + (threadIdx.x >> 6);
@@ -212,6 +216,10 @@ __global__ __launch_bounds__(NORM_THREADS) void layernorm_wave_kernel(
       } else {
 #pragma unroll
         for (int i = 0; i < V; ++i) vals[k][i] = to_f32(xv[k][i]);
+      }
+      if (row_bias) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) vals[k][i] += row_bias[(int64_t)iv * V + i];
       }
 #pragma unroll
       for (int i = 0; i < V; ++i) s1 += vals[k][i];
@@ -402,8 +410,8 @@ int launch_gated(const void* x, const void* z, const void* w, void* y, int64_t r
 bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 template <typename T>
-int launch_ln(const void* x, const void* delta, const void* w, const void* b, void* sum_out, void* y,
-              int64_t rows, int D, int64_t xs, int64_t ds, int64_t ss, int64_t ys, float eps,
+int launch_ln(const void* x, const void* delta, const void* w, const void* b, const float* rb, void* sum_out,
+              void* y, int64_t rows, int D, int64_t xs, int64_t ds, int64_t ss, int64_t ys, float eps,
               hipStream_t s) {
   constexpr int V = Vec16<T>::N;
   if (D % V || D / V > NORM_THREADS * NORM_MAXV)
@@ -412,11 +420,11 @@ int launch_ln(const void* x, const void* delta, const void* w, const void* b, vo
   if (D / V <= 64 * NORM_MAXV) {
     const int64_t nblk = (rows + NORM_THREADS / 64 - 1) / (NORM_THREADS / 64);
     layernorm_wave_kernel<T><<<dim3((unsigned)nblk), NORM_THREADS, 0, s>>>(
-        (const T*)x, (const T*)delta, (const T*)w, (const T*)b, (T*)sum_out, (T*)y, rows, D, xs, ds, ss,
+        (const T*)x, (const T*)delta, (const T*)w, (const T*)b, rb, (T*)sum_out, (T*)y, rows, D, xs, ds, ss,
         ys, eps);
   } else {
     layernorm_kernel<T><<<dim3((unsigned)rows), NORM_THREADS, 0, s>>>(
-        (const T*)x, (const T*)delta, (const T*)w, (const T*)b, (T*)sum_out, (T*)y, D, xs, ds, ss, ys, eps);
+        (const T*)x, (const T*)delta, (const T*)w, (const T*)b, rb, (T*)sum_out, (T*)y, D, xs, ds, ss, ys, eps);
   }
   TV_LAUNCH_CHECK();
 }
@@ -483,7 +491,7 @@ extern "C" int tv_rmsnorm_gated_fwd(const void* x, const void* z, const void* we
 }
 
 extern "C" int tv_layernorm_fwd(const void* x, const void* delta, const void* weight,
-                                const void* bias, void* sum_out, void* y, int64_t rows, int dim,
+                                const void* bias, const void* row_bias, void* sum_out, void* y, int64_t rows, int dim,
                                 int64_t x_stride, int64_t delta_stride, int64_t sum_stride,
                                 int64_t y_stride, float eps, int dtype, void* stream) {
   TV_CHECK_ARG(weight && (rows == 0 || (x && y)), "layernorm: null pointer");
@@ -497,13 +505,13 @@ extern "C" int tv_layernorm_fwd(const void* x, const void* delta, const void* we
   hipStream_t s = (hipStream_t)stream;
   switch (dtype) {
     case TV_F32:
-      return launch_ln<float>(x, delta, weight, bias, sum_out, y, rows, dim, x_stride, delta_stride,
+      return launch_ln<float>(x, delta, weight, bias, (const float*)row_bias, sum_out, y, rows, dim, x_stride, delta_stride,
                               sum_stride, y_stride, eps, s);
     case TV_BF16:
-      return launch_ln<bf16_t>(x, delta, weight, bias, sum_out, y, rows, dim, x_stride,
+      return launch_ln<bf16_t>(x, delta, weight, bias, (const float*)row_bias, sum_out, y, rows, dim, x_stride,
                                delta_stride, sum_stride, y_stride, eps, s);
     case TV_F16:
-      return launch_ln<f16_t>(x, delta, weight, bias, sum_out, y, rows, dim, x_stride, delta_stride,
+      return launch_ln<f16_t>(x, delta, weight, bias, (const float*)row_bias, sum_out, y, rows, dim, x_stride, delta_stride,
                               sum_stride, y_stride, eps, s);
   }
   TV_UNSUPPORTED("layernorm: dtype %d", dtype);

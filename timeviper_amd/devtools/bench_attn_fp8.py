@@ -1,4 +1,4 @@
-"""Dev tool: fp8 vs bf16 attention kernels — errors against the oracle definition on sampled rows and
+"""Dev tool: fp8 vs bf16 attention kernels — errors against the fp32 definition on sampled rows and
 kernel times.   python timeviper_amd/devtools/bench_attn_fp8.py [L=32868] [Hq=28] [Hkv=4] [D=128] [causal=1]"""
 import math
 import sys

@@ -171,18 +171,21 @@ def rms_norm(x, weight, eps, residual=None, return_sum=False):
     return y
 
 
-def layer_norm(x, weight, bias, eps, residual=None, return_sum=False):
+def layer_norm(x, weight, bias, eps, residual=None, return_sum=False, row_bias=None):
     """nn.LayerNorm over the last dim, optionally of s = x + residual (rounded to x.dtype),
-    returning s too — the fused form of a pre-norm ViT block's residual add + norm."""
-    _gpu(x, weight, bias, residual)
+    returning s too — the fused form of a pre-norm ViT block's residual add + norm.
+    `row_bias` (D,) fp32: a constant row added to every s before the statistics (not to the
+    returned sum): the projection biases a caller carries beside a stream its GEMMs accumulate into."""
+    _gpu(x, weight, bias, residual, row_bias)
     x2 = _rows2d(x)
     r2 = None if residual is None else _rows2d(residual)
     y = torch.empty(x2.shape, dtype=x.dtype, device=x.device)
     s = torch.empty_like(y) if (return_sum and residual is not None) else None
     w = weight.to(x.dtype).contiguous()
     b = None if bias is None else bias.to(x.dtype).contiguous()
+    rb = None if row_bias is None else row_bias.to(torch.float32).contiguous()
     check(_capi.lib().tv_layernorm_fwd(
-        _p(x2), _p(r2), _p(w), _p(b), _p(s), _p(y), x2.shape[0], x2.shape[1], x2.stride(0),
+        _p(x2), _p(r2), _p(w), _p(b), _p(rb), _p(s), _p(y), x2.shape[0], x2.shape[1], x2.stride(0),
         0 if r2 is None else r2.stride(0), 0 if s is None else s.stride(0), y.stride(0), float(eps),
         _dt(x), _stream()), "tv_layernorm_fwd")
     y = y.view(x.shape)

@@ -15,6 +15,7 @@ loads with strict=True; the pooling head is kept for that reason only and never 
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -103,7 +104,8 @@ class Attention(nn.Module):
         self.proj = nn.Linear(dim, dim, bias=True)
         self._padded = ZeroPaddedLinears()
 
-    def forward(self, x):
+    def heads(self, x):
+        """qkv projection + attention, without the output projection"""
         B, N, C = x.shape
         if ZeroPaddedLinears.wanted(x, 3 * C):
             w, b = self._padded.get((self.qkv.weight, self.qkv.bias), lambda: (
@@ -114,7 +116,10 @@ class Attention(nn.Module):
             qkv = self.qkv(x).view(B, N, 3, self.num_heads, self.head_dim)
         o = K.flash_attn_func(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], softmax_scale=self.scale,
                               causal=False)
-        return self.proj(o.reshape(B, N, C))
+        return o.reshape(B, N, C)
+
+    def forward(self, x):
+        return self.proj(self.heads(x))
 
 
 class Mlp(nn.Module):
@@ -126,18 +131,22 @@ class Mlp(nn.Module):
         self.fc2 = nn.Linear(hidden, dim)
         self._padded = ZeroPaddedLinears()
 
-    def forward(self, x):
+    def hidden(self, x):
+        """act(fc1(x)) and the fc2 weight that goes with it (zero-padded to the GEMM tile when that pays)"""
         Hd = self.fc1.out_features
         if ZeroPaddedLinears.wanted(x, Hd):
             w1, b1, w2 = self._padded.get((self.fc1.weight, self.fc1.bias, self.fc2.weight), lambda: (
                 _pad_rows(self.fc1.weight.detach(), _aligned(Hd)), _pad_rows(self.fc1.bias.detach(), _aligned(Hd)),
                 _pad_rows(self.fc2.weight.detach().t(), _aligned(Hd)).t().contiguous()))
             h = F.linear(x, w1, b1)
-            h = K.gelu(h, inplace=True) if self.exact_gelu else self.act(h)
-            return F.linear(h, w2, self.fc2.bias)
-        h = self.fc1(x)
+        else:
+            h, w2 = self.fc1(x), self.fc2.weight
         h = K.gelu(h, inplace=True) if self.exact_gelu else self.act(h)
-        return self.fc2(h)
+        return h, w2
+
+    def forward(self, x):
+        h, w2 = self.hidden(x)
+        return F.linear(h, w2, self.fc2.bias)
 
 
 class LayerScale(nn.Module):
@@ -175,6 +184,25 @@ class Block(nn.Module):
         a = self.ls1(self.attn(h))
         h, x = K.layer_norm(x, n2.weight, n2.bias, n2.eps, residual=a, return_sum=True)
         return x, self.ls2(self.mlp(h))
+
+    def forward_stream(self, x, pend):
+        """Same block (no LayerScale) on a residual stream the projections accumulate INTO: the output
+        GEMMs of both sub-layers run as x += h W^T (one pass over x inside the GEMM's epilogue instead
+        of a separate read-add-write), their biases are carried beside the stream in `pend` (fp32, one
+        row) and enter through the LayerNorm kernel, which then reads x once and writes the normalised
+        rows once — 2 passes over the stream per LayerNorm instead of 4.  x (B, N, C), contiguous, is
+        updated in place; the block's output is x + pend.  Arithmetic: x + h W^T is rounded to bf16
+        once (the two-step form rounds h W^T + b and the sum separately)."""
+        n1, n2 = self.norm1, self.norm2
+        x2 = x.view(-1, x.shape[-1])
+        h = K.layer_norm(x, n1.weight, n1.bias, n1.eps, row_bias=pend)
+        o = self.attn.heads(h)
+        torch.addmm(x2, o.view(x2.shape), self.attn.proj.weight.t(), out=x2)
+        pend = self.attn.proj.bias.float() if pend is None else pend + self.attn.proj.bias.float()
+        h = K.layer_norm(x, n2.weight, n2.bias, n2.eps, row_bias=pend)
+        hid, w2 = self.mlp.hidden(h)
+        torch.addmm(x2, hid.view(x2.shape[0], -1), w2.t(), out=x2)
+        return x, pend + self.mlp.fc2.bias.float()
 
 
 class AttentionPoolLatent(nn.Module):
@@ -226,9 +254,19 @@ class VisionTransformer(nn.Module):
                 prefix = [t for t in (self.cls_token, self.reg_token) if t is not None]
                 x = torch.cat([t.expand(x.shape[0], -1, -1) for t in prefix] + [x], dim=1)
                 x = x + self.pos_embed
+        blocks = [self.blocks[i] for i in range(last + 1)]
+        if x.is_cuda and all(isinstance(b.ls1, nn.Identity) and b.mlp.exact_gelu for b in blocks) \
+                and os.environ.get("TV_VIT_STREAM", "1") != "0":
+            # output projections accumulate into the stream, biases ride beside it (Block.forward_stream)
+            x = x if x.is_contiguous() else x.contiguous()
+            pend = None
+            for blk in blocks:
+                x, pend = blk.forward_stream(x, pend)
+            x = x + pend.to(x.dtype)
+            return (x[:, self.num_prefix_tokens:],)
         delta = None
-        for i in range(last + 1):
-            x, delta = self.blocks[i].forward_fused(x, delta)
+        for blk in blocks:
+            x, delta = blk.forward_fused(x, delta)
         x = x + delta
         return (x[:, self.num_prefix_tokens:],)
 
