@@ -5,6 +5,7 @@ import collections
 import csv
 import glob
 import json
+import re
 import sys
 from pathlib import Path
 
@@ -24,7 +25,8 @@ for f in sorted(glob.glob(str(ROOT / "gpurun_out/pmc_slice*/**/p_counter_collect
         k = next((n for n in KERNELS if n in r["Kernel_Name"]), None)
         if k is None:
             continue
-        names[k] = r["Kernel_Name"].split("(")[0]
+        m_ = re.search(k + r"(<[^>]*>)?", r["Kernel_Name"])
+        names[k] = m_.group(0) if m_ else k
         per[(k, r["Dispatch_Id"])][r["Counter_Name"]] += float(r["Counter_Value"])
     for (k, _), cs in per.items():
         for c, v in cs.items():
