@@ -49,10 +49,29 @@ with torch.inference_mode(), ctx:
     torch.cuda.synchronize()
 assert torch.isfinite(out.float()).all()
 err = ((out.float() - ref.float()).norm() / ref.float().norm()).item()
+# how sensitive are THESE logits (random-init weights, 28 layers) to any perturbation at all: the bf16 path
+# again with a +-0.4 % (one bf16 ulp) relative noise on the outputs of the long attention calls
+orig = K.flash_attn_func
+
+
+def noisy_attn(q, k, v, *a, **kw):
+    o = orig(q, k, v, *a, **kw)
+    return o * (1 + (torch.rand_like(o, dtype=torch.float32) - 0.5) * 2 ** -7).to(o.dtype) if k.shape[1] >= 4096 else o
+
+
+K.flash_attn_func = noisy_attn
+with torch.inference_mode():
+    noisy = vlm(input_ids=ids, pixel_values_videos=pix).logits
+K.flash_attn_func = orig
+err_noise = ((noisy.float() - ref.float()).norm() / ref.float().norm()).item()
 print(json.dumps({"config": "BASELINE configs[4]: Qwen2.5-7B geometry, DINOv2-L + InternVideo2-1B, pdrop " + pd + " + TransV",
                   "attention": "fp8 e4m3 MFMA" if fp8 else "bf16 MFMA", "frames": T, "tokens": T * 32 + 100,
                   "ms_per_forward": round(dt * 1e3, 1), "frames_per_s": round(T / dt, 1),
                   "vision_ms": round(ev[0].elapsed_time(ev[1]), 1), "lm_ms": round(ev[1].elapsed_time(ev[2]), 1),
                   "logits_rel_err_vs_bf16_attention": round(err, 5),
                   "same_argmax_as_bf16": bool(out.argmax() == ref.argmax()),
+                  "logits_rel_err_of_bf16_with_one_ulp_noise_on_attention_outputs": round(err_noise, 5),
+                  "note": "random-init weights make the last-token logits chaotic: one bf16 ulp of noise on the attention "
+                          "outputs moves them as much as the fp8 operands do; the fp8 kernel itself is checked against the "
+                          "oracle in tests/test_attention_fp8_gpu.py and tests/test_config5_gpu.py",
                   "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2**30, 1)}))
