@@ -25,11 +25,25 @@ def free_port():
     return p
 
 
-def build(merge):
-    from timeviper_amd.model import HybridTimeViperVLM
+def build(merge, family="nano"):
+    from timeviper_amd.model import GenericTimeViperVLM, HybridTimeViperVLM
     from timeviper_amd.model.llm import GenericLLMBackbone, NemotronHConfig
     from timeviper_amd.model.vit import TimmViTBackbone
     torch.manual_seed(0)
+    if family == "qwen2":
+        from timeviper_amd.model.llm.qwen2 import Qwen2Config
+        cfg = Qwen2Config(vocab_size=128, hidden_size=64, intermediate_size=96, num_hidden_layers=8,
+                          num_attention_heads=4, num_key_value_heads=2, rope_theta=10000.0)
+        vb = TimmViTBackbone("siglip-vit-b16-224px", depth_override=2, default_image_size=96)
+        llm = GenericLLMBackbone("qwen2.5-7b-instruct", config=cfg, merge_module=merge, use_pdrop=True, pdrop_type=PD)
+        vlm = GenericTimeViperVLM("t", vb, llm, arch_specifier="tome_mlp-16").eval()
+        with torch.no_grad():
+            for n, p in vlm.named_parameters():
+                if n.endswith("alpha"):
+                    p.fill_(0.7)
+                elif ("q_proj" in n or "k_proj" in n) and n.endswith("weight"):
+                    p.mul_(20.0)
+        return vlm
     cfg = NemotronHConfig(vocab_size=128, hidden_size=64, intermediate_size=96, num_hidden_layers=8,
                           hybrid_override_pattern="M-M*M-*M", num_attention_heads=4, head_dim=16,
                           num_key_value_heads=2, ssm_state_size=16, mamba_num_heads=8,
@@ -73,13 +87,13 @@ class HostReadCounter:
             setattr(torch.Tensor, n, f)
 
 
-def worker(rank, world, port, merge, T, q):
+def worker(rank, world, port, merge, T, q, family="nano"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2 if world <= 4 else 1)
     try:
         from timeviper_amd.distributed import SequenceParallelTimeViper
-        vlm = build(merge)
+        vlm = build(merge, family)
         tok = vlm.default_token_id
         g = torch.Generator().manual_seed(1)
         ids = torch.tensor([[5, 6, 7] + [tok] * T + [8, 9, 10, 11, 12]])
@@ -89,7 +103,7 @@ def worker(rank, world, port, merge, T, q):
             runner = SequenceParallelTimeViper(vlm, rank, world,
                                                causal_skew=10.0 if merge == "CrossAttention" else None)
             lo, hi = runner.frame_range(T)
-            if merge == "CrossAttention" and world == 2:
+            if merge == "CrossAttention" and world == 2 and family == "nano":
                 assert runner.frame_split(T) == [(0, 4), (4, 5)]
             # host reads: none in the layer loop outside the pdrop stages; inside a stage at most the
             # one copy of world + 1 positions (a .tolist()) — counted here on every rank
@@ -126,13 +140,16 @@ def worker(rank, world, port, merge, T, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("merge,world,T", [("no_merge", 2, 5), ("CrossAttention", 2, 5), ("CrossAttention", 8, 21)])
-def test_sequence_parallel_matches_single_process(merge, world, T):
-    """world 8 = the node size the driver scales to: eight ranks, unequal frame ranges"""
+@pytest.mark.parametrize("merge,world,T,family", [("no_merge", 2, 5, "nano"), ("CrossAttention", 2, 5, "nano"),
+                                                  ("CrossAttention", 8, 21, "nano"), ("CrossAttention", 2, 7, "qwen2"),
+                                                  ("no_merge", 4, 9, "qwen2")])
+def test_sequence_parallel_matches_single_process(merge, world, T, family):
+    """world 8 = the node size the driver scales to: eight ranks, unequal frame ranges; qwen2 = the
+    decoder-only family of BASELINE config 5 (every layer gathers rotated K and V)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=worker, args=(r, world, port, merge, T, q)) for r in range(world)]
+    procs = [ctx.Process(target=worker, args=(r, world, port, merge, T, q, family)) for r in range(world)]
     for p in procs:
         p.start()
     try:
@@ -231,6 +248,10 @@ def test_split_frames_balances_causal_cost():
     assert max(cost) / min(cost) < 1.002
     even = [(b - a) * (1 + k * (a + (b - a) / 2)) for a, b in split_frames(10240, 8)]
     assert max(even) > 1.025 * max(cost)                     # what the skew buys: ~3 % of the step
+    # clip-aligned boundaries (towers that regroup the frames of a 256-frame clip into tubes)
+    al = split_frames(4096, 8, k, align=256)
+    assert al[0][0] == 0 and al[-1][1] == 4096 and all(a[1] == b[0] and a[1] % 256 == 0 for a, b in zip(al, al[1:]))
+    assert split_frames(4096, 8, 0.0, align=256) == [(512 * r, 512 * (r + 1)) for r in range(8)]
     for n, w in ((3, 8), (17, 8), (1, 2), (0, 4)):
         sp = split_frames(n, w, 1e-2)
         assert len(sp) == w and sp[0][0] == 0 and sp[-1][1] == n

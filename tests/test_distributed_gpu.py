@@ -49,7 +49,7 @@ def stage_collectives_through_host():
     dist.all_gather, dist.broadcast, dist.all_gather_into_tensor = all_gather, broadcast, all_gather_into_tensor
 
 
-def worker(rank, world, port, merge, T, q, pd=PD):
+def worker(rank, world, port, merge, T, q, pd=PD, family="nano"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -64,8 +64,14 @@ def worker(rank, world, port, merge, T, q, pd=PD):
                               hybrid_override_pattern="M-M*M-*M", num_attention_heads=4, head_dim=64,
                               num_key_value_heads=2, ssm_state_size=128, mamba_num_heads=8,
                               mamba_n_groups=2, mamba_head_dim=40, mamba_chunk_size=64)
+        kw = {}
+        if family == "qwen2":
+            from timeviper_amd.model.llm.qwen2 import Qwen2Config
+            cfg = Qwen2Config(vocab_size=128, hidden_size=256, intermediate_size=512, num_hidden_layers=6,
+                              num_attention_heads=4, num_key_value_heads=2, rope_theta=10000.0)
+            kw = {"llm_backbone_id": "qwen2.5-7b-instruct"}
         vlm = build_synthetic_timeviper(cfg, "siglip-vit-b16-224px", pdrop_type=pd, merge_module=merge,
-                                        vit_depth=3, image_size=96, seed=3)
+                                        vit_depth=3, image_size=96, seed=3, **kw)
         tok = vlm.default_token_id
         g = torch.Generator().manual_seed(1)
         ids = torch.tensor([[5, 6, 7] + [tok] * T + [8, 9, 10, 11, 12]], device="cuda")
@@ -91,13 +97,14 @@ def worker(rank, world, port, merge, T, q, pd=PD):
 UNI3 = "uni_2_0.75-uni_3_0.5-uni_6_0.25"
 
 
-@pytest.mark.parametrize("merge,pd", [("no_merge", None), ("CrossAttention", UNI3), ("CrossAttention", PD)])
-def test_sequence_parallel_hip_matches_single_process(merge, pd):
+@pytest.mark.parametrize("merge,pd,family", [("no_merge", None, "nano"), ("CrossAttention", UNI3, "nano"),
+                                             ("CrossAttention", PD, "nano"), ("CrossAttention", UNI3, "qwen2")])
+def test_sequence_parallel_hip_matches_single_process(merge, pd, family):
     world, T = 2, 21           # 21 frames x 16 tokens: shards of 11 / 10 frames, ragged scan chunks
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=worker, args=(r, world, port, merge, T, q, pd)) for r in range(world)]
+    procs = [ctx.Process(target=worker, args=(r, world, port, merge, T, q, pd, family)) for r in range(world)]
     for p in procs:
         p.start()
     try:

@@ -76,13 +76,13 @@ def chain_states(states: torch.Tensor, decays: torch.Tensor, rank: int) -> torch
     return inc
 
 
-def split_frames(n_frames: int, world: int, causal_skew: float = 0.0) -> List[Tuple[int, int]]:
+def split_frames(n_frames: int, world: int, causal_skew: float = 0.0, align: int = 1) -> List[Tuple[int, int]]:
     """Contiguous frame ranges, one per rank.  `causal_skew` = k >= 0 models a rank's step time as
     f_r (1 + k (F_before_r + f_r / 2)): work linear in its frames (ViT, GEMMs, scans) plus causal
     attention of its frames against everything before them.  k = 0 gives the even split; k > 0
     hands later ranks fewer frames so that all ranks finish together (k from
     `estimate_causal_skew`; at 10 240 frames over 8 ranks the last rank's attention is otherwise
-    1.9x the mean: ~3 % of the step)."""
+    1.9x the mean: ~3 % of the step).  `align`: shard boundaries fall on multiples of `align` frames."""
     if causal_skew <= 0.0 or world == 1 or n_frames < 2 * world:
         base, rem = divmod(n_frames, world)
         sizes = [base + (1 if r < rem else 0) for r in range(world)]
@@ -106,6 +106,15 @@ def split_frames(n_frames: int, world: int, causal_skew: float = 0.0) -> List[Tu
         order = sorted(range(world), key=lambda r: real[r] - sizes[r], reverse=True)
         for r in order[: n_frames - sum(sizes)]:
             sizes[r] += 1
+    if align > 1:      # boundaries on multiples of `align` frames (towers that regroup frames per clip)
+        cuts, acc = [], 0
+        for n in sizes[:-1]:
+            acc += n
+            cuts.append(min(n_frames, int(round(acc / align)) * align))
+        cuts = [0] + [max(c, 0) for c in cuts] + [n_frames]
+        for i in range(1, len(cuts)):
+            cuts[i] = max(cuts[i], cuts[i - 1])
+        return [(cuts[i], cuts[i + 1]) for i in range(world)]
     out, lo_f = [], 0
     for n in sizes:
         out.append((lo_f, lo_f + n))
@@ -135,8 +144,8 @@ def estimate_causal_skew(vlm, tokens_per_frame: int) -> float:
         if i in layers:
             keep = float(ratios[layers.index(i) + 1])
         flops_lin += 2.0 * lin(block) * tokens_per_frame * keep
-        if getattr(block, "block_type", "") == "attention":
-            mx = block.mixer
+        mx = block.mixer if getattr(block, "block_type", "") == "attention" else getattr(block, "self_attn", None)
+        if mx is not None:          # a hybrid stack's attention layers / every Qwen2 layer
             attn_pair += 4.0 * (tokens_per_frame * keep) ** 2 * mx.head_dim * mx.num_heads
     if flops_lin <= 0.0:
         return 0.0
@@ -156,10 +165,10 @@ class SequenceParallelTimeViper:
         self.causal_skew = causal_skew
         self.shard_lens: Optional[List[int]] = None     # host-side shard lengths (set by forward)
         self.llm = vlm.llm_backbone.llm
-        if vlm.llm_backbone.llm_family != "nano":
-            raise NotImplementedError("sequence parallelism is built for the hybrid Mamba-2 backbone only "
-                                      f"(got family `{vlm.llm_backbone.llm_family}`)")
-        self.bb = self.llm.backbone
+        self.family = vlm.llm_backbone.llm_family
+        if self.family not in ("nano", "qwen2"):
+            raise NotImplementedError(f"sequence parallelism: unknown LLM family `{self.family}`")
+        self.bb = self.llm.backbone            # NemotronHModel / Qwen2Model
         self.cfg = self.llm.config
 
     # ---------------------------------------------------------------- layout
@@ -172,7 +181,11 @@ class SequenceParallelTimeViper:
             if hasattr(self.vlm.vision_backbone, "backbone_ids"):
                 tpf *= len(self.vlm.vision_backbone.backbone_ids)
             self.causal_skew = estimate_causal_skew(self.vlm, tpf)
-        return split_frames(n_frames, self.world, self.causal_skew)
+        # towers that regroup the frames of a clip into tubes (InternVideo2, alone or inside a dual
+        # encoder) see the same clips as an unsharded run only if the shards start on clip boundaries
+        vb = self.vlm.vision_backbone
+        align = int(getattr(self.vlm, "vit_clip_frames", 256)) if getattr(vb, "batched_clips", False) else 1
+        return split_frames(n_frames, self.world, self.causal_skew, align=align)
 
     def shard_layout(self, input_ids: torch.Tensor, n_frames: int, tok_per_frame: int):
         """Global token ranges [start, end) of every rank's shard, for a prompt of the form
@@ -259,7 +272,9 @@ class SequenceParallelTimeViper:
         y = mixer.norm(y.view(Bsz, L, d_in), gate)
         return mixer.out_proj(y)
 
-    def _attention(self, attn, normed):
+    def _attention(self, attn, normed, rope=None):
+        """`rope` = (cos, sin) of this shard's GLOBAL positions (Qwen2): keys are rotated before they are
+        gathered (every rank rotates its own rows once), queries after the gather has been started."""
         Bsz, L, _ = normed.shape
         assert Bsz == 1, "the sequence-sharded runner is batch 1 (the evaluation path)"
         kvd = attn.num_key_value_heads * attn.head_dim
@@ -272,15 +287,21 @@ class SequenceParallelTimeViper:
         kv[1, :L] = attn.v_proj(normed).view(L, kvd)
         if L < mx:
             kv[:, L:].zero_()
+        q = None
+        if rope is not None and L > 0:       # rotary embedding in place on q and on the k rows of the buffer
+            q = attn.q_proj(normed).view(Bsz, L, attn.num_heads, attn.head_dim)
+            K.apply_rotary_pos_emb_(q, kv[0, :L].view(1, L, attn.num_key_value_heads, attn.head_dim), *rope)
         gathered = torch.empty((self.world, kv.numel()), dtype=kv.dtype, device=kv.device)
         work = dist.all_gather_into_tensor(gathered, kv.view(1, -1), group=self.group, async_op=True)
         gathered = gathered.view((self.world,) + tuple(kv.shape))
-        q = attn.q_proj(normed).view(Bsz, L, attn.num_heads, attn.head_dim)
+        if q is None:
+            q = attn.q_proj(normed).view(Bsz, L, attn.num_heads, attn.head_dim)
         work.wait()
         upto = self.rank + 1
         kf = torch.cat([gathered[r, 0, :lens[r]] for r in range(upto)]).view(1, -1, attn.num_key_value_heads, attn.head_dim)
         vf = torch.cat([gathered[r, 1, :lens[r]] for r in range(upto)]).view(1, -1, attn.num_key_value_heads, attn.head_dim)
-        o = K.flash_attn_func(q, kf, vf, causal=True)      # bottom-right aligned: Lk >= Lq
+        scale = getattr(attn, "scaling", None)
+        o = K.flash_attn_func(q, kf, vf, softmax_scale=scale, causal=True)      # bottom-right aligned: Lk >= Lq
         return attn.o_proj(o.reshape(Bsz, L, attn.num_heads * attn.head_dim))
 
     # ---------------------------------------------------------------- pdrop
@@ -297,7 +318,7 @@ class SequenceParallelTimeViper:
         dev = feats.device
         vis_end = vis0 + image_tokens
         if "attn" in ctype:
-            sa = bb.layers[layer_idx].mixer
+            sa = bb._rank_attention(layer_idx)
             row = txt_len + image_tokens - 1                      # global index of the query token
             # the query row lives on the last rank: broadcast its projected queries
             q_row = torch.empty((sa.num_heads, sa.head_dim), dtype=feats.dtype, device=dev)
@@ -418,6 +439,8 @@ class SequenceParallelTimeViper:
         (tests/test_distributed_cpu.py counts the host reads)."""
         bb = self.bb
         self.trace = []
+        if self.family == "qwen2":
+            return self._run_layers_qwen2(hidden, start, meta)
         delta = None
         for i, block in enumerate(bb.layers):
             if bb.use_pdrop and i in bb.pdrop_layers:
@@ -437,6 +460,40 @@ class SequenceParallelTimeViper:
             else:
                 delta = block.mixer(normed)
         hidden = bb.norm_f(hidden, residual=delta) if delta is not None else bb.norm_f(hidden)
+        logits = torch.empty((1, 1, self.cfg.vocab_size), dtype=torch.float32, device=hidden.device)
+        if self.rank == self.world - 1:
+            logits = self.llm.lm_head(hidden[:, -1:]).float()
+        dist.broadcast(logits, src=_global_rank(self.group, self.world - 1), group=self.group)
+        return logits
+
+    def _run_layers_qwen2(self, hidden, start: int, meta):
+        """Qwen2 decoder stack (modeling_qwen2.py:878-1038) on this rank's shard: every layer is attention
+        (K/V all-gather, rotary embedding at the shard's global positions) + a row-local SwiGLU MLP;
+        positions restart from 0 after each pdrop stage (:918-966), i.e. they are the global row indices
+        of the shortened sequence."""
+        bb = self.bb
+
+        def rope_of(h, s0):
+            pos = torch.arange(s0, s0 + h.shape[1], device=h.device)[None]
+            return bb.rotary_emb(h, pos)
+        rope = rope_of(hidden, start)
+        delta = None
+        for i, layer in enumerate(bb.layers):
+            if bb.use_pdrop and i in bb.pdrop_layers:
+                if delta is not None:
+                    hidden, delta = hidden + delta, None
+                stage = bb.pdrop_layers.index(i)
+                hidden, start, top = self._pdrop(stage, i, hidden, start, meta)
+                self.trace.append(top)
+                rope = rope_of(hidden, start)
+            if delta is None:
+                h = layer.input_layernorm(hidden)
+            else:
+                h, hidden = layer.input_layernorm(hidden, residual=delta, return_sum=True)
+            a = self._attention(layer.self_attn, h, rope=rope)
+            h, hidden = layer.post_attention_layernorm(hidden, residual=a, return_sum=True)
+            delta = layer.mlp(h)
+        hidden = bb.norm(hidden, residual=delta) if delta is not None else bb.norm(hidden)
         logits = torch.empty((1, 1, self.cfg.vocab_size), dtype=torch.float32, device=hidden.device)
         if self.rank == self.world - 1:
             logits = self.llm.lm_head(hidden[:, -1:]).float()
