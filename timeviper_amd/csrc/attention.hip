@@ -28,14 +28,24 @@ constexpr int FA_QW = 32;                  // query rows per wave
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
+// Fragment reads take a 32-bit LDS byte offset: one base register per fragment family and iteration,
+// everything compile-time (sub-tile, k-step, row half) in the instruction's offset field.  (With generic
+// pointers hipcc spent a v_add per read: 112 of the ~330 VALU instructions of a ViT tile, in a loop
+// that is VALU-bound at head_dim 72.)
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+__device__ __forceinline__ const lds_u8* lds_at(unsigned off) { return (const lds_u8*)(uintptr_t)off; }
+
 template <typename T> struct Frag;
 template <> struct Frag<bf16_t> {
   typedef bf16x8 v8; typedef bf16x4 v4;
   static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
   }
-  static __device__ __forceinline__ v4 tr_read(const bf16_t* p) {
+  static __device__ __forceinline__ v4 tr_read(const lds_u8* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p);
+  }
+  static __device__ __forceinline__ v8 row_read(const lds_u8* p) {
+    return *(const __attribute__((address_space(3))) v8*)p;
   }
 };
 template <> struct Frag<f16_t> {
@@ -43,9 +53,12 @@ template <> struct Frag<f16_t> {
   static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
   }
-  static __device__ __forceinline__ v4 tr_read(const f16_t* p) {
+  static __device__ __forceinline__ v4 tr_read(const lds_u8* p) {
     const s16x4 raw = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
     return __builtin_bit_cast(f16x4, raw);
+  }
+  static __device__ __forceinline__ v8 row_read(const lds_u8* p) {
+    return *(const __attribute__((address_space(3))) v8*)p;
   }
 };
 
@@ -83,6 +96,7 @@ __global__ __launch_bounds__(NW * 64) void flash_fwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fa_smem[];
   unsigned char* const sK = fa_smem;
   unsigned char* const sV = fa_smem + NS * TILEB;
+  const unsigned sK_off = (unsigned)(uintptr_t)(lds_u8*)fa_smem, sV_off = sK_off + NS * TILEB;
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -211,8 +225,9 @@ __global__ __launch_bounds__(NW * 64) void flash_fwd_kernel(AttnArgs a) {
   for (int kt = 0; kt < ntiles; ++kt) {
     const int kbase = kt * FA_KB;
     const bool ahead = kt + 2 < ntiles;
-    const unsigned char* cK = sK + (kt % NS) * TILEB;
-    const unsigned char* cV = sV + (kt % NS) * TILEB;
+    // stage bases as LDS byte offsets (scalar), folded into one base register per fragment family
+    const unsigned stage_off = (unsigned)((kt % NS) * TILEB);
+    const unsigned cK = sK_off + stage_off, cV = sV_off + stage_off;
 
     // wave-uniform skip of tiles entirely above this wave's causal diagonal
     const int wave_q_last = q0 + FA_QW - 1;
@@ -223,10 +238,13 @@ __global__ __launch_bounds__(NW * 64) void flash_fwd_kernel(AttnArgs a) {
       // the copies of tile kt+2 are issued between the MFMAs, whose pipe time hides them ----
       f32x16 sacc[KT];
       v8 kf[KT][KS];
+      unsigned kb[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) kb[ks] = cK + (unsigned)k_rd[ks];
 #pragma unroll
       for (int t = 0; t < KT; ++t)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) kf[t][ks] = *(const v8*)(cK + t * (32 * ROWB) + k_rd[ks]);
+        for (int ks = 0; ks < KS; ++ks) kf[t][ks] = Frag<T>::row_read(lds_at(kb[ks]) + t * (32 * ROWB));
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int t = 0; t < KT; ++t) {
@@ -299,12 +317,15 @@ __global__ __launch_bounds__(NW * 64) void flash_fwd_kernel(AttnArgs a) {
       // ---- O^T += V^T . P^T over 4 k-steps of 16 keys; the V^T fragments of k-step s+1 are in
       // flight while k-step s multiplies ----
       {
+        unsigned vb[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) vb[dt] = cV + (unsigned)v_rd[dt];
         auto read_v = [&](int s_, v4 (&lo)[DT], v4 (&hi)[DT]) {
           // element j of this lane is key row 16s + 8(j>>2) + 4hh + (j&3) of the tile
 #pragma unroll
           for (int dt = 0; dt < DT; ++dt) {
-            lo[dt] = Frag<T>::tr_read((const T*)(cV + s_ * (16 * ROWB) + v_rd[dt]));
-            hi[dt] = Frag<T>::tr_read((const T*)(cV + s_ * (16 * ROWB) + 8 * ROWB + v_rd[dt]));
+            lo[dt] = Frag<T>::tr_read(lds_at(vb[dt]) + s_ * (16 * ROWB));
+            hi[dt] = Frag<T>::tr_read(lds_at(vb[dt]) + s_ * (16 * ROWB) + 8 * ROWB);
           }
         };
         v4 vlo[2][DT], vhi[2][DT];

@@ -25,7 +25,7 @@ for f in sorted(glob.glob("gpurun_out/pmc_attn*/p_counter_collection.csv")):
     for (name, _), cs in per.items():
         for c, v in cs.items():
             agg[name][c].append(v)
-out = ["# rocprofv3 --pmc passes on `python3 timeviper_amd/devtools/bench_ops.py --ops attn,patch` (end of round 1)\n",
+out = ["# rocprofv3 --pmc passes on `python3 timeviper_amd/devtools/bench_ops.py --ops attn,patch` (round 2; the attention and patch-embed kernels are unchanged since the end of round 1)\n",
        "One counter set per pass (`timeviper_amd/devtools/pmc_attn.sh`, no tracing options); mean per launch, summed over "
        "the rows rocprofv3 reports per dispatch (`timeviper_amd/devtools/summarize_pmc_attn.py`). Kernels: "
        "`flash_fwd_kernel<bf16,8,4,8,3>` = causal GQA attention, L = 32 868, 40/8 heads x 128, 96-key tiles; "
