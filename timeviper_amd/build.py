@@ -29,6 +29,8 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=
          "-Wno-unused-result", "-DNDEBUG"]
 if os.environ.get("TV_MARCH_ABLATE"):   # dev only: compile the scan kernel's ablation switches in
     FLAGS.append("-DTV_MARCH_ABLATE")
+if os.environ.get("TV_FA_STAMP"):       # dev only: per-phase stamps in the streaming attention kernel
+    FLAGS.append("-DTV_FA_STAMP")
 if os.environ.get("TV_SLICE_STAMP"):    # dev only: per-wave barrier-wait stamps in ssd_slice.hip
     FLAGS.append("-DTV_SLICE_STAMP")
 

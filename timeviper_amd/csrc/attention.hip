@@ -35,6 +35,10 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 typedef __attribute__((address_space(3))) unsigned char lds_u8;
 __device__ __forceinline__ const lds_u8* lds_at(unsigned off) { return (const lds_u8*)(uintptr_t)off; }
 
+using ssdk::u32x4;
+using ssdk::gload16_async;
+using ssdk::settle;
+
 template <typename T> struct Frag;
 template <> struct Frag<bf16_t> {
   typedef bf16x8 v8; typedef bf16x4 v4;
@@ -71,6 +75,7 @@ struct AttnArgs {
   float scale_log2;  // softmax_scale * log2(e)
   int causal;
   int nqb, nb;       // nqb > 0: 1-D XCD-aware grid, nqb query blocks per (batch, head), nb batches; 0: 3-D grid
+  int ppx;           // streaming kernel: (batch, head) pairs per XCD
 };
 
 // KS = ceil(D/16) k-steps of QK^T, DT = ceil(D/32) d-tiles of PV, NW waves per workgroup.
@@ -142,13 +147,14 @@ __global__ __launch_bounds__(NW * 64) void flash_fwd_kernel(AttnArgs a) {
     }
   }
 
-  // Q^T fragments (B operand): lane (r,hh) holds Q[qrow][16ks + 8hh + j]
+  // Q^T fragments (B operand): lane (r,hh) holds Q[qrow][16ks + 8hh + j]; untracked loads, settled
+  // behind the first counted wait below
   v8 qf[KS];
+  u32x4 qraw[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     const int d0 = ks * 16 + hh * 8;
-    v8 z = {};
-    qf[ks] = (qrow < a.Lq && d0 < D) ? *(const v8*)(qp + (int64_t)qrow * a.qsl + d0) : z;
+    qraw[ks] = gload16_async((qrow < a.Lq && d0 < D) ? qp + (int64_t)qrow * a.qsl + d0 : qp);
   }
 
   f32x16 oacc[DT];
@@ -221,6 +227,12 @@ __global__ __launch_bounds__(NW * 64) void flash_fwd_kernel(AttnArgs a) {
   if (ntiles > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {      // the Q loads are older than every copy: landed
+    settle(qraw[ks]);
+    const v8 z = {};
+    qf[ks] = (qrow < a.Lq && ks * 16 + hh * 8 < D) ? __builtin_bit_cast(v8, qraw[ks]) : z;
+  }
 
   for (int kt = 0; kt < ntiles; ++kt) {
     const int kbase = kt * FA_KB;
@@ -379,6 +391,341 @@ __global__ __launch_bounds__(NW * 64) void flash_fwd_kernel(AttnArgs a) {
   }
 }
 
+
+// -DTV_FA_STAMP (dev): waves 0 and 4 of work-group 0 of the streaming kernel sum the cycles of each phase
+// of tile kt (s_memtime): g_fa_stamps[wave/4][kt < 16][phase < 8]; tv_fa_debug_stamps() copies them out.
+#ifdef TV_FA_STAMP
+__device__ unsigned long long g_fa_stamps[2 * 16 * 8];
+#define FSTAMP(ph) do { if (st_on) { const unsigned long long n__ = clock64(); if (lane == 0) st_acc[((wave >> 2) * 16 + (kt < 16 ? kt : 15)) * 8 + ph] += n__ - st_last; st_last = n__; } } while (0)
+#else
+#define FSTAMP(ph) do {} while (0)
+#endif
+
+// Many short sequences (ViT frames: 729 tokens = 8 key tiles per query block): a work-group that
+// handles ONE query block spends a third of its life outside the tile loop — waiting for Q and the
+// first two K/V tiles, zeroing LDS, storing O — and at 147 KiB of LDS nothing else is resident on
+// the CU to cover that (measured: 27.9 us per work-group of which 8 x 2.2 us in the loop).  This
+// kernel keeps the work-group and STREAMS query blocks through it: the K/V ring never drains — the
+// copies of the next block's first two tiles are issued under the last two tiles of the current
+// one, its Q fragments are loaded under the last tile — and the O stores of a block complete under
+// the first tile of the next.  Non-causal, >= 2 key tiles.  Grid: 8 x (work-groups per XCD); the
+// work-groups of XCD x walk slots x*... of that XCD's contiguous range of (batch, head) pairs, so the
+// query blocks that share K / V still meet in one L2 at about the same time.
+template <typename T, int KS, int DT, int KT>
+__global__ __launch_bounds__(512) void flash_fwd_stream_kernel(AttnArgs a) {
+  constexpr int NW = 8;
+  constexpr int FA_KB = 32 * KT;
+  constexpr int NPK = FA_KB / 4;
+  typedef typename Frag<T>::v8 v8;
+  typedef typename Frag<T>::v4 v4;
+  constexpr int QB = NW * FA_QW;
+  constexpr int ROWB = 256;
+  constexpr int TILEB = FA_KB * ROWB;
+  constexpr int NS = 3;
+  constexpr int PPW = 2 * NPK / NW;
+  static_assert(2 * NPK % NW == 0, "pieces must divide over the waves");
+  extern __shared__ __attribute__((aligned(16))) unsigned char fa_smem[];
+  unsigned char* const sK = fa_smem;
+  const unsigned sK_off = (unsigned)(uintptr_t)(lds_u8*)fa_smem, sV_off = sK_off + NS * TILEB;
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int r = lane & 31, hh = lane >> 5;
+  const int D = a.D;
+  const int xcd = blockIdx.x & 7, step = gridDim.x >> 3;
+  const int nslots = a.ppx * a.nqb, npairs = a.nb * a.Hq;
+  int slot = blockIdx.x >> 3;
+  int pair = xcd * a.ppx + slot / a.nqb, qblk = slot % a.nqb;
+  if (slot >= nslots || pair >= npairs) return;
+  const int gq = a.Hq / a.Hkv;
+  auto k_of = [&](int pr) { return (const T*)a.k + (int64_t)(pr / a.Hq) * a.ksb + (int64_t)((pr % a.Hq) / gq) * a.ksh; };
+  auto v_of = [&](int pr) { return (const T*)a.v + (int64_t)(pr / a.Hq) * a.vsb + (int64_t)((pr % a.Hq) / gq) * a.vsh; };
+  // Q^T fragments (B operand): lane (r,hh) holds Q[qrow][16ks + 8hh + j]
+  // untracked loads (gload16_async) + a finishing step behind the counted wait that covers them
+  auto load_q = [&](int pr, int qb, u32x4 (&raw)[KS]) {
+    const T* qp = (const T*)a.q + (int64_t)(pr / a.Hq) * a.qsb + (int64_t)(pr % a.Hq) * a.qsh;
+    const int qrow = qb * QB + wave * FA_QW + r;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int d0 = ks * 16 + hh * 8;
+      raw[ks] = gload16_async((qrow < a.Lq && d0 < D) ? qp + (int64_t)qrow * a.qsl + d0 : qp);
+    }
+  };
+  auto finish_q = [&](int qb, u32x4 (&raw)[KS], v8 (&qf)[KS]) {
+    const int qrow = qb * QB + wave * FA_QW + r;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      settle(raw[ks]);
+      const v8 z = {};
+      qf[ks] = (qrow < a.Lq && ks * 16 + hh * 8 < D) ? __builtin_bit_cast(v8, raw[ks]) : z;
+    }
+  };
+  v8 qf[KS];
+  u32x4 qn[KS];
+  load_q(pair, qblk, qn);
+
+  if (D < 16 * KS) {                 // K chunks between head_dim and 16 KS: read by QK^T, never copied
+    const v8 z = {};
+    const int c0 = D / 8, nc = 2 * KS - c0;
+    for (int i = tid; i < NS * FA_KB * nc; i += NW * 64) {
+      const int row = (i / nc) % FA_KB, st = i / (nc * FA_KB), c = c0 + i % nc;
+      *reinterpret_cast<v8*>(sK + st * TILEB + row * ROWB + ((c ^ (row & 15)) << 4)) = z;
+    }
+  }
+
+  // ---- DMA pieces of this wave (as in flash_fwd_kernel) ----
+  int p_row[PPW];
+  unsigned p_off[PPW];
+  int p_chunk[PPW];
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) {
+    const int pc = wave + NW * i;
+    const bool isK = pc < NPK;
+    const int row = 4 * (isK ? pc : pc - NPK) + (lane >> 4);
+    const int c = (lane & 15) ^ (isK ? (row & 15) : 4 * (row & 3));
+    p_row[i] = row;
+    p_chunk[i] = c;
+    p_off[i] = (unsigned)(((int64_t)row * (isK ? a.ksl : a.vsl) + c * 8) * (int)sizeof(T));
+  }
+  const int dchunks = D / 8;
+  auto issue_piece = [&](const T* kpx, const T* vpx, int kt, int stage, int i) {
+    const int kbase = kt * FA_KB;
+    const int pc = wave + NW * i;
+    const bool isK = pc < NPK;           // compile-time per (wave-uniform) branch
+    const void* tb = ssdk::uniform_ptr(isK ? (const void*)(kpx + (int64_t)kbase * a.ksl)
+                                           : (const void*)(vpx + (int64_t)kbase * a.vsl));
+    const int left = a.Lk - kbase;
+    unsigned off = p_off[i];
+    if (left < FA_KB) {                  // last tile: rows past the end repeat the last key (masked later)
+      const int rr = min(p_row[i], left - 1);
+      off = (unsigned)(((int64_t)rr * (isK ? a.ksl : a.vsl) + p_chunk[i] * 8) * (int)sizeof(T));
+    }
+    const unsigned dst = (isK ? sK_off : sV_off) + (unsigned)(stage * TILEB + (isK ? pc : pc - NPK) * 1024);
+    if (p_chunk[i] < dchunks) ssdk::glds16(tb, off, __builtin_amdgcn_readfirstlane(dst));
+  };
+
+  int k_rd[KS];
+  const int kz = (hh ^ (r & 15)) << 4;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) k_rd[ks] = r * ROWB + ((32 * ks) ^ kz);
+  const int q4 = (lane & 15) >> 2, p4 = lane & 3;
+  int v_rd[DT];
+  {
+    const int cc = 2 * ((lane >> 4) & 1) + (p4 >> 1);
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+      v_rd[dt] = (4 * hh + q4) * ROWB + ((4 * (dt ^ q4) + cc) << 4) + (p4 & 1) * 8;
+  }
+
+  const int ntiles = (a.Lk + FA_KB - 1) / FA_KB;       // >= 2 (launcher)
+  const T* kp = k_of(pair);
+  const T* vp = v_of(pair);
+  __syncthreads();                 // LDS zeroed before the first copy lands
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) issue_piece(kp, vp, 0, 0, i);
+#pragma unroll
+  for (int i = 0; i < PPW; ++i) issue_piece(kp, vp, 1, 1, i);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+  __builtin_amdgcn_s_barrier();
+  finish_q(qblk, qn, qf);
+
+  int stage = 0;                   // ring stage of the current tile
+#ifdef TV_FA_STAMP
+  const bool st_on = blockIdx.x == 0 && (wave == 0 || wave == 4);
+  __shared__ unsigned long long st_acc[2 * 16 * 8];
+  if (tid < 256) st_acc[tid] = 0;
+  __syncthreads();
+  unsigned long long st_last = clock64();
+#endif
+  for (;;) {
+    const int slot_n = slot + step;
+    const int pair_n = xcd * a.ppx + slot_n / a.nqb, qblk_n = slot_n % a.nqb;
+    const bool has_next = slot_n < nslots && pair_n < npairs;
+    const T* kp_n = has_next ? k_of(pair_n) : kp;
+    const T* vp_n = has_next ? v_of(pair_n) : vp;
+
+    f32x16 oacc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) oacc[dt][i] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    for (int kt = 0; kt < ntiles; ++kt) {
+      const int kbase = kt * FA_KB;
+      // the copy that goes out under this tile: two tiles on, in this block or the next one
+      const bool wrap = kt + 2 >= ntiles;
+      const bool ahead = !wrap || has_next;
+      const T* pk = wrap ? kp_n : kp;
+      const T* pv = wrap ? vp_n : vp;
+      const int pf_kt = wrap ? kt + 2 - ntiles : kt + 2;
+      const int pf_stage = stage == 0 ? 2 : stage - 1;
+      if (kt == ntiles - 1 && has_next) load_q(pair_n, qblk_n, qn);   // older than this tile's copies
+      const unsigned stage_off = (unsigned)(stage * TILEB);
+      const unsigned cK = sK_off + stage_off, cV = sV_off + stage_off;
+
+      f32x16 sacc[KT];
+      v8 kf[KT][KS];
+      unsigned kb[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) kb[ks] = cK + (unsigned)k_rd[ks];
+#pragma unroll
+      for (int t = 0; t < KT; ++t)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) kf[t][ks] = Frag<T>::row_read(lds_at(kb[ks]) + t * (32 * ROWB));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < KT; ++t) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sacc[t][i] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          sacc[t] = Frag<T>::mfma(kf[t][ks], qf[ks], sacc[t]);
+          constexpr int every = (KT * KS) / PPW > 0 ? (KT * KS) / PPW : 1;
+          const int idx = t * KS + ks;
+          if (ahead && idx % every == 0 && idx / every < PPW) issue_piece(pk, pv, pf_kt, pf_stage, idx / every);
+        }
+      }
+      if (ahead) {
+#pragma unroll
+        for (int i = (KT * KS) / ((KT * KS) / PPW > 0 ? (KT * KS) / PPW : 1); i < PPW; ++i)
+          issue_piece(pk, pv, pf_kt, pf_stage, i);
+      }
+      FSTAMP(0);
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      if (kbase + FA_KB > a.Lk) {
+#pragma unroll
+        for (int t = 0; t < KT; ++t)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int key = kbase + t * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+            sacc[t][i] = key < a.Lk ? sacc[t][i] : -INFINITY;
+          }
+      }
+      float tmax = -INFINITY;
+#pragma unroll
+      for (int t = 0; t < KT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) tmax = fmaxf(fmaxf(tmax, sacc[t][i]), sacc[t][i + 1]);
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float m_new = fmaxf(m_run, tmax * a.scale_log2);
+      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+      const f32x2 sc2 = {a.scale_log2, a.scale_log2}, nm2 = {-m_use, -m_use};
+      f32x2 ps2 = {0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < KT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {
+          const f32x2 e = __builtin_elementwise_fma(f32x2{sacc[t][i], sacc[t][i + 1]}, sc2, nm2);
+          const f32x2 pp = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+          sacc[t][i] = pp[0];
+          sacc[t][i + 1] = pp[1];
+          ps2 += pp;
+        }
+      l_run = l_run * alpha + (ps2[0] + ps2[1]);
+      if (__builtin_amdgcn_ballot_w64(m_new > m_run)) {
+        const f32x2 al2 = {alpha, alpha};
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+          for (int i = 0; i < 16; i += 2) {
+            const f32x2 v = f32x2{oacc[dt][i], oacc[dt][i + 1]} * al2;
+            oacc[dt][i] = v[0];
+            oacc[dt][i + 1] = v[1];
+          }
+      }
+      m_run = m_new;
+      FSTAMP(1);
+      {
+        unsigned vb[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) vb[dt] = cV + (unsigned)v_rd[dt];
+        auto read_v = [&](int s_, v4 (&lo)[DT], v4 (&hi)[DT]) {
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            lo[dt] = Frag<T>::tr_read(lds_at(vb[dt]) + s_ * (16 * ROWB));
+            hi[dt] = Frag<T>::tr_read(lds_at(vb[dt]) + s_ * (16 * ROWB) + 8 * ROWB);
+          }
+        };
+        v4 vlo[2][DT], vhi[2][DT];
+        read_v(0, vlo[0], vhi[0]);
+#pragma unroll
+        for (int s_ = 0; s_ < 2 * KT; ++s_) {
+          if (s_ < 2 * KT - 1) read_v(s_ + 1, vlo[(s_ + 1) & 1], vhi[(s_ + 1) & 1]);
+          const int t = s_ >> 1, rb = (s_ & 1) * 8;
+          v8 pf;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pf[j] = from_f32<T>(sacc[t][rb + j]);
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            v8 vf;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { vf[j] = vlo[s_ & 1][dt][j]; vf[4 + j] = vhi[s_ & 1][dt][j]; }
+            oacc[dt] = Frag<T>::mfma(vf, pf, oacc[dt]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      FSTAMP(2);
+      // the next tile (copied an iteration ago) must have landed; this iteration's copies stay in flight
+      if (ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      FSTAMP(3);
+      __builtin_amdgcn_s_barrier();
+      FSTAMP(4);
+      stage = stage == NS - 1 ? 0 : stage + 1;
+    }
+
+    // ---- normalise and store O[q][d] of this block; the stores complete under the next block's first tile ----
+    {
+      const int h = pair % a.Hq, b = pair / a.Hq;
+      const int qrow = qblk * QB + wave * FA_QW + r;
+      const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+      const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+      if (qrow < a.Lq) {
+        T* op = (T*)a.o + (int64_t)b * a.osb + (int64_t)qrow * a.osl + (int64_t)h * a.osh;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int d0 = dt * 32 + 8 * g + 4 * hh;
+            if (d0 < D) {
+              v4 pk4;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) pk4[j] = from_f32<T>(oacc[dt][4 * g + j] * inv);
+              *(v4*)(op + d0) = pk4;
+            }
+          }
+        if (a.lse && hh == 0) {
+          const float lse = l_tot > 0.f ? (m_run * 0.6931471805599453f + logf(l_tot)) : -INFINITY;
+          a.lse[((int64_t)b * a.Hq + h) * a.Lq + qrow] = lse;
+        }
+      }
+    }
+    { const int kt = 15; FSTAMP(5); (void)kt; }
+    if (!has_next) break;
+    slot = slot_n; pair = pair_n; qblk = qblk_n; kp = kp_n; vp = vp_n;
+    finish_q(qblk, qn, qf);        // loaded under the last tile, older than the copies its wait left in flight
+  }
+#ifdef TV_FA_STAMP
+  __syncthreads();
+  if (blockIdx.x == 0 && tid < 256) g_fa_stamps[tid] = st_acc[tid];
+#endif
+}
+
+int tv_cu_count() {
+  static const int n = [] {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8)
+      cus = 256;                               // MI355X
+    return cus;
+  }();
+  return n;
+}
+
 template <typename T, int KS, int DT>
 int launch_fa_d(const AttnArgs& a, int B, hipStream_t st) {
   constexpr int KT = FA_KT;
@@ -395,7 +742,20 @@ int launch_fa_d(const AttnArgs& a, int B, hipStream_t st) {
         ax.nqb = nqb;
         ax.nb = B;
         const int64_t pairs = ((int64_t)B * a.Hq + 7) / 8 * 8;
-        flash_fwd_kernel<T, KS, DT, 8, KT><<<dim3((unsigned)(pairs * nqb), 1, 1), 512, lds, st>>>(ax);
+        ax.ppx = (int)(pairs / 8);
+        static const int stream_ = [] { const char* v = getenv("TV_FA_STREAM"); return v ? atoi(v) : 1; }();
+        const int64_t slots = (int64_t)ax.ppx * nqb;          // query blocks per XCD
+        if constexpr (KS > 6) {                                // head_dim 128: the second Q set does not fit the registers
+          flash_fwd_kernel<T, KS, DT, 8, KT><<<dim3((unsigned)(pairs * nqb), 1, 1), 512, lds, st>>>(ax);
+        } else if (stream_ && a.Lk > 32 * KT && slots > tv_cu_count() / 8) {
+          // one resident work-group per CU streams its share of the query blocks
+          e = hipFuncSetAttribute((const void*)flash_fwd_stream_kernel<T, KS, DT, KT>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+          if (e == hipSuccess)
+            flash_fwd_stream_kernel<T, KS, DT, KT><<<dim3((unsigned)(8 * (tv_cu_count() / 8)), 1, 1), 512, lds, st>>>(ax);
+        } else {
+          flash_fwd_kernel<T, KS, DT, 8, KT><<<dim3((unsigned)(pairs * nqb), 1, 1), 512, lds, st>>>(ax);
+        }
       } else {
         dim3 grid(nqb, a.Hq, B);
         flash_fwd_kernel<T, KS, DT, 8, KT><<<grid, 512, lds, st>>>(a);
@@ -427,6 +787,12 @@ int launch_fa(const AttnArgs& a, int B, hipStream_t st) {
 }
 
 }  // namespace
+
+#ifdef TV_FA_STAMP
+extern "C" int tv_fa_debug_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fa_stamps), sizeof(g_fa_stamps));
+}
+#endif
 
 extern "C" int tv_flash_attn_fwd(const void* q, const void* k, const void* v, void* o, void* lse,
                                  int batch, int seqlen_q, int seqlen_k, int nheads_q,

@@ -205,17 +205,16 @@ __global__ __launch_bounds__(NW * 64) void flash_fwd_fp8_kernel(Fp8Args a) {
   const float c = a.scale_log2 * f8_dequant_scale(aq) * f8_dequant_scale(ak);   // raw accumulator -> log2 domain
 
   // Q^T fragments (B operand): lane (r, hh) holds q~[qrow][64 s + 32 hh + 0..31]
+  // (loads the compiler does not track — ssd_common.hpp gload16_async — settled behind the first counted wait:
+  // tracked ones made hipcc drain the copy queue with vmcnt(0) in front of the first MFMA of every tile)
   i32x8 qf[2];
+  ssdk::u32x4 qraw[2][2];
   {
     const unsigned char* qp = a.qq + (((int64_t)b * a.Hq + h) * a.Lq + min(qrow, a.Lq - 1)) * F8_DP + 32 * hh;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      i32x4 lo = {0, 0, 0, 0}, hi = lo;
-      if (qrow < a.Lq) {
-        lo = *(const i32x4*)(qp + 64 * s);
-        hi = *(const i32x4*)(qp + 64 * s + 16);
-      }
-      qf[s] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      qraw[s][0] = ssdk::gload16_async(qp + 64 * s);
+      qraw[s][1] = ssdk::gload16_async(qp + 64 * s + 16);
     }
   }
 
@@ -256,6 +255,15 @@ __global__ __launch_bounds__(NW * 64) void flash_fwd_fp8_kernel(Fp8Args a) {
   if (nstages > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {                      // the Q loads are older than every copy: landed
+    ssdk::settle(qraw[s][0]);
+    ssdk::settle(qraw[s][1]);
+    const ssdk::u32x4 lo = qraw[s][0], hi = qraw[s][1];
+    const bool ok = qrow < a.Lq;
+    qf[s] = ok ? i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]}
+               : i32x8{0, 0, 0, 0, 0, 0, 0, 0};
+  }
 
   for (int st = 0; st < nstages; ++st) {
     const bool ahead = st + 2 < nstages;

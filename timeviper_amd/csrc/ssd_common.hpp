@@ -43,6 +43,18 @@ __device__ __forceinline__ void glds4(const void* sbase, unsigned voff, unsigned
                "global_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
+// A 16-byte global load the compiler does not track: beside the hand-counted LDS-DMA copies hipcc waits
+// vmcnt(0) at the first use of any ordinary load result — inside the tile loop that drained the copy
+// queue at the top of every tile (the Q fragments are such results).  The caller's own counted wait covers
+// these loads (they are older than the copies it leaves in flight); `settle` pins the uses behind it.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4 gload16_async(const void* p) {
+  u32x4 r;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(p) : "memory");
+  return r;
+}
+__device__ __forceinline__ void settle(u32x4& r) { asm volatile("" : "+v"(r)); }
+
 __device__ __forceinline__ const void* uniform_ptr(const void* p) {
   const unsigned long long v = (unsigned long long)p;
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);

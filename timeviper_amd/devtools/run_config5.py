@@ -72,6 +72,6 @@ print(json.dumps({"config": "BASELINE configs[4]: Qwen2.5-7B geometry, DINOv2-L 
                   "same_argmax_as_bf16": bool(out.argmax() == ref.argmax()),
                   "logits_rel_err_of_bf16_with_one_ulp_noise_on_attention_outputs": round(err_noise, 5),
                   "note": "random-init weights make the last-token logits chaotic: one bf16 ulp of noise on the attention "
-                          "outputs moves them as much as the fp8 operands do; the fp8 kernel itself is checked against the "
-                          "oracle in tests/test_attention_fp8_gpu.py and tests/test_config5_gpu.py",
+                          "outputs moves them as much as the fp8 operands do; the fp8 kernel itself is checked against the CPU "
+                          "restatement in tests/test_attention_fp8_gpu.py and tests/test_config5_gpu.py",
                   "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2**30, 1)}))
