@@ -464,44 +464,50 @@ __global__ __launch_bounds__(512) void flash_fwd_stream_kernel(AttnArgs a) {
   u32x4 qn[KS];
   load_q(pair, qblk, qn);
 
-  if (D < 16 * KS) {                 // K chunks between head_dim and 16 KS: read by QK^T, never copied
-    const v8 z = {};
-    const int c0 = D / 8, nc = 2 * KS - c0;
-    for (int i = tid; i < NS * FA_KB * nc; i += NW * 64) {
-      const int row = (i / nc) % FA_KB, st = i / (nc * FA_KB), c = c0 + i % nc;
-      *reinterpret_cast<v8*>(sK + st * TILEB + row * ROWB + ((c ^ (row & 15)) << 4)) = z;
-    }
-  }
-
-  // ---- DMA pieces of this wave (as in flash_fwd_kernel) ----
-  int p_row[PPW];
-  unsigned p_off[PPW];
-  int p_chunk[PPW];
-#pragma unroll
-  for (int i = 0; i < PPW; ++i) {
-    const int pc = wave + NW * i;
-    const bool isK = pc < NPK;
-    const int row = 4 * (isK ? pc : pc - NPK) + (lane >> 4);
-    const int c = (lane & 15) ^ (isK ? (row & 15) : 4 * (row & 3));
-    p_row[i] = row;
-    p_chunk[i] = c;
-    p_off[i] = (unsigned)(((int64_t)row * (isK ? a.ksl : a.vsl) + c * 8) * (int)sizeof(T));
-  }
+  // ---- DMA pieces of this wave: K pieces wave + NW i (4 key rows each, i < KPW), as many of V; lane l
+  // carries row 4 piece + l/16, LDS slot l%16 (source chunk = slot ^ swizzle).  Lanes whose chunk lies
+  // past head_dim re-fetch chunk 0 of their row instead of being masked off: the pad slots then hold
+  // finite copies of real values — K pad columns meet Q columns that are exact zeros, V pad columns
+  // feed output rows that are never stored — and the issue path needs no EXEC juggling: per piece one
+  // scalar add for M0 and the copy itself (the masked, per-piece-addressed form cost ~300 cycles a
+  // piece and paced the whole QK^T phase: 2 100 cycles for 480 cycles of MFMA) ----
+  static_assert(NPK % NW == 0, "K pieces must divide over the waves");
+  constexpr int KPW = NPK / NW;
   const int dchunks = D / 8;
-  auto issue_piece = [&](const T* kpx, const T* vpx, int kt, int stage, int i) {
-    const int kbase = kt * FA_KB;
-    const int pc = wave + NW * i;
-    const bool isK = pc < NPK;           // compile-time per (wave-uniform) branch
-    const void* tb = ssdk::uniform_ptr(isK ? (const void*)(kpx + (int64_t)kbase * a.ksl)
-                                           : (const void*)(vpx + (int64_t)kbase * a.vsl));
-    const int left = a.Lk - kbase;
-    unsigned off = p_off[i];
-    if (left < FA_KB) {                  // last tile: rows past the end repeat the last key (masked later)
-      const int rr = min(p_row[i], left - 1);
-      off = (unsigned)(((int64_t)rr * (isK ? a.ksl : a.vsl) + p_chunk[i] * 8) * (int)sizeof(T));
+  int p_row[KPW];
+  unsigned offK[KPW], offV[KPW], coK[KPW], coV[KPW];
+#pragma unroll
+  for (int i = 0; i < KPW; ++i) {
+    const int row = 4 * (wave + NW * i) + (lane >> 4);
+    int ck = (lane & 15) ^ (row & 15), cv = (lane & 15) ^ (4 * (row & 3));
+    ck = ck < dchunks ? ck : 0;
+    cv = cv < dchunks ? cv : 0;
+    p_row[i] = row;
+    coK[i] = (unsigned)(ck * 8 * (int)sizeof(T));
+    coV[i] = (unsigned)(cv * 8 * (int)sizeof(T));
+    offK[i] = (unsigned)(row * (int)a.ksl * (int)sizeof(T)) + coK[i];
+    offV[i] = (unsigned)(row * (int)a.vsl * (int)sizeof(T)) + coV[i];
+  }
+  const unsigned m0_wave = (unsigned)(wave * 1024);
+  // tile `kt` of the sequence at kpx / vpx into ring stage `stage`: piece j (0..PPW-1; K first)
+  struct TileCopy { const unsigned char *tk, *tv; unsigned mk; int left; };
+  auto tile_copy = [&](const T* kpx, const T* vpx, int kt, int stage) {
+    TileCopy c;
+    c.tk = (const unsigned char*)(kpx + (int64_t)kt * FA_KB * a.ksl);
+    c.tv = (const unsigned char*)(vpx + (int64_t)kt * FA_KB * a.vsl);
+    c.mk = sK_off + (unsigned)(stage * TILEB) + m0_wave;
+    c.left = a.Lk - kt * FA_KB;                 // rows of this tile that exist
+    return c;
+  };
+  auto issue_piece = [&](const TileCopy& c, int j) {
+    const bool isK = j < KPW;                   // compile-time after unrolling
+    const int i = isK ? j : j - KPW;
+    unsigned off = isK ? offK[i] : offV[i];
+    if (c.left < FA_KB) {                       // last tile: rows past the end repeat the last key (masked later)
+      const int rr = min(p_row[i], c.left - 1);
+      off = (unsigned)(rr * (int)(isK ? a.ksl : a.vsl) * (int)sizeof(T)) + (isK ? coK[i] : coV[i]);
     }
-    const unsigned dst = (isK ? sK_off : sV_off) + (unsigned)(stage * TILEB + (isK ? pc : pc - NPK) * 1024);
-    if (p_chunk[i] < dchunks) ssdk::glds16(tb, off, __builtin_amdgcn_readfirstlane(dst));
+    ssdk::glds16(isK ? c.tk : c.tv, off, c.mk + (unsigned)(i * NW * 1024) + (isK ? 0u : (unsigned)(NS * TILEB)));
   };
 
   int k_rd[KS];
@@ -520,11 +526,13 @@ __global__ __launch_bounds__(512) void flash_fwd_stream_kernel(AttnArgs a) {
   const int ntiles = (a.Lk + FA_KB - 1) / FA_KB;       // >= 2 (launcher)
   const T* kp = k_of(pair);
   const T* vp = v_of(pair);
-  __syncthreads();                 // LDS zeroed before the first copy lands
+  {
+    const TileCopy c0 = tile_copy(kp, vp, 0, 0), c1 = tile_copy(kp, vp, 1, 1);
 #pragma unroll
-  for (int i = 0; i < PPW; ++i) issue_piece(kp, vp, 0, 0, i);
+    for (int j = 0; j < PPW; ++j) issue_piece(c0, j);
 #pragma unroll
-  for (int i = 0; i < PPW; ++i) issue_piece(kp, vp, 1, 1, i);
+    for (int j = 0; j < PPW; ++j) issue_piece(c1, j);
+  }
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
   __builtin_amdgcn_s_barrier();
   finish_q(qblk, qn, qf);
@@ -560,6 +568,7 @@ __global__ __launch_bounds__(512) void flash_fwd_stream_kernel(AttnArgs a) {
       const T* pv = wrap ? vp_n : vp;
       const int pf_kt = wrap ? kt + 2 - ntiles : kt + 2;
       const int pf_stage = stage == 0 ? 2 : stage - 1;
+      const TileCopy pf = tile_copy(pk, pv, pf_kt, pf_stage);
       if (kt == ntiles - 1 && has_next) load_q(pair_n, qblk_n, qn);   // older than this tile's copies
       const unsigned stage_off = (unsigned)(stage * TILEB);
       const unsigned cK = sK_off + stage_off, cV = sV_off + stage_off;
@@ -581,15 +590,17 @@ __global__ __launch_bounds__(512) void flash_fwd_stream_kernel(AttnArgs a) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           sacc[t] = Frag<T>::mfma(kf[t][ks], qf[ks], sacc[t]);
+          // the copies of tile kt+2 go out between the MFMAs (placing them between the exponentials
+          // of the softmax instead measured the same)
           constexpr int every = (KT * KS) / PPW > 0 ? (KT * KS) / PPW : 1;
           const int idx = t * KS + ks;
-          if (ahead && idx % every == 0 && idx / every < PPW) issue_piece(pk, pv, pf_kt, pf_stage, idx / every);
+          if (ahead && idx % every == 0 && idx / every < PPW) issue_piece(pf, idx / every);
         }
       }
       if (ahead) {
 #pragma unroll
         for (int i = (KT * KS) / ((KT * KS) / PPW > 0 ? (KT * KS) / PPW : 1); i < PPW; ++i)
-          issue_piece(pk, pv, pf_kt, pf_stage, i);
+          issue_piece(pf, i);
       }
       FSTAMP(0);
       typedef float f32x2 __attribute__((ext_vector_type(2)));
