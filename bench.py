@@ -167,7 +167,7 @@ class OpTimers:
 
     def all_rooflines(self, bytes_per_token):
         out = [self.scan_roofline(bytes_per_token),
-               self.mfma_roofline("attn_vit", "flash_fwd_kernel, ViT frames (non-causal, head_dim 72; useful FLOPs)"),
+               self.mfma_roofline("attn_vit", "flash_fwd_stream_kernel, ViT frames (non-causal, head_dim 72; useful FLOPs)"),
                self.mfma_roofline("attn_causal", "flash_fwd_kernel, causal GQA (LLM attention layers; useful FLOPs)")]
         return [o for o in out if o] + self.patch_rooflines()
 

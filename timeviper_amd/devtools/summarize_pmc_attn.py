@@ -25,12 +25,12 @@ for f in sorted(glob.glob("gpurun_out/pmc_attn*/p_counter_collection.csv")):
     for (name, _), cs in per.items():
         for c, v in cs.items():
             agg[name][c].append(v)
-out = ["# rocprofv3 --pmc passes on `python3 timeviper_amd/devtools/bench_ops.py --ops attn,patch` (round 2; the attention and patch-embed kernels are unchanged since the end of round 1)\n",
+out = ["# rocprofv3 --pmc passes on `python3 timeviper_amd/devtools/bench_ops.py --ops attn,patch` (end of round 2)\n",
        "One counter set per pass (`timeviper_amd/devtools/pmc_attn.sh`, no tracing options); mean per launch, summed over "
        "the rows rocprofv3 reports per dispatch (`timeviper_amd/devtools/summarize_pmc_attn.py`). Kernels: "
        "`flash_fwd_kernel<bf16,8,4,8,3>` = causal GQA attention, L = 32 868, 40/8 heads x 128, 96-key tiles; "
-       "`flash_fwd_kernel<bf16,5,3,8,3>` = SigLIP ViT attention, 256 frames x 729 tokens x 16 heads x 72 (XCD-ordered "
-       "grid); `patch_embed_kernel<bf16,packed,7>` = 256 frames x 384 px. Durations are the event timings of the same "
+       "`flash_fwd_stream_kernel<bf16,5,3,3>` = SigLIP ViT attention, 256 frames x 729 tokens x 16 heads x 72 (one "
+       "resident work-group per CU streams the query blocks of its XCD's (frame, head) pairs); `patch_embed_kernel<bf16,packed,7>` = 256 frames x 384 px. Durations are the event timings of the same "
        "tool without the profiler.\n"]
 for name in dur:
     m = {c: sum(v) / len(v) for c, v in agg[name].items()}
