@@ -337,6 +337,33 @@ def test_flash_attention(K, dtype, B, Lq, Lk, Hq, Hkv, D, causal):
     close(lse, lse_ref, 1e-3, 2e-3, "lse")
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,Lq,Lk,Hq,Hkv,D", [
+    (24, 729, 729, 16, 16, 72),      # SigLIP frames: 144 query blocks per XCD for 32 resident work-groups
+    (20, 300, 500, 8, 4, 64),        # Lq != Lk, GQA, 4 k-steps
+    (11, 257, 257, 16, 16, 88),      # InternVideo2 heads (6 k-steps), 3 ragged key tiles
+    (7, 600, 97, 16, 16, 72),        # two key tiles, the second holds ONE key
+    (13, 300, 300, 13, 13, 72),      # 169 (batch, head) pairs padded to 176: the last XCD's range ends early
+])
+def test_flash_attention_streaming(K, dtype, B, Lq, Lk, Hq, Hkv, D):
+    """Many short sequences: `flash_fwd_stream_kernel` (one resident work-group per CU walks the query blocks;
+    K/V ring, Q prefetch and O stores cross the block seams).  q / k / v are strided views of a packed
+    projection, as in the ViT blocks (siglip.py Attention)."""
+    g = torch.Generator().manual_seed(Lq * 5 + Lk + D)
+    qkv = torch.randn(B, max(Lq, Lk), Hq + 2 * Hkv, D, generator=g).to(dtype).to(DEV)
+    q, k, v = qkv[:, :Lq, :Hq], qkv[:, :Lk, Hq:Hq + Hkv], qkv[:, :Lk, Hq + Hkv:]
+    # a few dominant keys in late tiles: the running maximum moves after the first tile
+    k[:, Lk - 1] *= 4.0
+    k[:, Lk // 2] *= 3.0
+    o_ref, lse_ref = R.attention_ref(q.float().cpu(), k.float().cpu(), v.float().cpu(), False)
+    o, lse = K.flash_attn_func(q, k, v, causal=False, return_lse=True)
+    rt, at = (2e-2, 1e-2) if dtype == torch.bfloat16 else (4e-3, 2e-3)
+    close(o, o_ref, rt, at, "o")
+    close(lse, lse_ref, 1e-3, 2e-3, "lse")
+    o2 = K.flash_attn_func(q, k, v, causal=False)                  # same bits on a second call (no stale ring state)
+    assert torch.equal(o, o2)
+
+
 def test_flash_attention_spiked_max(K):
     """force large running-max jumps at chosen tiles (guide rule 26)."""
     g = torch.Generator().manual_seed(0)
