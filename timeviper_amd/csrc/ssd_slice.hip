@@ -364,18 +364,24 @@ __global__ __launch_bounds__(Roles<PW>::NWAVES * 64) void ssd_slice_kernel(Slice
     // ct of this wave adds 32 ct bytes.  (A tile past the slice width reads finite neighbouring data —
     // the x slots carry a guard — and its results are never written.)
     const int trx = ((8 * kq + q4) * PW + 4 * p4) * 2 + wave * NC * 32;
-    const int trd = ((4 * kq + q4) * PW + 4 * p4) * 2 + wave * NC * 32;
-    unsigned ypk[NC][4][2] = {};
-    auto write_y = [&](int c) {     // y tile of chunk c: ds_write_b16 / _d16_hi of the packed halves
+    const int trd = (lc * PW + 4 * kq) * 2 + wave * NC * 32;     // x in the (transposed) y accumulator layout
+    // The y accumulators are kept TRANSPOSED (the MFMA operands of Yoff and Ydiag swapped: same registers,
+    // same products, same k order): a lane then holds FOUR CONSECUTIVE COLUMNS 16 tile + 4 kq + r of ONE token
+    // 16 ti + lc — 8 contiguous bytes of the [t][PW] y tile, one ds_write_b64 per (tile, ti).  (With tokens on the
+    // registers it took four ds_write_b16 each: 32 LDS writes per step, 680 of a slice-wave's 3 950 cycles.)
+    typedef __attribute__((ext_vector_type(2))) unsigned ypk_t;
+    ypk_t ypk[NC][4] = {};
+    bool cvalid[NC];                // this lane's four columns exist (PW is a multiple of 8)
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct) cvalid[ct] = 16 * (wave * NC + ct) + 4 * kq < PW;
+    auto write_y = [&](int c) {     // y tile of chunk c
 #pragma unroll
       for (int ct = 0; ct < NC; ++ct) {
-        if (!pvalid[ct]) continue;
+        if (!cvalid[ct]) continue;
 #pragma unroll
         for (int ti = 0; ti < 4; ++ti) {
-          const unsigned ya = lds_lane_addr(sm.yt[c & 1] + (16 * ti + 4 * kq) * PW + pcol[ct]);
-          asm volatile("ds_write_b16 %0, %1\n\tds_write_b16_d16_hi %0, %1 offset:%3\n\t"
-                       "ds_write_b16 %0, %2 offset:%4\n\tds_write_b16_d16_hi %0, %2 offset:%5"
-                       :: "v"(ya), "v"(ypk[ct][ti][0]), "v"(ypk[ct][ti][1]), "n"(PW * 2), "n"(PW * 4), "n"(PW * 6) : "memory");
+          const unsigned ya = lds_lane_addr(sm.yt[c & 1] + (16 * ti + lc) * PW + 16 * (wave * NC + ct) + 4 * kq);
+          asm volatile("ds_write_b64 %0, %1" :: "v"(ya), "v"(ypk[ct][ti]) : "memory");
         }
       }
     };
@@ -433,7 +439,7 @@ __global__ __launch_bounds__(Roles<PW>::NWAVES * 64) void ssd_slice_kernel(Slice
 #pragma unroll
         for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
-          for (int ct = 0; ct < NC; ++ct) yo[ct][ti] = mfma16(cf[ti], sbq[ct], yo[ct][ti]);
+          for (int ct = 0; ct < NC; ++ct) yo[ct][ti] = mfma16(sbq[ct], cf[ti], yo[ct][ti]);   // Yoff^T: [column][token]
         if (SDBG(a, 32)) return;
         const f32x2 dl2 = {dl, dl};
 #pragma unroll
@@ -481,6 +487,7 @@ __global__ __launch_bounds__(Roles<PW>::NWAVES * 64) void ssd_slice_kernel(Slice
       }
       const float dl = sm.dl[vb][0];
       read_b2(0, bq[0]);
+      PSTAMP(6);
       if (c > 0) write_y(c - 1);        // previous chunk's results, under the reads just issued
       __builtin_amdgcn_sched_barrier(0);
       PSTAMP(0);
@@ -524,13 +531,13 @@ __global__ __launch_bounds__(Roles<PW>::NWAVES * 64) void ssd_slice_kernel(Slice
       bf16x8 mf[NFRAG];
 #pragma unroll
       for (int f = 0; f < NFRAG; ++f) mf[f] = ld8(Mf + f * 1024 + lane * 16);
-      f32x4 ev[4];
-      bf16x4 xv[NC][4];
+      float ev[4];                    // exp(cs_t) of this lane's token 16 ti + lc
+      bf16x4 xv[NC][4];               // x[t][16 tile + 4 kq + 0..3]: a plain 8-byte row read
 #pragma unroll
       for (int ti = 0; ti < 4; ++ti) {
-        ev[ti] = *(const f32x4*)(&sm.ecs[vb][16 * ti + 4 * kq]);
+        ev[ti] = sm.ecs[vb][16 * ti + lc];
 #pragma unroll
-        for (int ct = 0; ct < NC; ++ct) xv[ct][ti] = tr4(xt + trd + 32 * ct + ti * (16 * PW * 2));
+        for (int ct = 0; ct < NC; ++ct) xv[ct][ti] = *(const bf16x4*)(xt + trd + 32 * ct + ti * (16 * PW * 2));
       }
       if (!RL::WIDE) {       // (wide: the raw fragments were read at the top of the step)
 #pragma unroll
@@ -554,15 +561,15 @@ __global__ __launch_bounds__(Roles<PW>::NWAVES * 64) void ssd_slice_kernel(Slice
           for (int ti = 0; ti < 4; ++ti) {
             const unsigned x01 = __builtin_bit_cast(u32x2, xv[ct][ti])[0], x23 = __builtin_bit_cast(u32x2, xv[ct][ti])[1];
             f32x2 y0 = {yo[ct][ti][0], yo[ct][ti][1]}, y1 = {yo[ct][ti][2], yo[ct][ti][3]};
-            y0 = __builtin_elementwise_fma(y0, f32x2{ev[ti][0], ev[ti][1]}, dh2 * f32x2{bf16_lo(x01), bf16_hi(x01)});
-            y1 = __builtin_elementwise_fma(y1, f32x2{ev[ti][2], ev[ti][3]}, dh2 * f32x2{bf16_lo(x23), bf16_hi(x23)});
+            y0 = __builtin_elementwise_fma(y0, f32x2{ev[ti], ev[ti]}, dh2 * f32x2{bf16_lo(x01), bf16_hi(x01)});
+            y1 = __builtin_elementwise_fma(y1, f32x2{ev[ti], ev[ti]}, dh2 * f32x2{bf16_lo(x23), bf16_hi(x23)});
             yo[ct][ti] = f32x4{y0[0], y0[1], y1[0], y1[1]};
           }
 #pragma unroll
           for (int ti = 0; ti < 4; ++ti) {
             const int f0 = ti == 0 ? 0 : ti == 1 ? 1 : ti == 2 ? 2 : 4;
-            yo[ct][ti] = mfma16(mf[f0], xf[0], yo[ct][ti]);
-            if (ti >= 2) yo[ct][ti] = mfma16(mf[f0 + 1], xf[1], yo[ct][ti]);
+            yo[ct][ti] = mfma16(xf[0], mf[f0], yo[ct][ti]);
+            if (ti >= 2) yo[ct][ti] = mfma16(xf[1], mf[f0 + 1], yo[ct][ti]);
           }
           // packed bf16 results stay in registers across the barrier; they are written to the y
           // tile at the start of the next step, beside that step's first fragment reads
@@ -570,8 +577,7 @@ __global__ __launch_bounds__(Roles<PW>::NWAVES * 64) void ssd_slice_kernel(Slice
           for (int ti = 0; ti < 4; ++ti) {
             typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
             const bf16x2 p01 = {(bf16_t)yo[ct][ti][0], (bf16_t)yo[ct][ti][1]}, p23 = {(bf16_t)yo[ct][ti][2], (bf16_t)yo[ct][ti][3]};
-            ypk[ct][ti][0] = __builtin_bit_cast(unsigned, p01);
-            ypk[ct][ti][1] = __builtin_bit_cast(unsigned, p23);
+            ypk[ct][ti] = ypk_t{__builtin_bit_cast(unsigned, p01), __builtin_bit_cast(unsigned, p23)};
           }
         }
       }

@@ -45,7 +45,7 @@ def main():
               f"parked {wait/total:6.1%}")
 
 
-    names = ["first reads", "quarter 0", "quarter 1", "quarter 2", "quarter 3", "Ydiag + epilogue", "-", "barrier + loop"]
+    names = ["y tile writes (prev. chunk)", "quarter 0", "quarter 1", "quarter 2", "quarter 3", "Ydiag + epilogue", "first reads issued", "barrier + loop"]
     print("slice-wave 0 phases (cycles/step): " + "  ".join(f"{n} {out[32 + i] / steps:.0f}" for i, n in enumerate(names) if n != "-"))
 
 
