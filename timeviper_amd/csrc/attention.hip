@@ -425,7 +425,6 @@ __global__ __launch_bounds__(512) void flash_fwd_stream_kernel(AttnArgs a) {
   constexpr int PPW = 2 * NPK / NW;
   static_assert(2 * NPK % NW == 0, "pieces must divide over the waves");
   extern __shared__ __attribute__((aligned(16))) unsigned char fa_smem[];
-  unsigned char* const sK = fa_smem;
   const unsigned sK_off = (unsigned)(uintptr_t)(lds_u8*)fa_smem, sV_off = sK_off + NS * TILEB;
 
   const int tid = threadIdx.x;
