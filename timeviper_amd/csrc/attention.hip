@@ -536,6 +536,10 @@ __global__ __launch_bounds__(512) void flash_fwd_stream_kernel(AttnArgs a) {
   __builtin_amdgcn_s_barrier();
   finish_q(qblk, qn, qf);
 
+  // the second-dispatched half of the work-group loses every VALU arbitration to the older half (priority, then
+  // age): one static priority bump for it, no per-phase flips (-0.8 % here; the causal and fp8 kernels measured
+  // 0.5 - 1 % SLOWER with it and do not have it)
+  if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
   int stage = 0;                   // ring stage of the current tile
 #ifdef TV_FA_STAMP
   const bool st_on = blockIdx.x == 0 && (wave == 0 || wave == 4);
