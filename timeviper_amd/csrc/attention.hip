@@ -76,6 +76,7 @@ struct AttnArgs {
   int causal;
   int nqb, nb;       // nqb > 0: 1-D XCD-aware grid, nqb query blocks per (batch, head), nb batches; 0: 3-D grid
   int ppx;           // streaming kernel: (batch, head) pairs per XCD
+  int o16;           // streaming kernel: o rows are 16-byte aligned (wide epilogue stores)
 };
 
 // KS = ceil(D/16) k-steps of QK^T, DT = ceil(D/32) d-tiles of PV, NW waves per workgroup.
@@ -698,20 +699,39 @@ __global__ __launch_bounds__(512) void flash_fwd_stream_kernel(AttnArgs a) {
       const int qrow = qblk * QB + wave * FA_QW + r;
       const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
       const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
-      if (qrow < a.Lq) {
-        T* op = (T*)a.o + (int64_t)b * a.osb + (int64_t)qrow * a.osl + (int64_t)h * a.osh;
+      // A lane holds 4 output columns (8 bytes) per (d-tile, group g): columns 32 dt + 8 g + 4 hh .. + 3.  The halves
+      // hh = 0 / 1 of a lane pair (r, r + 32) own the two halves of 8 consecutive columns, so one
+      // v_permlane32_swap per dword gives each lane 16 contiguous bytes (groups g, g + 1 -> the lower lane
+      // stores columns 16 gp .. + 7, the upper lane the next 8): half the store instructions — the epilogue of
+      // a block is store-ISSUE bound.  Needs 16-byte aligned rows (a.o16); the last lone group stays 8 bytes.
+      typedef unsigned u32x2s __attribute__((ext_vector_type(2)));
+      typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+      T* op = (T*)a.o + (int64_t)b * a.osb + (int64_t)min(qrow, a.Lq - 1) * a.osl + (int64_t)h * a.osh;
+      const bool rowok = qrow < a.Lq;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
+      for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int d0 = dt * 32 + 8 * g + 4 * hh;
-            if (d0 < D) {
-              v4 pk4;
+        for (int gp = 0; gp < 2; ++gp) {
+          const int d_lo = dt * 32 + 16 * gp;          // first column of the pair of groups
+          if (d_lo >= D) continue;
+          v4 pa, pb;
 #pragma unroll
-              for (int j = 0; j < 4; ++j) pk4[j] = from_f32<T>(oacc[dt][4 * g + j] * inv);
-              *(v4*)(op + d0) = pk4;
-            }
+          for (int j = 0; j < 4; ++j) {
+            pa[j] = from_f32<T>(oacc[dt][4 * (2 * gp) + j] * inv);
+            pb[j] = from_f32<T>(oacc[dt][4 * (2 * gp + 1) + j] * inv);
           }
+          if (a.o16 && d_lo + 8 < D) {                 // (wave-uniform)
+            const u32x2s ua = __builtin_bit_cast(u32x2s, pa), ub = __builtin_bit_cast(u32x2s, pb);
+            const auto s0 = __builtin_amdgcn_permlane32_swap(ua[0], ub[0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(ua[1], ub[1], false, false);
+            const u32x4s w = {s0[0], s1[0], s0[1], s1[1]};
+            if (rowok) *(u32x4s*)(op + d_lo + 8 * hh) = w;
+          } else {
+            if (rowok) *(v4*)(op + d_lo + 4 * hh) = pa;
+            if (rowok && d_lo + 8 + 4 * hh < D) *(v4*)(op + d_lo + 8 + 4 * hh) = pb;
+          }
+        }
+      if (rowok) {
         if (a.lse && hh == 0) {
           const float lse = l_tot > 0.f ? (m_run * 0.6931471805599453f + logf(l_tot)) : -INFINITY;
           a.lse[((int64_t)b * a.Hq + h) * a.Lq + qrow] = lse;
@@ -757,6 +777,7 @@ int launch_fa_d(const AttnArgs& a, int B, hipStream_t st) {
         ax.nb = B;
         const int64_t pairs = ((int64_t)B * a.Hq + 7) / 8 * 8;
         ax.ppx = (int)(pairs / 8);
+        ax.o16 = ((uintptr_t)a.o % 16 == 0 && a.osb % 8 == 0 && a.osl % 8 == 0 && a.osh % 8 == 0) ? 1 : 0;
         static const int stream_ = [] { const char* v = getenv("TV_FA_STREAM"); return v ? atoi(v) : 1; }();
         const int64_t slots = (int64_t)ax.ppx * nqb;          // query blocks per XCD
         if constexpr (KS > 6) {                                // head_dim 128: the second Q set does not fit the registers
