@@ -77,6 +77,20 @@ int tv_causal_conv1d_xbc_fwd(const void* x, const void* weight, const void* bias
                              int64_t x_stride_l, int dtype, int silu,
                              void* stream);
 
+/* The same with one more output: the causal part of C.B^T of every (64-token
+ * chunk, group) — the G_{l,s} = C_l . B_s of the reference's intra-chunk term
+ * (modeling_nano.py:800-811) — in the MFMA-fragment order tv_ssd_scan_cb_fwd
+ * reads (6 fragments of 512 bf16 per chunk and group; tv_ssd_cb_bytes() bytes).
+ * The B / C tiles are multiplied while they are still on the chip, so the scan
+ * does not read B and C back for it.  bf16, d_state 128 only.                */
+size_t tv_ssd_cb_bytes(int batch, int seqlen, int ngroups);
+int tv_causal_conv1d_xbc_cb_fwd(const void* x, const void* weight, const void* bias,
+                                const void* halo, void* y_x, void* y_b, void* y_c,
+                                void* cb, int batch, int seqlen, int d_inner,
+                                int ngroups, int dstate, int kernel,
+                                int64_t x_stride_b, int64_t x_stride_l, int dtype,
+                                int silu, void* stream);
+
 /* Single-token decode step, replaces causal_conv1d_update (:495-501).
  * conv_state (B,C,K) contiguous, updated in place (shift left, append x).   */
 int tv_causal_conv1d_update(const void* x, void* conv_state, const void* weight,
@@ -166,6 +180,23 @@ int tv_ssd_scan_fwd(const void* x, const void* dt, const void* A,
                     int dtype, int dt_softplus, float dt_min, float dt_max,
                     int group_map, void* workspace, size_t workspace_bytes,
                     void* stream);
+/* tv_ssd_scan_fwd with the C.B^T fragments supplied by the caller (`cb`: the
+ * output of tv_causal_conv1d_xbc_cb_fwd on the same Bm / Cm, or NULL: computed
+ * here by a pre-pass over Bm and Cm as in tv_ssd_scan_fwd).  Kernels that do
+ * not use the fragments (fp32, other d_state) ignore them.                   */
+int tv_ssd_scan_cb_fwd(const void* x, const void* dt, const void* A,
+                       const void* Bm, const void* Cm, const void* cb,
+                       const void* D, const void* dt_bias,
+                       const void* init_state, void* y, void* final_state,
+                       void* total_decay, int batch, int seqlen, int nheads,
+                       int headdim, int ngroups, int dstate, int64_t x_stride_b,
+                       int64_t x_stride_l, int64_t dt_stride_b,
+                       int64_t dt_stride_l, int64_t b_stride_b,
+                       int64_t b_stride_l, int64_t b_stride_g, int64_t c_stride_b,
+                       int64_t c_stride_l, int64_t c_stride_g, int64_t y_stride_b,
+                       int64_t y_stride_l, int dtype, int dt_softplus, float dt_min,
+                       float dt_max, int group_map, void* workspace,
+                       size_t workspace_bytes, void* stream);
 
 /* Carried-in state correction ("sequence sharding"; the Y_off term of
  * modeling_nano.py:833-836 with the decay taken from the range start): a shard — another GPU's
@@ -173,8 +204,9 @@ int tv_ssd_scan_fwd(const void* x, const void* dt, const void* A,
  * tv_ssd_scan_fwd; once the state entering it is known its outputs are completed in place,
  *   y_t += exp(sum_{j<=t} dt_j A_h) * C_t . state_in[h]        (dt discretised as in tv_ssd_scan_fwd)
  * y (B,L,H,P) `dtype`, read-modify-write; dt (B,L,H) raw; Cm (B,L,G,N) with a group stride;
- * state_in (B,H,P,N) fp32 contiguous.  The factor reaches exactly 0 in fp32 after the head's
- * decay horizon and the kernel stops there, so the cost is that horizon, not L.
+ * state_in (B,H,P,N) fp32 contiguous.  Past a head's decay horizon (factor < 2^-48: the term is
+ * under 4e-15 of |C_t . state_in|, far below the fp32 rounding of the sum) the kernel stops, so the
+ * cost is that horizon, not L.
  * bf16, d_state 128, headdim % 8 == 0 (<= 128).  workspace:
  * tv_ssd_state_correction_workspace_bytes() bytes (per-chunk log-decays and their prefix). */
 size_t tv_ssd_state_correction_workspace_bytes(int batch, int seqlen, int nheads);

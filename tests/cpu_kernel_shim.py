@@ -10,13 +10,14 @@ from oracle import ops as R
 from oracle import vit as RV
 
 
-def _conv_xbc(xBC, weight, bias, d_inner, ngroups, dstate, activation="silu", halo=None):
+def _conv_xbc(xBC, weight, bias, d_inner, ngroups, dstate, activation="silu", halo=None, return_cb=False):
     y = R.causal_conv1d_ref(xBC.float(), weight.float().reshape(xBC.shape[-1], -1),
                             None if bias is None else bias.float(), activation,
                             None if halo is None else halo.float()).to(xBC.dtype)
     B, L, _ = xBC.shape
     x, Bm, Cm = y.split([d_inner, ngroups * dstate, ngroups * dstate], dim=-1)
-    return x.contiguous(), Bm.reshape(B, L, ngroups, dstate), Cm.reshape(B, L, ngroups, dstate)
+    out = (x.contiguous(), Bm.reshape(B, L, ngroups, dstate), Cm.reshape(B, L, ngroups, dstate))
+    return out + (None,) if return_cb else out       # the C.B^T fragments are a device-side detail
 
 
 def _conv_fn(x, weight, bias=None, activation=None, halo=None, **kw):

@@ -149,7 +149,7 @@ def run_scan(K, x, dt, A, Bm, Cm, D, dt_bias, **kw):
                                        return_final_states=True, return_total_decay=True, **kw)
 
 
-@pytest.mark.parametrize("impl", [1, 0, 2, 3, 4])
+@pytest.mark.parametrize("impl", [1, 0, 2, 3, 4, 5])
 @pytest.mark.parametrize("dtype,B,L,H,P,G,N", [
     (torch.float32, 1, 1024, 32, 64, 1, 16),      # BASELINE config 1
     (torch.float32, 2, 77, 8, 8, 2, 16),
@@ -194,7 +194,7 @@ def test_ssd_scan_initial_state_and_sharding(K, dtype, H, P, G, N):
     close(f1, fin_ref, rt, at)
 
 
-@pytest.mark.parametrize("impl", [2, 3, 4])
+@pytest.mark.parametrize("impl", [2, 3, 4, 5])
 @pytest.mark.parametrize("B,L,H,P,G", [(1, 1000, 16, 80, 8), (2, 449, 8, 64, 2), (1, 64, 4, 48, 1),
                                        (1, 2049, 8, 80, 4), (1, 130, 4, 128, 2), (1, 65, 6, 24, 3),
                                        (1, 5000, 8, 80, 8), (1, 4100, 4, 72, 2), (2, 2500, 4, 56, 1)])
@@ -625,6 +625,44 @@ def test_zero_length_inputs(K):
     full = K.causal_conv1d_xbc(xs, w, b, H * P, G, N)[0]
     one = K.causal_conv1d_xbc(xs[:, 3:], w, b, H * P, G, N, halo=xs[:, :3].contiguous())[0]
     assert torch.equal(one, full[:, 3:])
+
+
+@pytest.mark.parametrize("Bsz,L,H,P,G", [(1, 300, 16, 80, 2), (2, 129, 8, 64, 8), (1, 2300, 8, 80, 8), (1, 64, 4, 40, 1)])
+def test_conv_xbc_with_cb_fragments(K, Bsz, L, H, P, G):
+    """tv_causal_conv1d_xbc_cb_fwd: x, B, C bit-identical to the plain conv (with and without a shard halo), and the
+    scan fed with its C.B^T fragments bit-identical to the scan that recomputes them in its pre-pass — same bf16
+    operands, same MFMA order (the G_{l,s} = C_l . B_s of modeling_nano.py:800-811)."""
+    N = 128
+    g = torch.Generator().manual_seed(L + H)
+    conv_dim = H * P + 2 * G * N
+    xs = torch.randn(Bsz, L + 3, conv_dim, generator=g).bfloat16().to(DEV)
+    w, b = torch.randn(conv_dim, 4, generator=g).bfloat16().to(DEV), torch.randn(conv_dim, generator=g).bfloat16().to(DEV)
+    for halo in (None, xs[:, :3].contiguous()):
+        xin = xs[:, 3:]
+        x0, B0, C0 = K.causal_conv1d_xbc(xin, w, b, H * P, G, N, halo=halo)
+        x1, B1, C1, cb = K.causal_conv1d_xbc(xin, w, b, H * P, G, N, halo=halo, return_cb=True)
+        assert cb is not None and cb.dtype == torch.bfloat16
+        assert torch.equal(x0, x1) and torch.equal(B0, B1) and torch.equal(C0, C1)
+        assert B1.stride(1) == N and C1.stride(1) == N        # group-major storage
+        dt = (torch.randn(Bsz, L, H, generator=g) * 0.5).bfloat16().to(DEV)
+        A = -(torch.rand(H, generator=g) * 15 + 1).to(DEV)
+        D, dtb = torch.ones(H, device=DEV), torch.full((H,), -2.0, device=DEV)
+        kw = dict(chunk_size=64, D=D, dt_bias=dtb, dt_softplus=True, return_final_states=True)
+        for impl in (3, 4):
+            K.ssd_scan_set_impl(impl)
+            try:
+                ya, fa = K.mamba_chunk_scan_combined(x0.view(Bsz, L, H, P), dt, A, B0, C0, **kw)
+                yb, fb = K.mamba_chunk_scan_combined(x1.view(Bsz, L, H, P), dt, A, B1, C1, cb=cb, **kw)
+            finally:
+                K.ssd_scan_set_impl(0)
+            assert torch.equal(ya, yb) and torch.equal(fa, fb), f"impl {impl}"
+    # the fragments are refused for other shapes than the ones they were made for
+    with pytest.raises(Exception):
+        K.mamba_chunk_scan_combined(x0.view(Bsz, L, H, P), dt, A, B0, C0, cb=cb[:-512], **kw)
+    # fp32 / other d_state: no fragments, plain path
+    xf = torch.randn(1, 50, 8 * 16 + 2 * 2 * 16, device=DEV)
+    out = K.causal_conv1d_xbc(xf, torch.randn(xf.shape[-1], 4, device=DEV), None, 8 * 16, 2, 16, return_cb=True)
+    assert out[3] is None
 
 
 # ---------------------------------------------------------------- ToMe (V3)

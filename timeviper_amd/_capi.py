@@ -25,6 +25,8 @@ SIGNATURES = {
     "tv_build_id": (C.c_char_p, []),
     "tv_causal_conv1d_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _l, _l, _l, _l, _i, _i, _p]),
     "tv_causal_conv1d_xbc_fwd": (_i, [_p] * 7 + [_i] * 6 + [_l, _l, _i, _i, _p]),
+    "tv_ssd_cb_bytes": (_z, [_i] * 3),
+    "tv_causal_conv1d_xbc_cb_fwd": (_i, [_p] * 8 + [_i] * 6 + [_l, _l, _i, _i, _p]),
     "tv_causal_conv1d_update": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "tv_rmsnorm_fwd": (_i, [_p, _p, _p, _p, _p, _l, _i, _l, _l, _l, _l, _f, _i, _i, _p]),
     "tv_layernorm_fwd": (_i, [_p] * 7 + [_l, _i, _l, _l, _l, _l, _f, _i, _p]),
@@ -33,6 +35,7 @@ SIGNATURES = {
     "tv_rmsnorm_gated_fwd": (_i, [_p, _p, _p, _p, _l, _i, _i, _l, _l, _l, _f, _i, _i, _p]),
     "tv_ssd_scan_workspace_bytes": (_z, [_i] * 7),
     "tv_ssd_scan_fwd": (_i, [_p] * 11 + [_i] * 6 + [_l] * 12 + [_i, _i, _f, _f, _i, _p, _z, _p]),
+    "tv_ssd_scan_cb_fwd": (_i, [_p] * 12 + [_i] * 6 + [_l] * 12 + [_i, _i, _f, _f, _i, _p, _z, _p]),
     "tv_ssd_state_correction_workspace_bytes": (_z, [_i] * 3),
     "tv_ssd_state_correction": (_i, [_p] * 6 + [_i] * 6 + [_l] * 7 + [_i, _i, _f, _f, _i, _p, _z, _p]),
     "tv_ssd_scan_set_impl": (None, [_i]),
@@ -61,7 +64,7 @@ class TimeViperHipError(RuntimeError):
     pass
 
 
-ABI_VERSION = 5      # tv_abi_version() of the library these SIGNATURES describe (csrc/capi.cpp)
+ABI_VERSION = 6      # tv_abi_version() of the library these SIGNATURES describe (csrc/capi.cpp)
 
 
 def lib_path() -> Path:

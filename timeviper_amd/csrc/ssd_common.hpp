@@ -36,6 +36,19 @@ __device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigne
                "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
+// Four 1 KiB pieces with ONE M0 set-up: piece j copies *(sbase + vj + 1024 j) to LDS[lds_dst + 1024 j + 16*lane].
+// The instruction offset moves the global and the LDS address alike, so the caller passes vj = (source offset of
+// piece j) - 1024 j (never negative for rows of >= 256 bytes taken in order).
+__device__ __forceinline__ void glds16x4(const void* sbase, unsigned v0, unsigned v1, unsigned v2, unsigned v3,
+                                         unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %1, %5\n\t"
+               "global_load_lds_dwordx4 %2, %5 offset:1024\n\t"
+               "global_load_lds_dwordx4 %3, %5 offset:2048\n\t"
+               "global_load_lds_dwordx4 %4, %5 offset:3072\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(sbase), "s"(lds_dst) : "memory");
+}
 // one dword per lane: LDS[lds_dst + 4*lane]
 __device__ __forceinline__ void glds4(const void* sbase, unsigned voff, unsigned lds_dst) {
   unsigned keep;

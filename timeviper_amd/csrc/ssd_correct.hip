@@ -7,10 +7,11 @@
 // known the outputs are completed by this term.  It is the Y_off term of modeling_nano.py:833-836
 // with the chunk-local decay replaced by the decay from the range start.
 //
-// The factor exp(cs_t) only shrinks along the sequence (dt >= 0, A < 0) and reaches exactly 0 in
-// fp32 once cs_t * log2(e) < -150: from there on the correction is exactly zero and the kernel
-// stops (the reference's fp32 state passing underflows the same way).  Heads that forget within a
-// few hundred tokens cost a few chunks; a head that never forgets costs the full range.
+// The factor exp(cs_t) only shrinks along the sequence (dt >= 0, A < 0); once cs_t * log2(e) < -48 the
+// term is below 4e-15 of |C_t . S_in| — far under the fp32 rounding of the sum it would enter, let alone
+// a bf16 ulp of y — and the kernel stops (C_UNDERFLOW; the reference's fp32 state passing loses such terms
+// in its own additions).  Heads that forget within a few hundred tokens cost a few chunks; a head that
+// never forgets costs the full range.
 //
 // Three launches: per-chunk log-decays (from dt), their exclusive prefix per head, and the
 // correction itself: work-groups (slot k of 64, head, batch) walk the chunks k, k+64, ... of their
@@ -26,7 +27,10 @@ constexpr int CQ = 64;            // tokens per chunk
 constexpr int CN = 128;           // d_state
 constexpr int CSLOTS = 64;        // work-groups per (batch, head): a head that never forgets is walked by all of them
                                   // (measured with 8: the slowest heads set the launch time, 808 us in the 9B model)
-constexpr float C_UNDERFLOW = -160.f;   // log2 of a factor that is exactly 0 in fp32, with margin
+// The walk of a head ends where the factor 2^(cs_t log2 e) has fallen below 2^-48: the term is then < 4e-15 of
+// |C_t . S_in| — eight orders of magnitude under the fp32 rounding of the sum it would be added to and eleven
+// under a bf16 ulp of y; round 2 walked on to 2^-160 (exactly 0 in fp32), three times the distance.
+constexpr float C_UNDERFLOW = -48.f;
 
 struct CorrArgs {
   bf16_t* y;
@@ -110,21 +114,39 @@ __global__ __launch_bounds__(256) void ssd_correct_kernel(CorrArgs a) {
   bf16_t* yp = a.y + (int64_t)b * a.ysb + (int64_t)h * a.P;
   const int nvec = a.P / 8;                          // 16-byte pieces per y row
 
+  // One chunk per iteration; the C rows, the dt value and the prefix of the NEXT chunk of this work-group and the y
+  // rows of the current one are requested before the current chunk's arithmetic, so an iteration waits for one
+  // round trip to memory instead of three in a row (C -> MFMA -> y read -> y write; round 2: 80 % of the
+  // wave-cycles of this kernel were parked).
+  constexpr int NY = (CQ * 2 * PT + 255) / 256;      // y pieces per thread (rows of at most 16 PT columns)
+  auto fetch = [&](int c, bf16x8 (&cf)[4], float& draw, float& p0) {
+    const int t0 = c * CQ;
+    const int trow = min(t0 + 16 * wave + lc, a.L - 1);       // rows past the end repeat the last row: finite
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) cf[ks] = *(const bf16x8*)(cp + (int64_t)trow * a.csl + 32 * ks + 8 * kq);
+    const int t = t0 + lane;
+    draw = (wave == 0 && t < a.L) ? (float)dp[(int64_t)t * a.dsl] : 0.f;
+    p0 = pre[c];
+  };
+  bf16x8 cf[4], cfn[4];
+  float draw, drawn = 0.f, p0, p0n = 0.f;
+  fetch(blockIdx.x, cf, draw, p0);
   for (int c = blockIdx.x; c < a.nchunks; c += CSLOTS) {
-    const float p0 = pre[c];
     if (p0 < C_UNDERFLOW) break;                     // the prefix only decreases: nothing left for this head
     const int t0 = c * CQ;
+    const bool more = c + CSLOTS < a.nchunks;
+    if (more) fetch(c + CSLOTS, cfn, drawn, p0n);
+    bf16x8 yv[NY];
+#pragma unroll
+    for (int k = 0; k < NY; ++k) {
+      const int i = tid + 256 * k, row = i / nvec, ch = i % nvec;
+      if (i < CQ * nvec && t0 + row < a.L) yv[k] = *(const bf16x8*)(yp + (int64_t)(t0 + row) * a.ysl + 8 * ch);
+    }
     if (wave == 0) {
-      const int t = t0 + lane;
-      const float d = t < a.L ? disc_dt(a, (float)dp[(int64_t)t * a.dsl], h) : 0.f;
+      const float d = t0 + lane < a.L ? disc_dt(a, draw, h) : 0.f;
       const float cs = wave_incl_scan_dpp(d * Ah);
       ef[lane] = __builtin_amdgcn_exp2f(p0 + cs);
     }
-    // C rows of this wave's 16 tokens as A operand (rows past the end repeat the last row: finite)
-    const int trow = min(t0 + 16 * wave + lc, a.L - 1);
-    bf16x8 cf[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) cf[ks] = *(const bf16x8*)(cp + (int64_t)trow * a.csl + 32 * ks + 8 * kq);
     f32x4 acc[PT];
 #pragma unroll
     for (int ct = 0; ct < PT; ++ct) {
@@ -141,11 +163,11 @@ __global__ __launch_bounds__(256) void ssd_correct_kernel(CorrArgs a) {
       for (int ct = 0; ct < PT; ++ct) tile[row * LDW + 16 * ct + lc] = acc[ct][r] * e;
     }
     __syncthreads();
-    for (int i = tid; i < CQ * nvec; i += 256) {
-      const int row = i / nvec, ch = i % nvec;
-      if (t0 + row < a.L) {
-        bf16_t* q = yp + (int64_t)(t0 + row) * a.ysl + 8 * ch;
-        bf16x8 v = *(const bf16x8*)q;
+#pragma unroll
+    for (int k = 0; k < NY; ++k) {
+      const int i = tid + 256 * k, row = i / nvec, ch = i % nvec;
+      if (i < CQ * nvec && t0 + row < a.L) {
+        bf16x8 v = yv[k];
         const f32x4 lo = *(const f32x4*)(tile + row * LDW + 8 * ch);
         const f32x4 hi = *(const f32x4*)(tile + row * LDW + 8 * ch + 4);
 #pragma unroll
@@ -153,9 +175,13 @@ __global__ __launch_bounds__(256) void ssd_correct_kernel(CorrArgs a) {
           v[j] = (bf16_t)((float)v[j] + lo[j]);
           v[4 + j] = (bf16_t)((float)v[4 + j] + hi[j]);
         }
-        *(bf16x8*)q = v;
+        *(bf16x8*)(yp + (int64_t)(t0 + row) * a.ysl + 8 * ch) = v;
       }
     }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) cf[ks] = cfn[ks];
+    draw = drawn;
+    p0 = p0n;
   }
 }
 

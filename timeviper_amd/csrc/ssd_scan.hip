@@ -31,9 +31,9 @@ int tv_ssd_march_launch(const void* x, const void* dt, const void* A, const void
 // ssd_slice.hip
 bool tv_ssd_slice_supported(int seqlen, int nheads, int headdim, int ngroups, int dstate,
                             int dtype, int64_t xsl, int64_t bsl, int64_t bsg, int64_t csl, int64_t csg, int64_t ysl,
-                            const void* x, const void* Bm, const void* Cm, const void* y, bool wide);
+                            const void* x, const void* Bm, const void* Cm, const void* y, int wide);
 size_t tv_ssd_slice_workspace_bytes(int batch, int seqlen, int nheads, int headdim, int ngroups,
-                                    int dstate, bool wide);
+                                    int dstate, int wide);
 int tv_ssd_slice_launch(const void* x, const void* dt, const void* A, const void* Bm,
                         const void* Cm, const void* D, const void* dt_bias,
                         const void* init_state, void* y, void* final_state, void* total_decay,
@@ -41,11 +41,12 @@ int tv_ssd_slice_launch(const void* x, const void* dt, const void* A, const void
                         int64_t xsb, int64_t xsl, int64_t dsb, int64_t dsl, int64_t bsb,
                         int64_t bsl, int64_t bsg, int64_t csb, int64_t csl, int64_t csg, int64_t ysb, int64_t ysl,
                         int dtype, int dt_softplus, float dt_min, float dt_max, int group_map,
-                        void* workspace, size_t workspace_bytes, bool wide, hipStream_t st);
+                        void* workspace, size_t workspace_bytes, int wide, const void* cb_pre, hipStream_t st);
 
 // 0 auto, 1 generic recurrence, 2 chunk march (ssd_march.hip), 3 slice march, two work-groups per
 // head (ssd_slice.hip), 4 slice march, whole-head work-groups x concurrent sequence segments +
-// carried-in state correction (ssd_slice.hip + ssd_correct.hip)
+// carried-in state correction (ssd_slice.hip + ssd_correct.hip), 8 waves with two column tiles per
+// slice-wave, 5 the same with 12 waves and one column tile per slice-wave
 // process-wide override for tests / dev tools; atomic so that concurrent callers never race on it
 static std::atomic<int> g_ssd_impl{0};
 static const int kAutoImpl = 4;   // whole-head slice march; falls back to 3, the chunk march, the generic kernel
@@ -55,22 +56,22 @@ extern "C" void tv_ssd_scan_set_impl(int impl) { g_ssd_impl.store(impl, std::mem
 extern "C" size_t tv_ssd_scan_workspace_bytes(int batch, int seqlen, int nheads, int headdim,
                                               int ngroups, int dstate, int dtype) {
   if (dtype != TV_BF16 || dstate != 128) return 0;
-  const size_t narrow = tv_ssd_slice_workspace_bytes(batch, seqlen, nheads, headdim, ngroups, dstate, false);
-  const size_t wide = tv_ssd_slice_workspace_bytes(batch, seqlen, nheads, headdim, ngroups, dstate, true);
+  const size_t narrow = tv_ssd_slice_workspace_bytes(batch, seqlen, nheads, headdim, ngroups, dstate, 0);
+  const size_t wide = tv_ssd_slice_workspace_bytes(batch, seqlen, nheads, headdim, ngroups, dstate, 1);
   return narrow > wide ? narrow : wide;       // either variant may be selected (tv_ssd_scan_set_impl)
 }
 
-extern "C" int tv_ssd_scan_fwd(const void* x, const void* dt, const void* A, const void* Bm,
-                               const void* Cm, const void* D, const void* dt_bias,
-                               const void* init_state, void* y, void* final_state,
-                               void* total_decay, int batch, int seqlen, int nheads, int headdim,
-                               int ngroups, int dstate, int64_t x_stride_b, int64_t x_stride_l,
-                               int64_t dt_stride_b, int64_t dt_stride_l, int64_t b_stride_b,
-                               int64_t b_stride_l, int64_t b_stride_g, int64_t c_stride_b,
-                               int64_t c_stride_l, int64_t c_stride_g, int64_t y_stride_b,
-                               int64_t y_stride_l, int dtype, int dt_softplus,
-                               float dt_min, float dt_max, int group_map, void* workspace,
-                               size_t workspace_bytes, void* stream) {
+static int scan_impl(const void* x, const void* dt, const void* A, const void* Bm,
+                     const void* Cm, const void* D, const void* dt_bias,
+                     const void* init_state, void* y, void* final_state,
+                     void* total_decay, int batch, int seqlen, int nheads, int headdim,
+                     int ngroups, int dstate, int64_t x_stride_b, int64_t x_stride_l,
+                     int64_t dt_stride_b, int64_t dt_stride_l, int64_t b_stride_b,
+                     int64_t b_stride_l, int64_t b_stride_g, int64_t c_stride_b,
+                     int64_t c_stride_l, int64_t c_stride_g, int64_t y_stride_b,
+                     int64_t y_stride_l, int dtype, int dt_softplus,
+                     float dt_min, float dt_max, int group_map, const void* cb, void* workspace,
+                     size_t workspace_bytes, void* stream) {
   TV_CHECK_ARG(A && (seqlen == 0 || (x && dt && Bm && Cm && y)), "ssd_scan: null pointer");   // empty tensors have no storage
   TV_CHECK_ARG(batch > 0 && seqlen >= 0 && nheads > 0 && headdim > 0 && ngroups > 0 &&
                    dstate > 0 && nheads % ngroups == 0,
@@ -96,17 +97,18 @@ extern "C" int tv_ssd_scan_fwd(const void* x, const void* dt, const void* A, con
   if (forced >= 2 && !march)
     TV_UNSUPPORTED("ssd_scan: MFMA march kernel forced but shape/dtype unsupported");
   const int impl = forced ? forced : kAutoImpl;
-  for (int wide = 1; wide >= 0; --wide) {       // impl 4: whole-head variant first, then two work-groups per head
-    if (wide && impl != 4) continue;
+  for (int wide = 2; wide >= 0; --wide) {       // impl 5 / 4: whole-head variants first, then two work-groups per head
+    if (wide == 2 && impl != 5) continue;
+    if (wide == 1 && impl != 4) continue;
     if (march && impl >= 3 && workspace &&
         tv_ssd_slice_supported(seqlen, nheads, headdim, ngroups, dstate, dtype, x_stride_l, b_stride_l,
-                               b_stride_g, c_stride_l, c_stride_g, y_stride_l, x, Bm, Cm, y, wide != 0)) {
+                               b_stride_g, c_stride_l, c_stride_g, y_stride_l, x, Bm, Cm, y, wide)) {
       return tv_ssd_slice_launch(x, dt, A, Bm, Cm, D, dt_bias, init_state, y, final_state,
                                  total_decay, batch, seqlen, nheads, headdim, ngroups, dstate,
                                  x_stride_b, x_stride_l, dt_stride_b, dt_stride_l, b_stride_b,
                                  b_stride_l, b_stride_g, c_stride_b, c_stride_l, c_stride_g, y_stride_b, y_stride_l, dtype,
                                  dt_softplus, dt_min, dt_max, group_map, workspace, workspace_bytes,
-                                 wide != 0, st);
+                                 wide, cb, st);
     }
   }
   if (march) {
@@ -122,4 +124,42 @@ extern "C" int tv_ssd_scan_fwd(const void* x, const void* dt, const void* A, con
                                x_stride_b, x_stride_l, dt_stride_b, dt_stride_l, b_stride_b,
                                b_stride_l, b_stride_g, c_stride_b, c_stride_l, c_stride_g, y_stride_b, y_stride_l, dtype,
                                dt_softplus, dt_min, dt_max, group_map, st);
+}
+
+extern "C" int tv_ssd_scan_fwd(const void* x, const void* dt, const void* A, const void* Bm,
+                               const void* Cm, const void* D, const void* dt_bias,
+                               const void* init_state, void* y, void* final_state,
+                               void* total_decay, int batch, int seqlen, int nheads, int headdim,
+                               int ngroups, int dstate, int64_t x_stride_b, int64_t x_stride_l,
+                               int64_t dt_stride_b, int64_t dt_stride_l, int64_t b_stride_b,
+                               int64_t b_stride_l, int64_t b_stride_g, int64_t c_stride_b,
+                               int64_t c_stride_l, int64_t c_stride_g, int64_t y_stride_b,
+                               int64_t y_stride_l, int dtype, int dt_softplus,
+                               float dt_min, float dt_max, int group_map, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+  return scan_impl(x, dt, A, Bm, Cm, D, dt_bias, init_state, y, final_state, total_decay, batch, seqlen, nheads,
+                   headdim, ngroups, dstate, x_stride_b, x_stride_l, dt_stride_b, dt_stride_l, b_stride_b, b_stride_l,
+                   b_stride_g, c_stride_b, c_stride_l, c_stride_g, y_stride_b, y_stride_l, dtype, dt_softplus, dt_min,
+                   dt_max, group_map, nullptr, workspace, workspace_bytes, stream);
+}
+
+// The same scan with the causal C.B^T fragments of every (chunk, group) supplied by the caller — the `cb` output of
+// tv_causal_conv1d_xbc_cb_fwd on the same B / C (tv_ssd_cb_bytes() bytes) — instead of recomputed by a pre-pass
+// that reads B and C back.  Kernels that do not use the fragments (fp32, other d_state) ignore them.
+extern "C" int tv_ssd_scan_cb_fwd(const void* x, const void* dt, const void* A, const void* Bm,
+                                  const void* Cm, const void* cb, const void* D, const void* dt_bias,
+                                  const void* init_state, void* y, void* final_state,
+                                  void* total_decay, int batch, int seqlen, int nheads, int headdim,
+                                  int ngroups, int dstate, int64_t x_stride_b, int64_t x_stride_l,
+                                  int64_t dt_stride_b, int64_t dt_stride_l, int64_t b_stride_b,
+                                  int64_t b_stride_l, int64_t b_stride_g, int64_t c_stride_b,
+                                  int64_t c_stride_l, int64_t c_stride_g, int64_t y_stride_b,
+                                  int64_t y_stride_l, int dtype, int dt_softplus,
+                                  float dt_min, float dt_max, int group_map, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  TV_CHECK_ARG(cb == nullptr || (((uintptr_t)cb) & 15) == 0, "ssd_scan_cb: C.B^T buffer must be 16-byte aligned");
+  return scan_impl(x, dt, A, Bm, Cm, D, dt_bias, init_state, y, final_state, total_decay, batch, seqlen, nheads,
+                   headdim, ngroups, dstate, x_stride_b, x_stride_l, dt_stride_b, dt_stride_l, b_stride_b, b_stride_l,
+                   b_stride_g, c_stride_b, c_stride_l, c_stride_g, y_stride_b, y_stride_l, dtype, dt_softplus, dt_min,
+                   dt_max, group_map, cb, workspace, workspace_bytes, stream);
 }

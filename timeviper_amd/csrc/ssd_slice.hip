@@ -37,8 +37,30 @@ int tv_ssd_correct_launch(void* y, const void* dt, const void* A, const void* Cm
                           int group_map, void* workspace, const float* chunk_tot, int64_t chunk_tot_stride,
                           hipStream_t st);
 
+// TV_BSCALE (wide layouts): 1 = the B/C waves scale the B tile in place (B~ = w_t B) and the slice-waves run the
+// state update on raw x fragments; 0 = the slice-waves form x~ = w_t x on their own fragments (round 2)
+#ifndef TV_BSCALE
+#define TV_BSCALE 0
+#endif
+// TV_YDIRECT (wide layouts): 1 = the slice-waves store y from their registers (no y tiles in LDS: room for a B/C ring
+// of 3); 0 = y tiles in LDS, stored by the B/C waves, B/C ring of 2 (round 2)
+#ifndef TV_YDIRECT
+#define TV_YDIRECT 0
+#endif
+// TV_YDIAG_FIRST (wide layouts): 1 = a step OPENS with Ydiag + D x (M and the raw x fragments are the first reads after the
+// barrier; their twelve MFMAs run while the C / B fragments of quarter 0 arrive) and ends with y = e^{cs_t} Yoff + that,
+// vector work only; 0 = Ydiag accumulates onto the scaled Yoff at the end of the step (round 2)
+#ifndef TV_YDIAG_FIRST
+#define TV_YDIAG_FIRST 0
+#endif
+// TV_SLICE_PRIO: static s_setprio level of the slice-waves (0 = none)
+#ifndef TV_SLICE_PRIO
+#define TV_SLICE_PRIO 0
+#endif
 namespace {
 using namespace ssdk;
+constexpr bool BSCALE = TV_BSCALE != 0, YDIRECT = TV_YDIRECT != 0, YDF = TV_YDIAG_FIRST != 0;
+static_assert(YDIRECT || !BSCALE, "TV_BSCALE needs the ring of 3 (TV_YDIRECT)");
 
 constexpr int SQ = 64;           // tokens per chunk
 constexpr int SN = 128;          // d_state
@@ -54,7 +76,7 @@ constexpr int NV = 3;            // cs / ecs / dt / weight vector buffers
 //     x issued 3 chunks ahead.
 template <int PW> struct Rings {
   static constexpr bool WIDE = PW > 48;
-  static constexpr int NB = WIDE ? 2 : 3;      // B/C ring slots
+  static constexpr int NB = (WIDE && !YDIRECT) ? 2 : 3;      // B/C ring slots
   static constexpr int BD = NB - 1;            // B/C prefetch distance (chunks)
   static constexpr int DXS = WIDE ? 3 : 4;     // x prefetch distance
   static constexpr int NXS = DXS + 1;          // x ring slots
@@ -172,7 +194,7 @@ struct __attribute__((aligned(16))) SliceSmem {
   static constexpr bool WIDE = Rings<PW>::WIDE;
   bf16_t xs[WIDE ? 1 : 2][WIDE ? 8 : XSLOT];        // x~ = exp(cs_Q - cs_t) dt_t x   (narrow layout only)
   bf16_t M[2][CB_ELEMS];      // decay-masked C.B^T fragments
-  bf16_t yt[2][SQ * PW];      // y tiles [t][PW]
+  bf16_t yt[(WIDE && YDIRECT) ? 1 : 2][(WIDE && YDIRECT) ? 8 : SQ * PW];      // y tiles [t][PW]   (not with TV_YDIRECT)
   unsigned dtr[NDT][SQ];      // raw dt of heads (h&~1, h|1)
   float cs[NV][SQ];           // inclusive cumsum of dt*A inside the chunk, times log2(e)
   float ecs[NV][SQ];          // exp(cs)
@@ -199,19 +221,28 @@ __device__ __forceinline__ int xad(int a, int k, int b) {
 //   narrow: 0-2 slices, 3 x/dt/y, 4-6 + 11 B/C (+ one x~ piece each), 7-8 mask, 9 prep, 10 x~ pieces —
 //     the two mask waves, the heaviest VALU helpers, sit on different SIMDs; SIMD 3 has no slice-wave;
 //   wide:   0-2 slices (two column tiles each), 3 x/dt copies + prep, 4-5 B/C copies + y stores, 6-7 mask.
-template <int PW> struct Roles {
+//   wide12 (round 3): 12 waves of <= 168 registers: 0-4 slices with ONE column tile each — five slice-waves on the four
+//     SIMDs run their (latency-bound) steps side by side instead of three waves taking two tiles in turn —
+//     5 x/dt copies + prep, 6-7 + 10-11 B/C copies + in-place B~ scaling, 9 + 8 mask (wave 8, the light one,
+//     shares SIMD 0 with two slice-waves).
+template <int PW, bool W12> struct Roles {
   static constexpr bool WIDE = PW > 48;
-  static constexpr int NWAVES = WIDE ? 8 : 12;
-  static constexpr int NC = WIDE ? 2 : 1;          // 16-column tiles per slice-wave
-  static constexpr int XIO = 3;                    // x / dt DMA (+ y stores, narrow; + prep, wide)
-  static constexpr int PREP = WIDE ? 3 : 9;        // dt -> softplus -> prefix sum, mask factors
+  static constexpr bool WIDE8 = WIDE && !W12, WIDE12 = WIDE && W12;
+  static constexpr int NWAVES = WIDE8 ? 8 : 12;
+  static constexpr int NC = WIDE8 ? 2 : 1;         // 16-column tiles per slice-wave
+  static constexpr int XIO = WIDE12 ? 5 : 3;       // x / dt DMA (+ y stores, narrow; + prep, wide)
+  static constexpr int PREP = WIDE ? XIO : 9;      // dt -> softplus -> prefix sum, mask factors
   static constexpr int SCALE = WIDE ? -1 : 10;     // x~ pieces the four B/C waves do not take (narrow)
-  static constexpr int NBCW = WIDE ? 2 : 4;        // B/C copy waves
+  static constexpr int NBCW = WIDE8 ? 2 : 4;       // B/C copy waves
   static __device__ __forceinline__ int bc(int w) {
-    return WIDE ? ((w == 4 || w == 5) ? w - 4 : -1) : (w == 4 ? 0 : w == 5 ? 1 : w == 6 ? 2 : w == 11 ? 3 : -1);
+    if (WIDE8) return (w == 4 || w == 5) ? w - 4 : -1;
+    if (WIDE12) return w == 6 ? 0 : w == 7 ? 1 : w == 10 ? 2 : w == 11 ? 3 : -1;
+    return w == 4 ? 0 : w == 5 ? 1 : w == 6 ? 2 : w == 11 ? 3 : -1;
   }
   static __device__ __forceinline__ int mask(int w) {
-    return WIDE ? (w == 6 ? 0 : w == 7 ? 1 : -1) : (w == 7 ? 0 : w == 8 ? 1 : -1);
+    if (WIDE8) return w == 6 ? 0 : w == 7 ? 1 : -1;
+    if (WIDE12) return w == 9 ? 0 : w == 8 ? 1 : -1;
+    return w == 7 ? 0 : w == 8 ? 1 : -1;
   }
 };
 
@@ -237,11 +268,11 @@ __device__ unsigned long long g_slice_phases[8];
   } while (0)
 #endif
 
-template <int PT, int PW>
-__global__ __launch_bounds__(Roles<PW>::NWAVES * 64) void ssd_slice_kernel(SliceArgs a) {
+template <int PT, int PW, bool W12>
+__global__ __launch_bounds__((Roles<PW, W12>::NWAVES * 64)) void ssd_slice_kernel(SliceArgs a) {
   typedef SliceSmem<PW> Smem;
   typedef Rings<PW> RG;
-  typedef Roles<PW> RL;
+  typedef Roles<PW, W12> RL;
   constexpr int STHREADS = RL::NWAVES * 64, NC = RL::NC;
   constexpr int NB = RG::NB, BD = RG::BD, DXS = RG::DXS, NXS = RG::NXS, NDT = RG::NDT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -335,6 +366,7 @@ __global__ __launch_bounds__(Roles<PW>::NWAVES * 64) void ssd_slice_kernel(Slice
   };
   if (wave < PT) {
     // ============================================================ slice-wave (NC tiles of 16 columns)
+    if (TV_SLICE_PRIO) __builtin_amdgcn_s_setprio(TV_SLICE_PRIO);
     const float Dh = a.D ? a.D[h] : 0.f;
     f32x4 xacc[NC][8];
     int pcol[NC];
@@ -374,7 +406,8 @@ __global__ __launch_bounds__(Roles<PW>::NWAVES * 64) void ssd_slice_kernel(Slice
     bool cvalid[NC];                // this lane's four columns exist (PW is a multiple of 8)
 #pragma unroll
     for (int ct = 0; ct < NC; ++ct) cvalid[ct] = 16 * (wave * NC + ct) + 4 * kq < PW;
-    auto write_y = [&](int c) {     // y tile of chunk c
+    auto write_y = [&](int c) {     // y tile of chunk c (stored by the x/dt/y wave, narrow, or the B/C waves, wide)
+      if (RL::WIDE && YDIRECT) return;
 #pragma unroll
       for (int ct = 0; ct < NC; ++ct) {
         if (!cvalid[ct]) continue;
@@ -384,6 +417,44 @@ __global__ __launch_bounds__(Roles<PW>::NWAVES * 64) void ssd_slice_kernel(Slice
           asm volatile("ds_write_b64 %0, %1" :: "v"(ya), "v"(ypk[ct][ti]) : "memory");
         }
       }
+    };
+    // Wide layout: y leaves the wave straight from these registers — 8 bytes per lane and (tile, t-tile),
+    // NC * 4 global_store_dwordx2 per step, nobody waits for them (round 3; the y tiles in LDS, their
+    // ds_write_b64 / ds_read_b128 round trip and the helper waves' stores are gone, and the 20 KiB they
+    // took hold the third B/C ring slot).  The 32-byte pieces of a row that the five tiles write meet in L2.
+    bf16_t* const ygs = a.y + (int64_t)b * a.ysb + (int64_t)t_first * a.ysl + (int64_t)h * a.P + p_base;
+    unsigned yoff[4];               // byte offset of this lane's 8 bytes inside a chunk's rows, tile 0 of the wave
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) yoff[ti] = (unsigned)(((16 * ti + lc) * a.ysl + 16 * wave * NC + 4 * kq) * 2);
+    auto store_y = [&](int c) {
+      const int t0 = c * SQ;
+      const void* yc = uniform_ptr(ygs + (int64_t)t0 * a.ysl);
+      const bool full = t0 + SQ <= L;
+#pragma unroll
+      for (int ct = 0; ct < NC; ++ct) {
+        if (!cvalid[ct]) continue;
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti)
+          if (full || t0 + 16 * ti + lc < L)      // scalar base + 32-bit lane offset (a generic pointer store would be a flat_store, which also counts in lgkmcnt)
+            asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3" :: "v"(yoff[ti]), "v"(ypk[ct][ti]), "s"(yc), "n"(32 * ct) : "memory");
+      }
+    };
+    bf16x8 cq[2][4];
+    bf16x4 bq[2][2][4];
+    auto read_cq_at = [&](const unsigned char* Ct, int q, bf16x8 (&cf)[4]) {     // [t-tile]
+      const unsigned char* cp = Ct + xad(c_z, 64 * q, c_lo);
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti) cf[ti] = ld8(cp + ti * 4096);
+    };
+    auto read_b2_at = [&](const unsigned char* Bt, int i0, bf16x4 (&dst)[2][4]) {   // tiles i0 = 2m, i0 + 1
+      const unsigned char* bp = Bt + xad(bsw, 32 * i0, b_lo);
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          dst[ii][2 * ks] = tr4(bp + ii * 8 + ks * 8192);
+          dst[ii][2 * ks + 1] = tr4(bp + ii * 8 + ks * 8192 + 1024);
+        }
     };
     SLICE_BARRIER();   // P1
     SLICE_BARRIER();   // P2
@@ -405,21 +476,8 @@ __global__ __launch_bounds__(Roles<PW>::NWAVES * 64) void ssd_slice_kernel(Slice
       // B^T x~.  The C columns and B tiles of quarter q+1 are read while quarter q computes
       // (LDS returns in order, waits are counted) and serve all column tiles of the wave; the
       // scheduling fences keep hipcc from sinking those reads back next to their uses.
-      auto read_cq = [&](int q, bf16x8 (&cf)[4]) {     // [t-tile]
-        const unsigned char* cp = Ct + xad(c_z, 64 * q, c_lo);
-#pragma unroll
-        for (int ti = 0; ti < 4; ++ti) cf[ti] = ld8(cp + ti * 4096);
-      };
-      auto read_b2 = [&](int i0, bf16x4 (&dst)[2][4]) {   // tiles i0 = 2m, i0 + 1
-        const unsigned char* bp = Bt + xad(bsw, 32 * i0, b_lo);
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) {
-            dst[ii][2 * ks] = tr4(bp + ii * 8 + ks * 8192);
-            dst[ii][2 * ks + 1] = tr4(bp + ii * 8 + ks * 8192 + 1024);
-          }
-      };
+      auto read_cq = [&](int q, bf16x8 (&cf)[4]) { read_cq_at(Ct, q, cf); };
+      auto read_b2 = [&](int i0, bf16x4 (&dst)[2][4]) { read_b2_at(Bt, i0, dst); };
       f32x4 yo[NC][4];
 #pragma unroll
       for (int ct = 0; ct < NC; ++ct)
@@ -460,23 +518,31 @@ __global__ __launch_bounds__(Roles<PW>::NWAVES * 64) void ssd_slice_kernel(Slice
             for (int ct = 0; ct < NC; ++ct) xacc[ct][2 * q + ii] = mfma16(bfrag, xwf[ct][ks], xacc[ct][2 * q + ii]);
           }
       };
-      bf16x8 cq[2][4];
-      bf16x4 bq[2][2][4];
       PSTAMP(7);
       // ---- first reads
-      read_cq(0, cq[0]);
+      constexpr bool YF = YDF && RL::WIDE;
+      bf16x8 mf[NFRAG];
+      bf16x4 xv[NC][4];               // x[t][16 tile + 4 kq + 0..3]: a plain 8-byte row read
+      if (YF) {
+#pragma unroll
+        for (int f = 0; f < NFRAG; ++f) mf[f] = ld8(Mf + f * 1024 + lane * 16);
+      } else {
+        read_cq(0, cq[0]);
+      }
       bf16x4 xq[NC][2][2], xwq[NC][2][2];
       f32x4 wq[2][2];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        if (RL::WIDE) {      // raw x fragments (kept for Ydiag) and the weights of their eight tokens
+        if (RL::WIDE) {      // raw x fragments (kept for Ydiag); BSCALE: the state update runs on them against B~ = w_t B
 #pragma unroll
           for (int ct = 0; ct < NC; ++ct) {
             xq[ct][ks][0] = tr4(xt + trx + 32 * ct + ks * (32 * PW * 2));
             xq[ct][ks][1] = tr4(xt + trx + 32 * ct + ks * (32 * PW * 2) + 4 * PW * 2);
           }
-          wq[ks][0] = *(const f32x4*)(&sm.wts[vb][32 * ks + 8 * kq]);
-          wq[ks][1] = *(const f32x4*)(&sm.wts[vb][32 * ks + 8 * kq + 4]);
+          if (!BSCALE) {     // the weights of their eight tokens
+            wq[ks][0] = *(const f32x4*)(&sm.wts[vb][32 * ks + 8 * kq]);
+            wq[ks][1] = *(const f32x4*)(&sm.wts[vb][32 * ks + 8 * kq + 4]);
+          }
         } else {
 #pragma unroll
           for (int ct = 0; ct < NC; ++ct) {
@@ -486,9 +552,37 @@ __global__ __launch_bounds__(Roles<PW>::NWAVES * 64) void ssd_slice_kernel(Slice
         }
       }
       const float dl = sm.dl[vb][0];
+      if (YF) {
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+          for (int ct = 0; ct < NC; ++ct) xv[ct][ti] = *(const bf16x4*)(xt + trd + 32 * ct + ti * (16 * PW * 2));
+        read_cq(0, cq[0]);
+      }
       read_b2(0, bq[0]);
       PSTAMP(6);
       if (c > 0) write_y(c - 1);        // previous chunk's results, under the reads just issued
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 yd[NC][4];                  // Ydiag + D x (YF)
+      if (YF && !SDBG(a, 128)) {
+        const f32x2 dh2 = {Dh, Dh};
+#pragma unroll
+        for (int ct = 0; ct < NC; ++ct) {
+          const bf16x8 xf[2] = {cat4(xq[ct][0][0], xq[ct][0][1]), cat4(xq[ct][1][0], xq[ct][1][1])};
+#pragma unroll
+          for (int ti = 0; ti < 4; ++ti) {
+            const unsigned x01 = __builtin_bit_cast(u32x2, xv[ct][ti])[0], x23 = __builtin_bit_cast(u32x2, xv[ct][ti])[1];
+            const f32x2 d0 = dh2 * f32x2{bf16_lo(x01), bf16_hi(x01)}, d1 = dh2 * f32x2{bf16_lo(x23), bf16_hi(x23)};
+            yd[ct][ti] = f32x4{d0[0], d0[1], d1[0], d1[1]};
+          }
+#pragma unroll
+          for (int ti = 0; ti < 4; ++ti) {
+            const int f0 = ti == 0 ? 0 : ti == 1 ? 1 : ti == 2 ? 2 : 4;
+            yd[ct][ti] = mfma16(xf[0], mf[f0], yd[ct][ti]);
+            if (ti >= 2) yd[ct][ti] = mfma16(xf[1], mf[f0 + 1], yd[ct][ti]);
+          }
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
       PSTAMP(0);
       read_cq(1, cq[1]);
@@ -496,7 +590,10 @@ __global__ __launch_bounds__(Roles<PW>::NWAVES * 64) void ssd_slice_kernel(Slice
       bf16x8 xwf[NC][2];
 #pragma unroll
       for (int ct = 0; ct < NC; ++ct) {
-        if (RL::WIDE) {
+        if (RL::WIDE && BSCALE) {
+          xwf[ct][0] = cat4(xq[ct][0][0], xq[ct][0][1]);
+          xwf[ct][1] = cat4(xq[ct][1][0], xq[ct][1][1]);
+        } else if (RL::WIDE) {
           // x~ = w_t x on this wave's own fragments: element j of fragment ks is token 32 ks + 8 kq + j
           // (same products and roundings as the helper waves' scale_piece of the narrow layout)
 #pragma unroll
@@ -528,16 +625,18 @@ __global__ __launch_bounds__(Roles<PW>::NWAVES * 64) void ssd_slice_kernel(Slice
       __builtin_amdgcn_sched_barrier(0);
       PSTAMP(3);
       // epilogue operands in flight under the last quarter
-      bf16x8 mf[NFRAG];
+      if (!YF) {
 #pragma unroll
-      for (int f = 0; f < NFRAG; ++f) mf[f] = ld8(Mf + f * 1024 + lane * 16);
+        for (int f = 0; f < NFRAG; ++f) mf[f] = ld8(Mf + f * 1024 + lane * 16);
+      }
       float ev[4];                    // exp(cs_t) of this lane's token 16 ti + lc
-      bf16x4 xv[NC][4];               // x[t][16 tile + 4 kq + 0..3]: a plain 8-byte row read
 #pragma unroll
       for (int ti = 0; ti < 4; ++ti) {
         ev[ti] = sm.ecs[vb][16 * ti + lc];
+        if (!YF) {
 #pragma unroll
-        for (int ct = 0; ct < NC; ++ct) xv[ct][ti] = *(const bf16x4*)(xt + trd + 32 * ct + ti * (16 * PW * 2));
+          for (int ct = 0; ct < NC; ++ct) xv[ct][ti] = *(const bf16x4*)(xt + trd + 32 * ct + ti * (16 * PW * 2));
+        }
       }
       if (!RL::WIDE) {       // (wide: the raw fragments were read at the top of the step)
 #pragma unroll
@@ -556,6 +655,15 @@ __global__ __launch_bounds__(Roles<PW>::NWAVES * 64) void ssd_slice_kernel(Slice
         const f32x2 dh2 = {Dh, Dh};
 #pragma unroll
         for (int ct = 0; ct < NC; ++ct) {
+          if (YF) {
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti) {
+              f32x2 y0 = {yo[ct][ti][0], yo[ct][ti][1]}, y1 = {yo[ct][ti][2], yo[ct][ti][3]};
+              y0 = __builtin_elementwise_fma(y0, f32x2{ev[ti], ev[ti]}, f32x2{yd[ct][ti][0], yd[ct][ti][1]});
+              y1 = __builtin_elementwise_fma(y1, f32x2{ev[ti], ev[ti]}, f32x2{yd[ct][ti][2], yd[ct][ti][3]});
+              yo[ct][ti] = f32x4{y0[0], y0[1], y1[0], y1[1]};
+            }
+          } else {
           const bf16x8 xf[2] = {cat4(xq[ct][0][0], xq[ct][0][1]), cat4(xq[ct][1][0], xq[ct][1][1])};
 #pragma unroll
           for (int ti = 0; ti < 4; ++ti) {
@@ -571,6 +679,7 @@ __global__ __launch_bounds__(Roles<PW>::NWAVES * 64) void ssd_slice_kernel(Slice
             yo[ct][ti] = mfma16(xf[0], mf[f0], yo[ct][ti]);
             if (ti >= 2) yo[ct][ti] = mfma16(xf[1], mf[f0 + 1], yo[ct][ti]);
           }
+          }
           // packed bf16 results stay in registers across the barrier; they are written to the y
           // tile at the start of the next step, beside that step's first fragment reads
 #pragma unroll
@@ -580,6 +689,7 @@ __global__ __launch_bounds__(Roles<PW>::NWAVES * 64) void ssd_slice_kernel(Slice
             ypk[ct][ti] = ypk_t{__builtin_bit_cast(unsigned, p01), __builtin_bit_cast(unsigned, p23)};
           }
         }
+        if (RL::WIDE && YDIRECT) store_y(c);
       }
       PSTAMP(5);
       SLICE_BARRIER();
@@ -704,6 +814,16 @@ __global__ __launch_bounds__(Roles<PW>::NWAVES * 64) void ssd_slice_kernel(Slice
       const void* sb = uniform_ptr(Bg + (int64_t)t0 * a.bsl);
       const void* sc = uniform_ptr(Cg + (int64_t)t0 * a.csl);
       const bool full = t0 + SQ <= L;
+      if (full && KP % 4 == 0) {     // four pieces per M0 set-up (piece k's row is >= 4 k: the offsets stay >= 0)
+#pragma unroll
+        for (int k = 0; k + 3 < KP; k += 4) {
+          glds16x4(sb, off_b[k], off_b[k + 1] - 1024u, off_b[k + 2] - 2048u, off_b[k + 3] - 3072u,
+                   lds_addr_of(sm.bt[slot] + (KP * q + k) * 512));
+          glds16x4(sc, off_c[k], off_c[k + 1] - 1024u, off_c[k + 2] - 2048u, off_c[k + 3] - 3072u,
+                   lds_addr_of(sm.ct[slot] + (KP * q + k) * 512));
+        }
+        return;
+      }
 #pragma unroll
       for (int k = 0; k < KP; ++k) {
         unsigned ob = off_b[k], oc = off_c[k];
@@ -716,16 +836,46 @@ __global__ __launch_bounds__(Roles<PW>::NWAVES * 64) void ssd_slice_kernel(Slice
         glds16(sc, oc, lds_addr_of(sm.ct[slot] + (KP * q + k) * 512));
       }
     };
+    // Wide layout: B~[t][n] = w_t B[t][n] (w_t = exp(cs_last - cs_t) dt_t) IN PLACE, each B/C wave on the pieces it
+    // copied itself — the state update X = e^{cs_Q} X + B~^T x then runs on the raw x fragments, and the slice-waves
+    // (the pole of the step) lose the unpack / multiply / repack of x~ = w_t x: ~110 of their ~400 vector instructions
+    // per step.  The raw B tile has no other reader (C.B^T comes from the pre-pass).  Rows past the sequence end have
+    // w = 0.
+    auto scale_b = [&](int c) {
+      if (!RL::WIDE || !BSCALE) return;
+      unsigned char* bp = reinterpret_cast<unsigned char*>(sm.bt[c % NB]) + KP * q * 1024 + lane * 16;
+      const float* wv = sm.wts[c % NV] + 4 * KP * q + (lane >> 4);
+      typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+      typedef __attribute__((ext_vector_type(2))) float f32x2;
+      u32x4 v[KP];
+      float w[KP];
+#pragma unroll
+      for (int k = 0; k < KP; ++k) {
+        v[k] = *(const u32x4*)(bp + k * 1024);
+        w[k] = wv[4 * k];
+      }
+#pragma unroll
+      for (int k = 0; k < KP; ++k) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const f32x2 pr = f32x2{bf16_lo(v[k][e]), bf16_hi(v[k][e])} * f32x2{w[k], w[k]};
+          o[2 * e] = (bf16_t)pr[0];
+          o[2 * e + 1] = (bf16_t)pr[1];
+        }
+        *(bf16x8*)(bp + k * 1024) = o;
+      }
+    };
     // x~ pieces (narrow layout only): this wave takes one of the first four, the W_SCALE wave the rest
     auto scale_mine = [&](int c) {
       if (!RL::WIDE && q < NPI) scale_piece(c, q);
     };
-    // wide: the two B/C waves store the y tiles (every other 1 KiB piece each).  (Measured: moved to
+    // wide without TV_YDIRECT: the two B/C waves store the y tiles (every other 1 KiB piece each).  (Measured: moved to
     // the lighter mask wave the stores' completion sits in front of that wave's compiler-placed waits
     // and makes it the pole of the step: 4 380 against 3 930 ticks.)
     bf16_t* ygw = a.y + (int64_t)b * a.ysb + (int64_t)t_first * a.ysl + (int64_t)h * a.P + p_base;
     auto store_y_half = [&](int c) {
-      if (!RL::WIDE) return;
+      if (!RL::WIDE || YDIRECT) return;
       const int t0 = c * SQ;
       const unsigned char* ytb = reinterpret_cast<const unsigned char*>(sm.yt[c & 1]);
       bf16_t* yc = ygw + (int64_t)t0 * a.ysl;
@@ -741,17 +891,26 @@ __global__ __launch_bounds__(Roles<PW>::NWAVES * 64) void ssd_slice_kernel(Slice
     if (BD > 1 && nchunks > 1) issue_bc(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     SLICE_BARRIER();   // P1
-    SLICE_BARRIER();   // P2
+    SLICE_BARRIER();   // P2 (chunks 0 / 1 prepared)
     scale_mine(0);
+    scale_b(0);
     SLICE_BARRIER();   // P3
     for (int c = 0; c < nchunks; ++c) {
       const bool issued = c + BD < nchunks && !SDBG(a, 2);
       if (issued) issue_bc(c + BD);
-      if (c > 1 && !SDBG(a, 4)) store_y_half(c - 2);   // written by the slice-waves at the start of step c-1
-      if (c + 1 < nchunks && !SDBG(a, 16)) scale_mine(c + 1);
-      // chunk c+1 must have landed; chunk c+2 (this step's 2 KP copies) stays in flight
-      if (BD > 1 && issued) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * KP) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (RL::WIDE && BSCALE) {
+        // chunk c+1 (issued a step ago) must have landed: it is scaled now and read after this step's barrier;
+        // this step's copies stay in flight
+        if (issued) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * KP) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (c + 1 < nchunks && !SDBG(a, 16)) scale_b(c + 1);
+      } else {
+        if (c > 1 && !SDBG(a, 4)) store_y_half(c - 2);   // written by the slice-waves at the start of step c-1
+        if (c + 1 < nchunks && !SDBG(a, 16)) scale_mine(c + 1);
+        // chunk c+1 must have landed; chunk c+2 (this step's 2 KP copies) stays in flight
+        if (BD > 1 && issued) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * KP) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       SLICE_BARRIER();
     }
     if (nchunks > 1) store_y_half(nchunks - 2);
@@ -916,7 +1075,7 @@ __global__ __launch_bounds__(Roles<PW>::NWAVES * 64) void ssd_slice_kernel(Slice
 }
 
 // wide = whole-head work-groups (one slice of up to 80 columns, 5 slice-waves)
-bool pick_slices(int P, int* nslices, int* pw, bool wide = false) {
+bool pick_slices(int P, int* nslices, int* pw, int wide = 0) {
   if (wide) {
     if (P > 48 && P <= 80 && P % 8 == 0) {
       *nslices = 1;
@@ -937,14 +1096,14 @@ bool pick_slices(int P, int* nslices, int* pw, bool wide = false) {
   return false;
 }
 
-template <int PT, int PW>
+template <int PT, int PW, bool W12 = false>
 hipError_t launch_slice(const SliceArgs& a, dim3 grid, hipStream_t st) {
   const size_t lds = sizeof(SliceSmem<PW>);
   static_assert(sizeof(SliceSmem<PW>) <= 160 * 1024, "LDS budget");
-  hipError_t e = hipFuncSetAttribute((const void*)ssd_slice_kernel<PT, PW>,
+  hipError_t e = hipFuncSetAttribute((const void*)ssd_slice_kernel<PT, PW, W12>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  ssd_slice_kernel<PT, PW><<<grid, Roles<PW>::NWAVES * 64, lds, st>>>(a);
+  ssd_slice_kernel<PT, PW, W12><<<grid, Roles<PW, W12>::NWAVES * 64, lds, st>>>(a);
   return hipSuccess;
 }
 
@@ -962,7 +1121,7 @@ struct SegLayout {
   size_t cb, seg_state, seg_decay, sin, corr, ctot, total;
   int nseg, seg_chunks;
 };
-SegLayout seg_layout(int batch, int seqlen, int nheads, int headdim, int ngroups, bool wide) {
+SegLayout seg_layout(int batch, int seqlen, int nheads, int headdim, int ngroups, int wide) {
   SegLayout l;
   const size_t nchunks = (size_t)(seqlen + SQ - 1) / SQ;
   auto up = [](size_t v) { return (v + 255) / 256 * 256; };
@@ -1019,21 +1178,22 @@ extern "C" int tv_ssd_slice_debug_stamps(unsigned long long* out) {
 bool tv_ssd_slice_supported(int seqlen, int nheads, int headdim, int ngroups, int dstate,
                             int dtype, int64_t xsl, int64_t bsl, int64_t bsg, int64_t csl,
                             int64_t csg, int64_t ysl, const void* x, const void* Bm,
-                            const void* Cm, const void* y, bool wide) {
+                            const void* Cm, const void* y, int wide) {
   int ns, pw;
   if (dtype != TV_BF16 || dstate != SN || seqlen < 1) return false;
   if (!pick_slices(headdim, &ns, &pw, wide)) return false;
   if (xsl % 8 || bsl % 8 || csl % 8 || bsg % 8 || csg % 8 || ysl % 8 || nheads % 2) return false;
   if (((uintptr_t)x & 15) || ((uintptr_t)Bm & 15) || ((uintptr_t)Cm & 15) || ((uintptr_t)y & 15))
     return false;
-  if (64 * xsl * 2 >= (1ll << 31) || 64 * bsl * 2 >= (1ll << 31) || 64 * csl * 2 >= (1ll << 31))
+  if (64 * xsl * 2 >= (1ll << 31) || 64 * bsl * 2 >= (1ll << 31) || 64 * csl * 2 >= (1ll << 31) ||
+      64 * ysl * 2 >= (1ll << 31))
     return false;
   (void)ngroups;
   return true;
 }
 
 size_t tv_ssd_slice_workspace_bytes(int batch, int seqlen, int nheads, int headdim, int ngroups, int,
-                                    bool wide) {
+                                    int wide) {
   return seg_layout(batch, seqlen, nheads, headdim, ngroups, wide).total;
 }
 
@@ -1045,7 +1205,7 @@ int tv_ssd_slice_launch(const void* x, const void* dt, const void* A, const void
                         int64_t bsl, int64_t bsg, int64_t csb, int64_t csl, int64_t csg,
                         int64_t ysb, int64_t ysl, int dtype, int dt_softplus, float dt_min,
                         float dt_max, int group_map, void* workspace, size_t workspace_bytes,
-                        bool wide, hipStream_t st) {
+                        int wide, const void* cb_pre, hipStream_t st) {
   (void)dtype; (void)dstate;
   const SegLayout lay = seg_layout(batch, seqlen, nheads, headdim, ngroups, wide);
   const size_t need = lay.total;
@@ -1054,7 +1214,7 @@ int tv_ssd_slice_launch(const void* x, const void* dt, const void* A, const void
                workspace_bytes);
   SliceArgs a;
   a.x = (const bf16_t*)x; a.dt = (const bf16_t*)dt; a.Bm = (const bf16_t*)Bm; a.Cm = (const bf16_t*)Cm;
-  a.cb = (const bf16_t*)workspace;
+  a.cb = cb_pre ? (const bf16_t*)cb_pre : (const bf16_t*)workspace;     // C.B^T fragments: the caller's (tv_causal_conv1d_xbc_cb_fwd) or the pre-pass's
   a.A = (const float*)A; a.D = (const float*)D; a.dt_bias = (const float*)dt_bias;
   a.init = (const float*)init_state; a.y = (bf16_t*)y; a.final_state = (float*)final_state;
   a.total_decay = (float*)total_decay;
@@ -1075,7 +1235,7 @@ int tv_ssd_slice_launch(const void* x, const void* dt, const void* A, const void
   ca.Bm = a.Bm; ca.Cm = a.Cm; ca.cb = (bf16_t*)workspace;
   ca.L = seqlen; ca.G = ngroups; ca.nchunks = a.nchunks;
   ca.bsb = bsb; ca.bsl = bsl; ca.bsg = bsg; ca.csb = csb; ca.csl = csl; ca.csg = csg;
-  ssd_cb_kernel<<<dim3(a.nchunks, ngroups, batch), 192, 0, st>>>(ca);
+  if (!cb_pre) ssd_cb_kernel<<<dim3(a.nchunks, ngroups, batch), 192, 0, st>>>(ca);
 
   dim3 grid(nheads * a.nslices, batch, a.nseg);
   hipError_t e = hipSuccess;
@@ -1085,10 +1245,11 @@ int tv_ssd_slice_launch(const void* x, const void* dt, const void* A, const void
     case 24: e = launch_slice<2, 24>(a, grid, st); break;
     case 32: e = launch_slice<2, 32>(a, grid, st); break;
     case 40: e = launch_slice<3, 40>(a, grid, st); break;
-    case 56: e = launch_slice<2, 56>(a, grid, st); break;      // wide: PT slice-waves x 2 column tiles
-    case 64: e = launch_slice<2, 64>(a, grid, st); break;
-    case 72: e = launch_slice<3, 72>(a, grid, st); break;
-    case 80: e = launch_slice<3, 80>(a, grid, st); break;
+    // wide (mode 1): PT slice-waves x 2 column tiles, 8 waves; wide12 (mode 2): one tile per slice-wave, 12 waves
+    case 56: e = wide == 2 ? launch_slice<4, 56, true>(a, grid, st) : launch_slice<2, 56>(a, grid, st); break;
+    case 64: e = wide == 2 ? launch_slice<4, 64, true>(a, grid, st) : launch_slice<2, 64>(a, grid, st); break;
+    case 72: e = wide == 2 ? launch_slice<5, 72, true>(a, grid, st) : launch_slice<3, 72>(a, grid, st); break;
+    case 80: e = wide == 2 ? launch_slice<5, 80, true>(a, grid, st) : launch_slice<3, 80>(a, grid, st); break;
     default: TV_UNSUPPORTED("ssd_slice: slice width %d", a.pw);
   }
   if (e != hipSuccess) {

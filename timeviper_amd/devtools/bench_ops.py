@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--ops", default="scan,conv,gnorm,rmsnorm,attn,patch,gather")
     ap.add_argument("--impl", type=int, default=0)
     ap.add_argument("--token-major", action="store_true", help="B/C as column slices of the conv rows")
+    ap.add_argument("--model-dt", action="store_true", help="dt_bias / dt as in the 9B model's init (slowly forgetting heads)")
+    ap.add_argument("--no-cb", action="store_true", help="scan recomputes C.B^T in its pre-pass (round 2)")
     a = ap.parse_args()
     L = a.tokens
     dev = "cuda"
@@ -52,17 +54,26 @@ def main():
             conv = K.causal_conv1d_fn(xBC.transpose(1, 2), w, b, activation="silu").transpose(1, 2)
             x, Bm, Cm = conv.split([d_in, G * N, G * N], dim=-1)
             Bm, Cm = Bm.view(1, L, G, N), Cm.view(1, L, G, N)
+            cb = None
         else:
-            x, Bm, Cm = K.causal_conv1d_xbc(xBC, w, b, d_in, G, N)
-            ms = timeit(lambda: K.causal_conv1d_xbc(xBC, w, b, d_in, G, N))
+            x, Bm, Cm, cb = K.causal_conv1d_xbc(xBC, w, b, d_in, G, N, return_cb=True)
+            if a.no_cb:
+                cb = None
+            ms = timeit(lambda: K.causal_conv1d_xbc(xBC, w, b, d_in, G, N, return_cb=not a.no_cb))
             by = L * 2 * 2 * conv_dim
-            print(f"conv1d xbc  {ms*1e3:9.1f} us  {by/ms/1e6:8.1f} GB/s  ({by/ms/1e6/8000:.1%} of 8 TB/s)")
+            print(f"conv1d xbc  {ms*1e3:9.1f} us  {by/ms/1e6:8.1f} GB/s  ({by/ms/1e6/8000:.1%} of 8 TB/s)"
+                  f"  {'+ C.B^T fragments' if cb is not None else ''}")
         A = -(torch.rand(H, device=dev, generator=g) * 15 + 1)
         D = torch.ones(H, device=dev)
-        dtb = torch.full((H,), -3.0, device=dev)
+        if a.model_dt:      # the 9B model's initialisation (modeling_nano.py:1345-1357): dt in [1e-3, 0.1], slow heads exist
+            dtv = torch.exp(torch.rand(H, device=dev, generator=g) * (math.log(0.1) - math.log(1e-3)) + math.log(1e-3))
+            dtb = dtv + torch.log(-torch.expm1(-dtv))
+            dt = (dt.float() * 0.02).bfloat16()
+        else:
+            dtb = torch.full((H,), -3.0, device=dev)
         fn = lambda: K.mamba_chunk_scan_combined(x.view(1, L, H, P), dt, A, Bm, Cm,
                                                  chunk_size=128, D=D, dt_bias=dtb,
-                                                 dt_softplus=True, return_final_states=True)
+                                                 dt_softplus=True, return_final_states=True, cb=cb)
         ms = timeit(fn, iters=5 if a.impl == 1 else 10)
         by = L * (2 * d_in * 2 + 2 * H + 4 * G * N)
         print(f"ssd_scan    {ms*1e3:9.1f} us  {by/ms/1e6:8.1f} GB/s  ({by/ms/1e6/8000:.1%} of 8 TB/s)  impl={a.impl}")

@@ -245,16 +245,16 @@ class SequenceParallelTimeViper:
                 if need:        # sequence start reached: zeros in front, like the unsharded conv
                     halo = torch.cat([halo.new_zeros((Bsz, need, halo.shape[-1])), halo], dim=1)
                 halo = halo.contiguous()
-        x, Bm, Cm = K.causal_conv1d_xbc(xBC, mixer.conv1d.weight.squeeze(1), mixer.conv1d.bias,
-                                        d_in, mixer.n_groups, mixer.ssm_state_size,
-                                        activation=mixer.activation, halo=halo)
+        x, Bm, Cm, cb = K.causal_conv1d_xbc(xBC, mixer.conv1d.weight.squeeze(1), mixer.conv1d.bias,
+                                            d_in, mixer.n_groups, mixer.ssm_state_size,
+                                            activation=mixer.activation, halo=halo, return_cb=True)
         xh = x.view(Bsz, L, mixer.num_heads, mixer.head_dim)
         kw = dict(chunk_size=mixer.chunk_size, D=mixer.D, dt_bias=mixer.dt_bias, dt_softplus=True,
                   return_final_states=True, group_map=mixer.group_map)
         if mixer.time_step_limit != (0.0, float("inf")):
             kw["dt_limit"] = mixer.time_step_limit
         A = mixer._neg_A()
-        y, S, dec = K.mamba_chunk_scan_combined(xh, dt, A, Bm, Cm, return_total_decay=True, **kw)
+        y, S, dec = K.mamba_chunk_scan_combined(xh, dt, A, Bm, Cm, return_total_decay=True, cb=cb, **kw)
         S_all = all_gather_stack(S, self.group)
         d_all = all_gather_stack(dec, self.group)
         if self.rank > 0 and L > 0:

@@ -107,11 +107,14 @@ def causal_conv1d_fn(x, weight, bias=None, seq_idx=None, initial_states=None,
 
 
 def causal_conv1d_xbc(xBC, weight, bias, d_inner: int, ngroups: int, dstate: int,
-                      activation="silu", halo=None):
+                      activation="silu", halo=None, return_cb: bool = False):
     """Mamba-2 mixer variant of causal_conv1d_fn + the [x | B | C] split of
     modeling_nano.py:628-636 in one pass.  xBC (B, L, d_inner + 2*G*N) (any row stride).
     Returns x (B, L, d_inner) and B, C as (B, L, G, N) VIEWS of group-major (B, G, L, N)
-    storage — the layout the scan kernel streams best."""
+    storage — the layout the scan kernel streams best.
+    `return_cb`: also return the causal C.B^T fragments of every (chunk, group) for
+    `mamba_chunk_scan_combined(..., cb=...)` (an opaque bf16 tensor; None where the scan would
+    not use them: other dtypes / d_state), computed while the B / C tiles are on the chip."""
     _gpu(xBC, weight, bias, halo)
     Bsz, L, Cc = xBC.shape
     assert Cc == d_inner + 2 * ngroups * dstate
@@ -125,10 +128,20 @@ def causal_conv1d_xbc(xBC, weight, bias, d_inner: int, ngroups: int, dstate: int
     yx = torch.empty((Bsz, L, d_inner), dtype=xBC.dtype, device=xBC.device)
     yb = torch.empty((Bsz, ngroups, L, dstate), dtype=xBC.dtype, device=xBC.device)
     yc = torch.empty((Bsz, ngroups, L, dstate), dtype=xBC.dtype, device=xBC.device)
-    check(_capi.lib().tv_causal_conv1d_xbc_fwd(
+    lib = _capi.lib()
+    if return_cb and xBC.dtype == torch.bfloat16 and dstate == 128 and L > 0:
+        cb = torch.empty(lib.tv_ssd_cb_bytes(Bsz, L, ngroups) // 2, dtype=torch.bfloat16, device=xBC.device)
+        check(lib.tv_causal_conv1d_xbc_cb_fwd(
+            _p(xBC), _p(w), _p(b), _p(halo), _p(yx), _p(yb), _p(yc), _p(cb), Bsz, L, d_inner, ngroups, dstate,
+            K, xBC.stride(0), xBC.stride(1), _dt(xBC), int(activation in ("silu", "swish")), _stream()),
+            "tv_causal_conv1d_xbc_cb_fwd")
+        return yx, yb.transpose(1, 2), yc.transpose(1, 2), cb
+    check(lib.tv_causal_conv1d_xbc_fwd(
         _p(xBC), _p(w), _p(b), _p(halo), _p(yx), _p(yb), _p(yc), Bsz, L, d_inner, ngroups, dstate,
         K, xBC.stride(0), xBC.stride(1), _dt(xBC), int(activation in ("silu", "swish")), _stream()),
         "tv_causal_conv1d_xbc_fwd")
+    if return_cb:
+        return yx, yb.transpose(1, 2), yc.transpose(1, 2), None
     return yx, yb.transpose(1, 2), yc.transpose(1, 2)
 
 
@@ -254,12 +267,13 @@ def mamba_chunk_scan_combined(x, dt, A, B, C, chunk_size=None, D=None, z=None, d
                               initial_states=None, seq_idx=None, cu_seqlens=None,
                               dt_softplus=False, dt_limit=(0.0, float("inf")),
                               return_final_states=False, return_varlen_states=False,
-                              group_map="block", return_total_decay=False):
+                              group_map="block", return_total_decay=False, cb=None):
     """x (B,L,H,P), dt (B,L,H), A (H), B/C (B,L,G,N), D (H), dt_bias (H),
     initial_states (B,H,P,N).  Returns y (B,L,H,P) [, final_states (B,H,P,N) fp32]
     [, total_decay (B,H) fp32].  `chunk_size` is accepted for signature parity
     and ignored (the result is chunk-invariant).  `group_map`: "block"
-    (h // (H/G), GPU reference) or "tile" (h % G, reference CPU quirk)."""
+    (h // (H/G), GPU reference) or "tile" (h % G, reference CPU quirk).
+    `cb`: the C.B^T fragments `causal_conv1d_xbc(..., return_cb=True)` returned for these B / C."""
     if z is not None or seq_idx is not None or cu_seqlens is not None or return_varlen_states:
         raise TimeViperHipError("mamba_chunk_scan_combined: z/seq_idx/cu_seqlens unsupported")
     if D is not None and D.dim() != 1:
@@ -292,12 +306,16 @@ def mamba_chunk_scan_combined(x, dt, A, B, C, chunk_size=None, D=None, z=None, d
     lib = _capi.lib()
     ws_bytes = lib.tv_ssd_scan_workspace_bytes(Bsz, L, H, P, G, N, _dt(x))
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
-    check(lib.tv_ssd_scan_fwd(
-        _p(x), _p(dt), _p(A), _p(B), _p(C), _p(D), _p(dt_bias), _p(initial_states), _p(y),
+    if cb is not None:
+        _gpu(cb)
+        if cb.dtype != torch.bfloat16 or cb.numel() * 2 != lib.tv_ssd_cb_bytes(Bsz, L, G) or not cb.is_contiguous():
+            raise TimeViperHipError("mamba_chunk_scan_combined: cb is not the C.B^T buffer of these shapes")
+    check(lib.tv_ssd_scan_cb_fwd(
+        _p(x), _p(dt), _p(A), _p(B), _p(C), _p(cb), _p(D), _p(dt_bias), _p(initial_states), _p(y),
         _p(final), _p(decay), Bsz, L, H, P, G, N, xsb, xsl, dsb, dsl, bsb, bsl, bsg, csb, csl, csg,
         y.stride(0), y.stride(1), _dt(x), int(bool(dt_softplus)), float(dt_limit[0]),
         float(min(dt_limit[1], 3.0e38)), {"block": 0, "tile": 1}[group_map], _p(ws), ws_bytes,
-        _stream()), "tv_ssd_scan_fwd")
+        _stream()), "tv_ssd_scan_cb_fwd")
     out = (y,)
     if return_final_states:
         out += (final,)

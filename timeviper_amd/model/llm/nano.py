@@ -289,9 +289,10 @@ class NemotronHMamba2Mixer(nn.Module):
             cache_params.update_conv_state(self.layer_idx, cs.contiguous(), cache_init=True)
         # causal_conv1d_fn (:619-624) + the x|B|C split (:628-636) in one pass; B and C come
         # back as (B, L, G, N) views of group-major storage
-        x, Bm, Cm = K.causal_conv1d_xbc(xBC, w, self.conv1d.bias, d_in, self.n_groups,
-                                        self.ssm_state_size, activation=self.activation,
-                                        halo=conv_halo)
+        # (+ the scan's causal C.B^T fragments, multiplied while the B / C tiles are on the chip)
+        x, Bm, Cm, cb = K.causal_conv1d_xbc(xBC, w, self.conv1d.bias, d_in, self.n_groups,
+                                            self.ssm_state_size, activation=self.activation,
+                                            halo=conv_halo, return_cb=True)
         dt_limit = {} if self.time_step_limit == (0.0, float("inf")) \
             else {"dt_limit": self.time_step_limit}
         res = K.mamba_chunk_scan_combined(
@@ -299,7 +300,7 @@ class NemotronHMamba2Mixer(nn.Module):
             chunk_size=self.chunk_size, D=self.D,
             z=None, seq_idx=None, return_final_states=True, dt_bias=self.dt_bias, dt_softplus=True,
             initial_states=initial_states, group_map=self.group_map,
-            return_total_decay=return_shard_state, **dt_limit)
+            return_total_decay=return_shard_state, cb=cb, **dt_limit)
         scan_output, ssm_state = res[0], res[1]
         if cache_params is not None:
             cache_params.update_ssm_state(self.layer_idx, ssm_state)
