@@ -149,7 +149,7 @@ def run_scan(K, x, dt, A, Bm, Cm, D, dt_bias, **kw):
                                        return_final_states=True, return_total_decay=True, **kw)
 
 
-@pytest.mark.parametrize("impl", [1, 0, 2, 3, 4, 5])
+@pytest.mark.parametrize("impl", [1, 0, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("dtype,B,L,H,P,G,N", [
     (torch.float32, 1, 1024, 32, 64, 1, 16),      # BASELINE config 1
     (torch.float32, 2, 77, 8, 8, 2, 16),
@@ -194,7 +194,7 @@ def test_ssd_scan_initial_state_and_sharding(K, dtype, H, P, G, N):
     close(f1, fin_ref, rt, at)
 
 
-@pytest.mark.parametrize("impl", [2, 3, 4, 5])
+@pytest.mark.parametrize("impl", [2, 3, 4, 5, 6])
 @pytest.mark.parametrize("B,L,H,P,G", [(1, 1000, 16, 80, 8), (2, 449, 8, 64, 2), (1, 64, 4, 48, 1),
                                        (1, 2049, 8, 80, 4), (1, 130, 4, 128, 2), (1, 65, 6, 24, 3),
                                        (1, 5000, 8, 80, 8), (1, 4100, 4, 72, 2), (2, 2500, 4, 56, 1)])

@@ -255,11 +255,14 @@ __global__ __launch_bounds__(256) void conv1d_bc_cb_kernel(
       d0 = mfma16(b0[si][ks], cf[ci][ks], d0);
       d1 = mfma16(b1[si][ks], cf[ci][ks], d1);
     }
+    // elements above the diagonal (s > t) are stored as zeros: the head-per-wave march uses the fragments as they are
+    const int f_ti = f == 0 ? 0 : f == 1 ? 1 : f < 4 ? 2 : 3, f_sp = (f == 3 || f == 5) ? 1 : 0;
+    const int t_in = 16 * f_ti + lc, s_in = 32 * f_sp + 8 * kq;
     bf16x8 o;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      o[r] = (bf16_t)d0[r];
-      o[4 + r] = (bf16_t)d1[r];
+      o[r] = s_in + r <= t_in ? (bf16_t)d0[r] : (bf16_t)0.f;
+      o[4 + r] = s_in + 4 + r <= t_in ? (bf16_t)d1[r] : (bf16_t)0.f;
     }
     *(bf16x8*)(cb + ((((int64_t)b * G + g) * nchunks + c) * CB_FRAGS + f) * 512 + lane * 8) = o;
   }

@@ -37,7 +37,12 @@ struct CorrArgs {
   const bf16_t *dt, *Cm;
   const float *A, *dt_bias, *state;
   float *tot, *pre;
-  int L, H, P, G, nchunks;
+  const bf16_t* state16;           // S_in as bf16 (the all-segments pass: written by ssd_seg_chain_kernel), or NULL: `state` (fp32)
+  int L, H, P, G, nchunks;         // nchunks: chunks of the whole sequence (row length of `pre`)
+  // the ranges that are corrected: nsegc of them per batch entry (blockIdx.z = b * nsegc + si), range si covering the
+  // chunks [(si + first_seg) * seg_chunks, + seg_chunks) of the sequence, its entering state at state[si][b][h];
+  // the stand-alone operator has one range = the whole sequence (nsegc 1, first_seg 0, seg_chunks = nchunks)
+  int nsegc, first_seg, seg_chunks;
   int64_t tot_stride;              // elements between the (b, h) rows of `tot`
   int64_t ysb, ysl, dsb, dsl, csb, csl, csg;
   int softplus, group_map;
@@ -62,37 +67,46 @@ __global__ __launch_bounds__(256) void ssd_chunk_decay_kernel(CorrArgs a) {
   if (lane == 0) a.tot[((int64_t)b * a.H + h) * a.nchunks + c] = s * a.A[h] * 1.4426950408889634f;
 }
 
-// grid (H, B), one wave: pre[b][h][c] = sum_{c' < c} tot[b][h][c']
+// grid (H, B * nsegc), one wave: pre[b][h][c] = sum_{first chunk of c's range <= c' < c} tot[b][h][c']
 __global__ __launch_bounds__(64) void ssd_decay_prefix_kernel(CorrArgs a) {
-  const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
-  const float* t = a.tot + ((int64_t)b * a.H + h) * a.tot_stride;
-  float* p = a.pre + ((int64_t)b * a.H + h) * a.nchunks;
+  const int h = blockIdx.x, b = blockIdx.y / a.nsegc, si = blockIdx.y % a.nsegc, lane = threadIdx.x;
+  const int cbeg = (si + a.first_seg) * a.seg_chunks;
+  const int nch = min(a.seg_chunks, a.nchunks - cbeg);
+  const float* t = a.tot + ((int64_t)b * a.H + h) * a.tot_stride + cbeg;
+  float* p = a.pre + ((int64_t)b * a.H + h) * a.nchunks + cbeg;
   float carry = 0.f;
-  for (int c0 = 0; c0 < a.nchunks; c0 += 64) {
-    const float v = c0 + lane < a.nchunks ? t[c0 + lane] : 0.f;
+  for (int c0 = 0; c0 < nch; c0 += 64) {
+    const float v = c0 + lane < nch ? t[c0 + lane] : 0.f;
     const float inc = wave_incl_scan_dpp(v);
-    if (c0 + lane < a.nchunks) p[c0 + lane] = carry + inc - v;
+    if (c0 + lane < nch) p[c0 + lane] = carry + inc - v;
     carry += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inc), 63));
   }
 }
 
-// grid (CSLOTS, H, B), 256 threads.  PT = ceil(P / 16) column tiles.
+// grid (slots, H, B * nsegc), 256 threads.  PT = ceil(P / 16) column tiles.  Work-group `slot` of a (head, range)
+// walks the chunks slot, slot + gridDim.x, ... of its range.
 template <int PT>
 __global__ __launch_bounds__(256) void ssd_correct_kernel(CorrArgs a) {
   constexpr int LDW = PT * 16 + 4;                  // padded fp32 row of the staging tile
   __shared__ float ef[CQ];
   __shared__ __attribute__((aligned(16))) float tile[CQ * LDW];
-  const int h = blockIdx.y, b = blockIdx.z;
+  const int h = blockIdx.y, b = blockIdx.z / a.nsegc, si = blockIdx.z % a.nsegc;
+  const int nslots = gridDim.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lc = lane & 15, kq = lane >> 4;
   const int hpg = a.H / a.G;
   const int g = a.group_map ? (h % a.G) : (h / hpg);
-  const float* pre = a.pre + ((int64_t)b * a.H + h) * a.nchunks;
-  if (pre[blockIdx.x < a.nchunks ? blockIdx.x : 0] < C_UNDERFLOW || (int)blockIdx.x >= a.nchunks) return;
+  const int cbeg = (si + a.first_seg) * a.seg_chunks;          // first chunk / token of the range
+  const int tbeg = cbeg * CQ;
+  const int nch = min(a.seg_chunks, a.nchunks - cbeg);
+  if (nch <= 0 || (int)blockIdx.x >= nch) return;
+  const int L = min(a.L - tbeg, nch * CQ);
+  const float* pre = a.pre + ((int64_t)b * a.H + h) * a.nchunks + cbeg;
+  if (pre[blockIdx.x] < C_UNDERFLOW) return;
 
   // S_in as B operand: lane (col lc, kq) of tile ct, k-step ks holds S[p = 16 ct + lc][n = 32 ks + 8 kq + 0..7]
   bf16x8 sf[PT][4];
-  const float* sp = a.state + ((int64_t)b * a.H + h) * a.P * CN;
+  const int64_t sbase = (((int64_t)si * (gridDim.z / a.nsegc) + b) * a.H + h) * a.P * CN;
 #pragma unroll
   for (int ct = 0; ct < PT; ++ct) {
     const int p = 16 * ct + lc;
@@ -100,18 +114,23 @@ __global__ __launch_bounds__(256) void ssd_correct_kernel(CorrArgs a) {
     for (int ks = 0; ks < 4; ++ks) {
       bf16x8 v = {};
       if (p < a.P) {
-        const f32x4 lo = *(const f32x4*)(sp + (int64_t)p * CN + 32 * ks + 8 * kq);
-        const f32x4 hi = *(const f32x4*)(sp + (int64_t)p * CN + 32 * ks + 8 * kq + 4);
+        if (a.state16) {
+          v = *(const bf16x8*)(a.state16 + sbase + (int64_t)p * CN + 32 * ks + 8 * kq);
+        } else {
+          const float* sp = a.state + sbase;
+          const f32x4 lo = *(const f32x4*)(sp + (int64_t)p * CN + 32 * ks + 8 * kq);
+          const f32x4 hi = *(const f32x4*)(sp + (int64_t)p * CN + 32 * ks + 8 * kq + 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { v[j] = (bf16_t)lo[j]; v[4 + j] = (bf16_t)hi[j]; }
+          for (int j = 0; j < 4; ++j) { v[j] = (bf16_t)lo[j]; v[4 + j] = (bf16_t)hi[j]; }
+        }
       }
       sf[ct][ks] = v;
     }
   }
   const float Ah = a.A[h] * 1.4426950408889634f;
-  const bf16_t* dp = a.dt + (int64_t)b * a.dsb + h;
-  const bf16_t* cp = a.Cm + (int64_t)b * a.csb + (int64_t)g * a.csg;
-  bf16_t* yp = a.y + (int64_t)b * a.ysb + (int64_t)h * a.P;
+  const bf16_t* dp = a.dt + (int64_t)b * a.dsb + (int64_t)tbeg * a.dsl + h;
+  const bf16_t* cp = a.Cm + (int64_t)b * a.csb + (int64_t)g * a.csg + (int64_t)tbeg * a.csl;
+  bf16_t* yp = a.y + (int64_t)b * a.ysb + (int64_t)tbeg * a.ysl + (int64_t)h * a.P;
   const int nvec = a.P / 8;                          // 16-byte pieces per y row
 
   // One chunk per iteration; the C rows, the dt value and the prefix of the NEXT chunk of this work-group and the y
@@ -121,29 +140,29 @@ __global__ __launch_bounds__(256) void ssd_correct_kernel(CorrArgs a) {
   constexpr int NY = (CQ * 2 * PT + 255) / 256;      // y pieces per thread (rows of at most 16 PT columns)
   auto fetch = [&](int c, bf16x8 (&cf)[4], float& draw, float& p0) {
     const int t0 = c * CQ;
-    const int trow = min(t0 + 16 * wave + lc, a.L - 1);       // rows past the end repeat the last row: finite
+    const int trow = min(t0 + 16 * wave + lc, L - 1);         // rows past the end repeat the last row: finite
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) cf[ks] = *(const bf16x8*)(cp + (int64_t)trow * a.csl + 32 * ks + 8 * kq);
     const int t = t0 + lane;
-    draw = (wave == 0 && t < a.L) ? (float)dp[(int64_t)t * a.dsl] : 0.f;
+    draw = (wave == 0 && t < L) ? (float)dp[(int64_t)t * a.dsl] : 0.f;
     p0 = pre[c];
   };
   bf16x8 cf[4], cfn[4];
   float draw, drawn = 0.f, p0, p0n = 0.f;
   fetch(blockIdx.x, cf, draw, p0);
-  for (int c = blockIdx.x; c < a.nchunks; c += CSLOTS) {
+  for (int c = blockIdx.x; c < nch; c += nslots) {
     if (p0 < C_UNDERFLOW) break;                     // the prefix only decreases: nothing left for this head
     const int t0 = c * CQ;
-    const bool more = c + CSLOTS < a.nchunks;
-    if (more) fetch(c + CSLOTS, cfn, drawn, p0n);
+    const bool more = c + nslots < nch;
+    if (more) fetch(c + nslots, cfn, drawn, p0n);
     bf16x8 yv[NY];
 #pragma unroll
     for (int k = 0; k < NY; ++k) {
       const int i = tid + 256 * k, row = i / nvec, ch = i % nvec;
-      if (i < CQ * nvec && t0 + row < a.L) yv[k] = *(const bf16x8*)(yp + (int64_t)(t0 + row) * a.ysl + 8 * ch);
+      if (i < CQ * nvec && t0 + row < L) yv[k] = *(const bf16x8*)(yp + (int64_t)(t0 + row) * a.ysl + 8 * ch);
     }
     if (wave == 0) {
-      const float d = t0 + lane < a.L ? disc_dt(a, draw, h) : 0.f;
+      const float d = t0 + lane < L ? disc_dt(a, draw, h) : 0.f;
       const float cs = wave_incl_scan_dpp(d * Ah);
       ef[lane] = __builtin_amdgcn_exp2f(p0 + cs);
     }
@@ -166,7 +185,7 @@ __global__ __launch_bounds__(256) void ssd_correct_kernel(CorrArgs a) {
 #pragma unroll
     for (int k = 0; k < NY; ++k) {
       const int i = tid + 256 * k, row = i / nvec, ch = i % nvec;
-      if (i < CQ * nvec && t0 + row < a.L) {
+      if (i < CQ * nvec && t0 + row < L) {
         bf16x8 v = yv[k];
         const f32x4 lo = *(const f32x4*)(tile + row * LDW + 8 * ch);
         const f32x4 hi = *(const f32x4*)(tile + row * LDW + 8 * ch + 4);
@@ -182,6 +201,51 @@ __global__ __launch_bounds__(256) void ssd_correct_kernel(CorrArgs a) {
     for (int ks = 0; ks < 4; ++ks) cf[ks] = cfn[ks];
     draw = drawn;
     p0 = p0n;
+  }
+}
+
+// Chain of the per-segment results of a segmented march (segments > 0 marched from a zero state):
+//   run = seg_state[0];  for s >= 1:  S_in(s) = run (stored as bf16: the correction's MFMA operand);
+//   run = exp(decay[s]) run + seg_state[s];  final state = run;  total decay = sum of the segments'
+__global__ __launch_bounds__(256) void ssd_seg_chain_kernel(const float* __restrict__ seg_state,
+                                                            const float* __restrict__ seg_decay,
+                                                            bf16_t* __restrict__ sin16, float* __restrict__ final_state,
+                                                            float* __restrict__ total_decay, int nseg,
+                                                            int64_t bh, int64_t per_head) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;      // float4 index
+  const int64_t n4 = bh * per_head / 4;
+  if (i < n4) {
+    const int64_t head = (i * 4) / per_head;
+    f32x4 run = ((const f32x4*)seg_state)[i];
+    for (int s = 1; s < nseg; ++s) {
+      bf16x4 o = {(bf16_t)run[0], (bf16_t)run[1], (bf16_t)run[2], (bf16_t)run[3]};
+      ((bf16x4*)sin16)[(int64_t)(s - 1) * n4 + i] = o;
+      const float e = __expf(seg_decay[(int64_t)s * bh + head]);
+      const f32x4 cur = ((const f32x4*)seg_state)[(int64_t)s * n4 + i];
+      run = f32x4{e * run[0] + cur[0], e * run[1] + cur[1], e * run[2] + cur[2], e * run[3] + cur[3]};
+    }
+    if (final_state) ((f32x4*)final_state)[i] = run;
+  }
+  if (total_decay && i < bh) {
+    float t = 0.f;
+    for (int s = 0; s < nseg; ++s) t += seg_decay[(int64_t)s * bh + i];
+    total_decay[i] = t;
+  }
+}
+
+template <int PT> void launch_correct(const CorrArgs& a, dim3 grid, hipStream_t st) {
+  ssd_correct_kernel<PT><<<grid, 256, 0, st>>>(a);
+}
+void launch_correct_pt(const CorrArgs& a, dim3 grid, int headdim, hipStream_t st) {
+  switch ((headdim + 15) / 16) {
+    case 1: launch_correct<1>(a, grid, st); break;
+    case 2: launch_correct<2>(a, grid, st); break;
+    case 3: launch_correct<3>(a, grid, st); break;
+    case 4: launch_correct<4>(a, grid, st); break;
+    case 5: launch_correct<5>(a, grid, st); break;
+    case 6: launch_correct<6>(a, grid, st); break;
+    case 7: launch_correct<7>(a, grid, st); break;
+    default: launch_correct<8>(a, grid, st); break;
   }
 }
 
@@ -214,6 +278,8 @@ int tv_ssd_correct_launch(void* y, const void* dt, const void* A, const void* Cm
   a.ysb = ysb; a.ysl = ysl; a.dsb = dsb; a.dsl = dsl; a.csb = csb; a.csl = csl; a.csg = csg;
   a.softplus = dt_softplus; a.group_map = group_map; a.dt_min = dt_min; a.dt_max = dt_max;
   a.tot_stride = a.nchunks;
+  a.state16 = nullptr;
+  a.nsegc = 1; a.first_seg = 0; a.seg_chunks = a.nchunks;
   if (chunk_tot) {
     a.tot = const_cast<float*>(chunk_tot);
     a.tot_stride = chunk_tot_stride;
@@ -221,16 +287,48 @@ int tv_ssd_correct_launch(void* y, const void* dt, const void* A, const void* Cm
     ssd_chunk_decay_kernel<<<dim3(a.nchunks, (nheads + 3) / 4, batch), 256, 0, st>>>(a);
   }
   ssd_decay_prefix_kernel<<<dim3(nheads, batch), 64, 0, st>>>(a);
-  const dim3 grid(CSLOTS, nheads, batch);
-  switch ((headdim + 15) / 16) {
-    case 1: ssd_correct_kernel<1><<<grid, 256, 0, st>>>(a); break;
-    case 2: ssd_correct_kernel<2><<<grid, 256, 0, st>>>(a); break;
-    case 3: ssd_correct_kernel<3><<<grid, 256, 0, st>>>(a); break;
-    case 4: ssd_correct_kernel<4><<<grid, 256, 0, st>>>(a); break;
-    case 5: ssd_correct_kernel<5><<<grid, 256, 0, st>>>(a); break;
-    case 6: ssd_correct_kernel<6><<<grid, 256, 0, st>>>(a); break;
-    case 7: ssd_correct_kernel<7><<<grid, 256, 0, st>>>(a); break;
-    default: ssd_correct_kernel<8><<<grid, 256, 0, st>>>(a); break;
+  launch_correct_pt(a, dim3(CSLOTS, nheads, batch), headdim, st);
+  TV_LAUNCH_CHECK();
+}
+
+// All segments of a segmented march in three launches (chain, prefixes, correction): the head-per-wave march
+// (ssd_head.hip) cuts a sequence into up to 16 segments; one launch per boundary cost a fixed ~140 us each
+// (every one of 64 x heads work-groups loading the 40 KB fp32 state before looking at its first chunk).
+size_t tv_ssd_correct_all_workspace_bytes(int batch, int nheads, int nchunks, int nseg, int headdim) {
+  // pre (B, H, nchunks) fp32 + S_in of the nseg - 1 boundaries as bf16
+  return ((size_t)batch * nheads * nchunks * sizeof(float) + 255) / 256 * 256 +
+         (size_t)(nseg > 1 ? nseg - 1 : 0) * batch * nheads * headdim * CN * sizeof(bf16_t);
+}
+
+int tv_ssd_correct_all_launch(void* y, const void* dt, const void* A, const void* Cm, const void* dt_bias,
+                              const float* seg_state, const float* seg_decay, float* final_state,
+                              float* total_decay, const float* chunk_tot, int batch, int seqlen, int nheads,
+                              int headdim, int ngroups, int nseg, int seg_chunks, int64_t ysb, int64_t ysl,
+                              int64_t dsb, int64_t dsl, int64_t csb, int64_t csl, int64_t csg, int dt_softplus,
+                              float dt_min, float dt_max, int group_map, void* workspace, hipStream_t st) {
+  CorrArgs a;
+  a.y = (bf16_t*)y; a.dt = (const bf16_t*)dt; a.Cm = (const bf16_t*)Cm;
+  a.A = (const float*)A; a.dt_bias = (const float*)dt_bias; a.state = nullptr;
+  a.L = seqlen; a.H = nheads; a.P = headdim; a.G = ngroups;
+  a.nchunks = (seqlen + CQ - 1) / CQ;
+  a.pre = (float*)workspace;
+  bf16_t* sin16 = (bf16_t*)((unsigned char*)workspace + ((size_t)batch * nheads * a.nchunks * sizeof(float) + 255) / 256 * 256);
+  a.state16 = sin16;
+  a.tot = const_cast<float*>(chunk_tot);
+  a.tot_stride = a.nchunks;
+  a.ysb = ysb; a.ysl = ysl; a.dsb = dsb; a.dsl = dsl; a.csb = csb; a.csl = csl; a.csg = csg;
+  a.softplus = dt_softplus; a.group_map = group_map; a.dt_min = dt_min; a.dt_max = dt_max;
+  int nsegc = 0;                     // segments that exist (a short sequence may leave the last ones empty)
+  for (int s = 1; s < nseg; ++s) if ((int64_t)s * seg_chunks < a.nchunks) ++nsegc;
+  a.nsegc = nsegc > 0 ? nsegc : 1; a.first_seg = 1; a.seg_chunks = seg_chunks;
+  const int64_t bh = (int64_t)batch * nheads, per_head = (int64_t)headdim * CN;
+  const int64_t n4 = bh * per_head / 4;
+  ssd_seg_chain_kernel<<<dim3((unsigned)((n4 + 255) / 256)), 256, 0, st>>>(seg_state, seg_decay, sin16, final_state,
+                                                                         total_decay, nseg, bh, per_head);
+  if (nsegc > 0) {
+    ssd_decay_prefix_kernel<<<dim3(nheads, batch * nsegc), 64, 0, st>>>(a);
+    const int slots = seg_chunks < 16 ? seg_chunks : 16;
+    launch_correct_pt(a, dim3(slots, nheads, batch * nsegc), headdim, st);
   }
   TV_LAUNCH_CHECK();
 }

@@ -145,11 +145,14 @@ __global__ __launch_bounds__(192) void ssd_cb_kernel(CbArgs a) {
       d0 = mfma16(b0[si][ks], cf[ci][ks], d0);
       d1 = mfma16(b1[si][ks], cf[ci][ks], d1);
     }
+    // elements above the diagonal (s > t) are stored as zeros: the head-per-wave march uses the fragments as they are
+    const int f_ti = f == 0 ? 0 : f == 1 ? 1 : f < 4 ? 2 : 3, f_sp = (f == 3 || f == 5) ? 1 : 0;
+    const int t_in = 16 * f_ti + lc, s_in = 32 * f_sp + 8 * kq;
     bf16x8 o;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      o[r] = (bf16_t)d0[r];
-      o[4 + r] = (bf16_t)d1[r];
+      o[r] = s_in + r <= t_in ? (bf16_t)d0[r] : (bf16_t)0.f;
+      o[4 + r] = s_in + 4 + r <= t_in ? (bf16_t)d1[r] : (bf16_t)0.f;
     }
     bf16_t* dst = a.cb + ((((int64_t)b * a.G + g) * a.nchunks + c) * NFRAG + f) * 512 + lane * 8;
     *(bf16x8*)dst = o;
@@ -1113,6 +1116,7 @@ int pick_segments(int batch, int nheads, int nchunks) {
   const int wg = batch * nheads;
   int nseg = wg >= 192 ? 1 : 256 / wg;
   if (nseg > 4) nseg = 4;
+  if (const char* e = getenv("TV_SSD_NSEG")) nseg = atoi(e);      // dev tool: correction cost against the segment count
   while (nseg > 1 && nchunks / nseg < 16) --nseg;      // short sequences: not worth the fix-up passes
   return nseg < 1 ? 1 : nseg;
 }
@@ -1166,6 +1170,18 @@ __global__ __launch_bounds__(256) void ssd_seg_combine_kernel(const float* __res
 }
 
 }  // namespace
+
+// the C.B^T pre-pass on its own (ssd_head.hip; callers that got no fragments from the conv kernel)
+int tv_ssd_cb_prepass_launch(const void* Bm, const void* Cm, void* cb, int batch, int seqlen, int ngroups,
+                             int64_t bsb, int64_t bsl, int64_t bsg, int64_t csb, int64_t csl, int64_t csg,
+                             hipStream_t st) {
+  CbArgs ca;
+  ca.Bm = (const bf16_t*)Bm; ca.Cm = (const bf16_t*)Cm; ca.cb = (bf16_t*)cb;
+  ca.L = seqlen; ca.G = ngroups; ca.nchunks = (seqlen + SQ - 1) / SQ;
+  ca.bsb = bsb; ca.bsl = bsl; ca.bsg = bsg; ca.csb = csb; ca.csl = csl; ca.csg = csg;
+  ssd_cb_kernel<<<dim3(ca.nchunks, ngroups, batch), 192, 0, st>>>(ca);
+  TV_LAUNCH_CHECK();
+}
 
 #ifdef TV_SLICE_STAMP
 extern "C" int tv_ssd_slice_debug_stamps(unsigned long long* out) {
