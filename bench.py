@@ -27,6 +27,8 @@ import sys
 import time
 from pathlib import Path
 
+import math
+
 import torch
 
 ROOT = Path(__file__).resolve().parent
@@ -38,7 +40,7 @@ HBM_PEAK_GBS = 8000.0                                      # MI355X_MICROARCH.md
 
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0                             # dense bf16, MI355X_MICROARCH.md
-SCAN_SOURCES = ("ssd_slice.hip", "ssd_correct.hip", "ssd_scan.hip", "ssd_common.hpp")
+SCAN_SOURCES = ("ssd_head.hip", "ssd_slice.hip", "ssd_correct.hip", "ssd_scan.hip", "ssd_common.hpp", "conv1d.hip")
 
 
 def scan_bytes_per_token(cfg) -> int:
@@ -135,8 +137,9 @@ class OpTimers:
             else:
                 src = (f"profiles/{files[-1].name} was taken on other scan kernels (source id "
                        f"{tf.get('scan_source_id')}, tree {scan_source_id()}): re-run devtools/pmc_scan.sh")
-        return {"bound": "hbm", "kernel": "ssd_scan (tv_ssd_scan_fwd: ssd_cb_kernel + ssd_slice_kernel<3,80> x 2 "
-                                          "segments + ssd_seg_combine + ssd_correct kernels)",
+        return {"bound": "hbm", "kernel": "ssd_scan (tv_ssd_scan_cb_fwd: ssd_head_kernel<5,4,2> head-per-wave march x 8-16 "
+                                          "segments (+ its complete variant for flagged work-groups) + ssd_seg_chain + "
+                                          "ssd_decay_prefix + ssd_correct kernels)",
                 "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "traffic_source": src, "launches": len(r),
                 "avg_launch_us": round(ms * 1e3 / len(r), 1), "bytes_per_token": bytes_per_token}
@@ -234,6 +237,77 @@ def cpu_baseline(cfg, frames_sample=256, vit_frames=16):
                        f"over-estimates CPU throughput at long lengths)")}
 
 
+def config1_scan(args):
+    """BASELINE configs[0]: one Mamba-2 selective scan, B=1 L=1024, 32 heads x 64, d_state 16, fp32 — the one configuration
+    the reference's eager CPU path runs as it is.  Prints one JSON line: the HIP kernel's time (tv_ssd_scan_fwd picks the
+    generic fp32-recurrence kernel for this dtype / d_state), the oracle's time on the host cores, and the largest
+    deviation of the HIP result from the oracle and of the oracle from the reference's golden fixture."""
+    import numpy as np
+    from timeviper_amd.build import ensure_built
+    ensure_built()
+    from oracle import ops as R
+    from timeviper_amd import kernels as K
+    dev = torch.device("cuda", 0)
+    Bz, L, H, P, G, N = 1, 1024, 32, 64, 1, 16
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(Bz, L, H, P, generator=g)
+    dt = torch.randn(Bz, L, H, generator=g) * 0.5
+    A = -(torch.rand(H, generator=g) * 15 + 1)
+    Bm, Cm = torch.randn(Bz, L, G, N, generator=g) * 0.5, torch.randn(Bz, L, G, N, generator=g) * 0.5
+    D = torch.rand(H, generator=g) + 0.5
+    dtv = torch.exp(torch.rand(H, generator=g) * (math.log(0.1) - math.log(1e-3)) + math.log(1e-3))
+    bias = dtv + torch.log(-torch.expm1(-dtv))
+    cores = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
+    R.ssd_chunk_scan_ref(x, dt, A, Bm, Cm, 128, D=D, dt_bias=bias)                     # warm the thread pool
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        y_ref, fin_ref = R.ssd_chunk_scan_ref(x, dt, A, Bm, Cm, 128, D=D, dt_bias=bias)[:2]
+    cpu_ms = (time.perf_counter() - t0) / reps * 1e3
+    d = lambda t: t.to(dev)
+    fn = lambda: K.mamba_chunk_scan_combined(d(x), d(dt), d(A), d(Bm), d(Cm), chunk_size=128, D=d(D), dt_bias=d(bias),
+                                             dt_softplus=True, return_final_states=True)
+    xs = [d(t) for t in (x, dt, A, Bm, Cm, D, bias)]
+    fn2 = lambda: K.mamba_chunk_scan_combined(xs[0], xs[1], xs[2], xs[3], xs[4], chunk_size=128, D=xs[5], dt_bias=xs[6],
+                                              dt_softplus=True, return_final_states=True)
+    for _ in range(max(args.warmup, 1)):
+        y, fin = fn2()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    steps = max(args.steps, 20)
+    e0.record()
+    for _ in range(steps):
+        y, fin = fn2()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / steps * 1e3
+    err_y = float((y.float().cpu() - y_ref).abs().max())
+    err_f = float((fin.cpu() - fin_ref).abs().max())
+    gold = np.load(ROOT / "tests" / "golden" / "mixer_g1.npz")
+    A_g = -torch.exp(torch.from_numpy(gold["w.A_log"]))
+    yg = R.ssd_chunk_scan_ref(*(torch.from_numpy(gold[k]) for k in ("scan_x", "scan_dt")), A_g,
+                              torch.from_numpy(gold["scan_B"]), torch.from_numpy(gold["scan_C"]), 16,
+                              D=torch.from_numpy(gold["w.D"]), dt_bias=torch.from_numpy(gold["w.dt_bias"]))[0]
+    err_gold = float((yg - torch.from_numpy(gold["scan_y"])).abs().max())
+    bytes_alg = Bz * L * (2 * H * P + H + 2 * G * N) * 4
+    print(json.dumps({
+        "metric": "Mamba-2 selective scan, B=1 L=1024 32x64 d_state 16 fp32 (BASELINE configs[0])",
+        "value": round(us, 1), "unit": "us per scan", "n_gpus": 1, "steps": steps, "warmup": max(args.warmup, 1),
+        "ms_per_step": round(us / 1e3, 4), "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "tv_ssd_scan_fwd (generic fp32 recurrence kernel: d_state 16 is not an MFMA shape), "
+                               f"tokens {L}, heads {H} x {P}, groups {G}, d_state {N}"},
+        "roofline": {"bound": "hbm", "kernel": "ssd_generic_kernel", "achieved": round(bytes_alg / us / 1e3, 2),
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(bytes_alg / us / 1e3 / HBM_PEAK_GBS, 5),
+                     "traffic": None, "note": "0.3 MB per scan: a launch-latency-sized problem, not a bandwidth one"},
+        "cpu_baseline": {"value": round(cpu_ms, 3), "unit": "ms per scan", "cores": cores, "kind": "port",
+                         "sample": f"oracle.ops.ssd_chunk_scan_ref (the reference's chunked formulation, modeling_nano.py:775-851), "
+                                   f"mean of {reps} calls"},
+        "max_abs_err": {"hip_vs_oracle_y": err_y, "hip_vs_oracle_final_state": err_f,
+                        "oracle_vs_reference_golden_y (tests/golden/mixer_g1.npz)": err_gold}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -242,7 +316,24 @@ def main():
     ap.add_argument("--frames", type=int, default=int(os.environ.get("TV_BENCH_FRAMES", 10240)))
     ap.add_argument("--no-pdrop", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", type=int, default=0,
+                    help="one of BASELINE.json's other configurations, counted from 1 (1 scan only, 2 256 frames, "
+                         "3 2 048 frames + TransV + pdrop, 5 Qwen2.5 + dual encoder + fp8 attention); default: the "
+                         "headline run (10 240 frames); 4 is the headline run with --gpus 8")
     args = ap.parse_args()
+    if args.config == 1:
+        return config1_scan(args)
+    if args.config == 2:
+        args.frames, args.no_pdrop = 256, True
+    elif args.config == 3:
+        args.frames = 2048
+    elif args.config == 5:
+        # a child process (nothing has touched the GPU here): devtools/run_config5.py prints the JSON line
+        import subprocess
+        sys.exit(subprocess.run([sys.executable, str(ROOT / "timeviper_amd" / "devtools" / "run_config5.py"), "4096",
+                                 str(max(args.steps, 1)), "1"], cwd=str(ROOT)).returncode)
+    elif args.config not in (0, 4):
+        sys.exit("bench.py: --config takes 1, 2, 3, 4 or 5")
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` typed by hand: start the N ranks as a CHILD job (one process per

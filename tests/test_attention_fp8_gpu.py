@@ -112,5 +112,7 @@ def test_fp8_switch_routes_flash_attn_func(K):
         o8 = K.flash_attn_func(q, k, v, causal=True)
         assert torch.equal(o8, K.flash_attn_fp8_func(q, k, v, causal=True))
         short = K.flash_attn_func(q[:, :1], k[:, :100], v[:, :100], causal=True)     # 100 keys < min_keys: bf16
+        decode = K.flash_attn_func(q[:, -1:], k, v, causal=True)                     # 1 query against 512 >= min_keys keys: bf16 too
     assert torch.equal(short, K.flash_attn_func(q[:, :1], k[:, :100], v[:, :100], causal=True))
+    assert torch.equal(decode, K.flash_attn_func(q[:, -1:], k, v, causal=True)), "decode step must stay on the bf16 kernel, bit for bit"
     assert not torch.equal(o8, o16) and torch.equal(K.flash_attn_func(q, k, v, causal=True), o16)

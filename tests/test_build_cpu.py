@@ -1,0 +1,85 @@
+"""Build-time checks on the gfx950 code objects (no GPU needed: hipcc cross-compiles, llvm-objdump / llvm-readelf read
+the result).
+
+Several kernels issue global loads from inline asm that the compiler does not track and cover them with hand-counted
+`s_waitcnt vmcnt(N)` (ssdk::gload16_async for the Q fragments of the attention kernels; the C.B^T and dt loads of the
+head-per-wave scan).  That is only sound while the compiler never saves or copies the destination registers between the
+load and the wait — i.e. while the kernel SPILLS NOTHING: a spilled register with a load in flight is stored before its
+data arrives and reloaded stale (this happened in the scan's complete kernel, which is why that one uses ordinary loads).
+So every kernel that uses the idiom must have zero scratch; a compiler upgrade or a source edit that introduces a spill
+fails here instead of producing silently wrong numbers on the GPU."""
+import re
+import shutil
+import subprocess
+from pathlib import Path
+
+import pytest
+
+from timeviper_amd import build
+
+LLVM = Path("/opt/rocm/lib/llvm/bin")
+needs_tools = pytest.mark.skipif(not (LLVM / "llvm-objdump").exists() or not (LLVM / "llvm-readelf").exists(),
+                                 reason="ROCm LLVM tools not found")
+
+
+def kernel_metadata(src_name: str, tmp_path: Path) -> dict:
+    """{mangled kernel name: {private_segment_fixed_size, vgpr_spill_count, ...}} of lib/obj/<src>.o"""
+    build.ensure_built()
+    obj = build.OBJ / (src_name + ".o")
+    work = tmp_path / src_name
+    work.mkdir()
+    shutil.copy(obj, work / obj.name)                      # llvm-objdump --offloading writes next to its input
+    subprocess.run([str(LLVM / "llvm-objdump"), "--offloading", obj.name], cwd=work, check=True, capture_output=True)
+    dev = [p for p in work.iterdir() if "amdgcn" in p.name]
+    assert len(dev) == 1, [p.name for p in work.iterdir()]
+    notes = subprocess.run([str(LLVM / "llvm-readelf"), "--notes", dev[0].name], cwd=work, check=True,
+                           capture_output=True, text=True).stdout
+    out, cur = {}, None
+    for line in notes.splitlines():
+        m = re.match(r"\s*-?\s*\.(\w+):\s*(\S+)", line)
+        if not m:
+            continue
+        key, val = m.group(1), m.group(2)
+        if key == "name" and val.startswith("_Z"):
+            cur = out.setdefault(val, {})
+        elif cur is not None and key in ("private_segment_fixed_size", "vgpr_spill_count", "sgpr_spill_count",
+                                         "vgpr_count", "agpr_count"):
+            cur[key] = int(val)
+    # (.name comes after the counts inside one kernel's block in some LLVM versions: collect per block instead)
+    blocks = re.split(r"\n\s*- \.agpr_count:", notes)
+    for b in blocks[1:]:
+        name = re.search(r"\.name:\s*(_Z\S+)", b)
+        if not name:
+            continue
+        d = out.setdefault(name.group(1), {})
+        for key in ("private_segment_fixed_size", "vgpr_spill_count", "sgpr_spill_count", "vgpr_count"):
+            m = re.search(r"\." + key + r":\s*(\d+)", b)
+            if m:
+                d[key] = int(m.group(1))
+    return out
+
+
+@needs_tools
+def test_head_scan_fast_kernels_spill_nothing(tmp_path):
+    """ssd_head_kernel<PT, 4, 2, false> (the kernels that run in the 9B model) carry untracked loads: zero scratch."""
+    md = kernel_metadata("ssd_head.hip", tmp_path)
+    fast4 = {k: v for k, v in md.items() if re.search(r"ssd_head_kernelILi\dELi4ELi2ELb0E", k)}
+    assert len(fast4) >= 3, list(md)
+    for k, v in fast4.items():
+        assert v.get("private_segment_fixed_size") == 0 and v.get("vgpr_spill_count", 0) == 0, (k, v)
+    # the complete kernels may spill (they use ordinary loads); they must exist
+    assert any("Lb1E" in k for k in md)
+
+
+@needs_tools
+def test_attention_kernels_with_untracked_q_loads_spill_nothing(tmp_path):
+    """flash_fwd_kernel / flash_fwd_stream_kernel load their Q fragments with ssdk::gload16_async."""
+    for src in ("attention.hip", "attention_fp8.hip"):
+        text = (build.CSRC / src).read_text()
+        if "gload16_async" not in text:
+            continue
+        md = kernel_metadata(src, tmp_path)
+        kernels = {k: v for k, v in md.items() if "flash_fwd" in k}
+        assert kernels, (src, list(md))
+        for k, v in kernels.items():
+            assert v.get("private_segment_fixed_size") == 0 and v.get("vgpr_spill_count", 0) == 0, (src, k, v)

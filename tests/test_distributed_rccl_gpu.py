@@ -1,0 +1,105 @@
+"""Sequence-parallel runner over REAL RCCL: one process per GPU, backend "nccl", 2 ranks (and 8 when the
+node has them).  Skipped on boxes with fewer than two devices (the 1-GPU test box: there
+test_distributed_gpu.py runs the same runner with host-staged collectives).  What only this file
+exercises: `init_process_group(device_id=...)`, `all_gather_into_tensor(async_op=True)` on RCCL's own
+stream overlapped with q_proj, `broadcast` of the ranking query, the `_attention` /
+`_run_layers_qwen2` data paths without any stand-in, and K.layer_norm's row_bias path under the
+sharded ViT.  Sharded logits and pdrop traces must equal the single-GPU forward
+(reference semantics modeling_nano.py:1134-1220, :1929-1942)."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from test_distributed_cpu import PD, free_port
+
+pytestmark = pytest.mark.gpu
+
+NGPU = torch.cuda.device_count()      # (counting devices does not initialise the GPU)
+needs2 = pytest.mark.skipif(NGPU < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")
+UNI3 = "uni_2_0.75-uni_3_0.5-uni_6_0.25"
+
+
+def worker(rank, world, port, merge, T, q, pd, family):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    try:
+        from timeviper_amd.distributed import SequenceParallelTimeViper
+        from timeviper_amd.model import build_synthetic_timeviper
+        from timeviper_amd.model.llm.nano import NemotronHConfig
+        cfg = NemotronHConfig(vocab_size=128, hidden_size=256, intermediate_size=384, num_hidden_layers=8,
+                              hybrid_override_pattern="M-M*M-*M", num_attention_heads=4, head_dim=64,
+                              num_key_value_heads=2, ssm_state_size=128, mamba_num_heads=8,
+                              mamba_n_groups=2, mamba_head_dim=40, mamba_chunk_size=64)
+        kw = {}
+        if family == "qwen2":
+            from timeviper_amd.model.llm.qwen2 import Qwen2Config
+            cfg = Qwen2Config(vocab_size=128, hidden_size=256, intermediate_size=512, num_hidden_layers=6,
+                              num_attention_heads=4, num_key_value_heads=2, rope_theta=10000.0)
+            kw = {"llm_backbone_id": "qwen2.5-7b-instruct"}
+        vlm = build_synthetic_timeviper(cfg, "siglip-vit-b16-224px", pdrop_type=pd, merge_module=merge,
+                                        vit_depth=3, image_size=96, seed=3, **kw)
+        tok = vlm.default_token_id
+        g = torch.Generator().manual_seed(1)
+        ids = torch.tensor([[5, 6, 7] + [tok] * T + [8, 9, 10, 11, 12]], device="cuda")
+        pix = torch.randn(T, 3, 96, 96, generator=g).cuda().bfloat16()
+        with torch.no_grad():
+            runner = SequenceParallelTimeViper(vlm, rank, world)
+            lo, hi = runner.frame_range(T)
+            logits = runner.forward(ids, pix[lo:hi], T)
+            trace = [t.cpu().numpy() for t in runner.trace]
+            if rank == 0:
+                ref = vlm(input_ids=ids, pixel_values_videos=pix).logits
+                ref_trace = [t["kept"].cpu().numpy() for t in (vlm.llm_backbone.llm.backbone.last_pdrop_trace or [])]
+                q.put((logits.float().cpu().numpy(), ref.float().cpu().numpy(), trace, ref_trace))
+        torch.cuda.synchronize()
+        dist.barrier()
+    except BaseException:
+        import traceback
+        traceback.print_exc()
+        os._exit(1)
+    finally:
+        dist.destroy_process_group()
+
+
+def run(world, merge, pd, family, T):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=worker, args=(r, world, port, merge, T, q, pd, family)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        out = q.get(timeout=900)
+    finally:
+        for p in procs:
+            p.join(180)
+            if p.is_alive():
+                p.kill()          # (this exact child, never a pattern)
+    assert all(p.exitcode == 0 for p in procs), "worker failed (see its traceback above)"
+    return out
+
+
+@needs2
+@pytest.mark.parametrize("world", [2] + ([8] if NGPU >= 8 else []))
+@pytest.mark.parametrize("merge,pd,family", [("no_merge", None, "nano"), ("CrossAttention", UNI3, "nano"),
+                                             ("CrossAttention", PD, "nano"), ("CrossAttention", UNI3, "qwen2")])
+def test_sequence_parallel_over_rccl_matches_single_gpu(world, merge, pd, family):
+    T = 21 if world == 2 else 67           # ragged shards: 11 / 10 frames, or 8 ranks of 8-9 frames
+    logits, ref, trace, ref_trace = run(world, merge, pd, family, T)
+    logits, ref = torch.from_numpy(logits), torch.from_numpy(ref)
+    assert logits.shape == ref.shape and torch.isfinite(logits).all()
+    assert len(trace) == len(ref_trace) and all(a.shape == b.shape for a, b in zip(trace, ref_trace))
+    rel = ((logits - ref).norm() / ref.norm()).item()
+    if pd != PD:
+        # uniform stages keep exactly the same tokens; logits agree to bf16 model-level noise
+        assert all((a == b).all() for a, b in zip(trace, ref_trace))
+        assert rel < 5e-2, rel
+    else:
+        # "attn" stages: the sharded ranking runs the single-GPU kernels on the same numbers (kept tokens are
+        # identical on identical inputs: test_distributed_gpu.py); here the inputs of later stages differ by bf16
+        # noise between the two forwards, so only the uniform stage is compared exactly
+        assert (trace[0] == ref_trace[0]).all()

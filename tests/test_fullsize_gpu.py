@@ -55,7 +55,10 @@ def test_scan_full_length_properties(K):
     ya, fa, da = run(K, x[:, :s], dt[:, :s], A, Bm[:, :s], Cm[:, :s], D, bias)
     yb, fb, db = run(K, x[:, s:], dt[:, s:], A, Bm[:, s:], Cm[:, s:], D, bias, initial_states=fa)
     assert rel(torch.cat([ya, yb], 1), y) < 5e-3
-    assert rel(fb, fin) < 1e-3
+    # (the march rounds x~ = w_s x to bf16 before the state update, ~2e-3 on the state — check (4); in the head-per-wave
+    # kernel w_s carries the floating frame's scale, which depends on where a march started, so two marches over the same
+    # tokens round differently: the states agree to that rounding, not to fp32)
+    assert rel(fb, fin) < 5e-3
     assert torch.allclose(da + db, dec, rtol=1e-4, atol=1e-2)
     del ya, yb
     # (3) the two MFMA kernels (slice march / chunk march) are independent implementations
@@ -64,7 +67,7 @@ def test_scan_full_length_properties(K):
         ym, fm, dm = run(K, x, dt, A, Bm, Cm, D, bias)
     finally:
         K.ssd_scan_set_impl(0)
-    assert rel(ym, y) < 5e-3 and rel(fm, fin) < 1e-3
+    assert rel(ym, y) < 5e-3 and rel(fm, fin) < 5e-3
     assert torch.allclose(dm, dec, rtol=1e-5, atol=1e-3)
     del ym
     # (4) the definition (fp32 token recurrence, generic kernel) on the last 3 000 tokens,
@@ -201,3 +204,9 @@ def test_pdrop_token_ops_full_length(K):
     top = lambda t: set(torch.topk(t, 2048).indices.tolist())
     assert len(top(sc.float()) & top(p)) >= 2048 * 0.98            # bf16 ties at the cut may differ
     assert rel(sc, p) < 2e-2
+    # ... and they differ ONLY inside the bf16 rounding band around the k-th score: every token above it is kept by both,
+    # every token below it by neither (tests/keepsets.py), at the four keep counts of the evaluate.py schedule
+    from keepsets import assert_keepsets_agree_outside_rounding_band
+    for r in (0.8, 0.6, 0.4, 0.2):
+        info = assert_keepsets_agree_outside_rounding_band(sc, p, int(NV * r))
+        assert info["disagree"] <= info["in_band"]

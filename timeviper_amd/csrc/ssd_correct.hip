@@ -7,8 +7,8 @@
 // known the outputs are completed by this term.  It is the Y_off term of modeling_nano.py:833-836
 // with the chunk-local decay replaced by the decay from the range start.
 //
-// The factor exp(cs_t) only shrinks along the sequence (dt >= 0, A < 0); once cs_t * log2(e) < -48 the
-// term is below 4e-15 of |C_t . S_in| — far under the fp32 rounding of the sum it would enter, let alone
+// The factor exp(cs_t) only shrinks along the sequence (dt >= 0, A < 0); once cs_t * log2(e) < -40 the
+// term is below 1e-12 of |C_t . S_in| — far under the fp32 rounding of the sum it would enter, let alone
 // a bf16 ulp of y — and the kernel stops (C_UNDERFLOW; the reference's fp32 state passing loses such terms
 // in its own additions).  Heads that forget within a few hundred tokens cost a few chunks; a head that
 // never forgets costs the full range.
@@ -18,6 +18,7 @@
 // head until the prefix underflows; per 64-token chunk C . S_in^T on MFMA 16x16x32 (S_in as bf16
 // B fragments in registers for the whole walk, like the march's state snapshot), scaled rows
 // through LDS, 16-byte read-modify-write of y.
+#include <stdlib.h>
 #include "ssd_common.hpp"
 
 namespace {
@@ -27,10 +28,10 @@ constexpr int CQ = 64;            // tokens per chunk
 constexpr int CN = 128;           // d_state
 constexpr int CSLOTS = 64;        // work-groups per (batch, head): a head that never forgets is walked by all of them
                                   // (measured with 8: the slowest heads set the launch time, 808 us in the 9B model)
-// The walk of a head ends where the factor 2^(cs_t log2 e) has fallen below 2^-48: the term is then < 4e-15 of
-// |C_t . S_in| — eight orders of magnitude under the fp32 rounding of the sum it would be added to and eleven
-// under a bf16 ulp of y; round 2 walked on to 2^-160 (exactly 0 in fp32), three times the distance.
-constexpr float C_UNDERFLOW = -48.f;
+// The walk of a head ends where the factor 2^(cs_t log2 e) has fallen below 2^-40: the term is then < 1e-12 of
+// |C_t . S_in| — five orders of magnitude under the fp32 rounding of the sum it would be added to and nine
+// under a bf16 ulp of y; round 2 walked on to 2^-160 (exactly 0 in fp32), four times the distance.
+constexpr float C_UNDERFLOW = -40.f;
 
 struct CorrArgs {
   bf16_t* y;
@@ -327,7 +328,8 @@ int tv_ssd_correct_all_launch(void* y, const void* dt, const void* A, const void
                                                                          total_decay, nseg, bh, per_head);
   if (nsegc > 0) {
     ssd_decay_prefix_kernel<<<dim3(nheads, batch * nsegc), 64, 0, st>>>(a);
-    const int slots = seg_chunks < 16 ? seg_chunks : 16;
+    int slots = seg_chunks < 8 ? seg_chunks : 8;       // (measured at 8 segments of the 9B model: 4: 311 us, 8: 274, 16: 336, 32: 533)
+    if (const char* e = getenv("TV_CORR_SLOTS")) slots = atoi(e) > 0 ? atoi(e) : slots;      // dev tool
     launch_correct_pt(a, dim3(slots, nheads, batch * nsegc), headdim, st);
   }
   TV_LAUNCH_CHECK();

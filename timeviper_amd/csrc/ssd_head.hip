@@ -141,6 +141,11 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 template <int PT, int NW, int NB, bool RARE>
 __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
   typedef HeadSmem<PT, NW, NB> Smem;
+  // Loads the compiler does not track (inline asm + counted waits) are only safe in a kernel that spills NOTHING: a
+  // register with such a load in flight may otherwise be saved before its data has arrived (seen: the complete kernel
+  // read stale C.B^T fragments that way).  Only the 4-wave fast kernels are held to zero scratch
+  // (tests/test_build_cpu.py reads it off the code object); every other variant uses ordinary loads and full waits.
+  constexpr bool UNTRACKED = !RARE && NW == 4;
   constexpr int BD = NB - 1;            // B/C prefetch distance (chunks)
   static_assert(BD == 1, "the waits below are counted for a B/C ring of 2");
   constexpr int P = PT * 16;
@@ -301,9 +306,7 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
     const int t = min(c * HQ + lane, L - 1);
     const bf16_t* p = dtg + (int64_t)t * a.dsl;
     unsigned r;
-    // (the complete kernel spills registers: a register with an untracked load in flight could be saved before its data
-    // arrives; there the load is an ordinary one and the compiler's own waits apply)
-    if (RARE) r = *(const unsigned short*)p;
+    if (!UNTRACKED) r = *(const unsigned short*)p;
     else asm volatile("global_load_ushort %0, %1, off" : "=v"(r) : "v"(p) : "memory");
     return r;
   };
@@ -562,7 +565,7 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
 #pragma unroll
         for (int f = 0; f < NFR; ++f) {
           u32x4v r;
-          if (RARE) r = *(const u32x4v*)(cbg + (int64_t)c * CBE + f * 512);
+          if (!UNTRACKED) r = *(const u32x4v*)(cbg + (int64_t)c * CBE + f * 512);
           else asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(cbg + (int64_t)c * CBE + f * 512) : "memory");
           cbv[f] = __builtin_bit_cast(bf16x8, r);
         }
@@ -585,7 +588,7 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
     quarter(3, cq[1], bq[1], sbq[1], sbq[0], [&](int) {}, false);
     HSTAMP(5);
     // C.B^T has landed; what was issued behind it (the last x copies, dt) may stay in flight
-    if (!RARE && more && (c + 2) * HQ <= L) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NXG > 2 ? NXI - 8 : 0) + 1) : "memory");
+    if (UNTRACKED && more && (c + 2) * HQ <= L) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NXG > 2 ? NXI - 8 : 0) + 1) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (!STD) {
 #pragma unroll
@@ -717,7 +720,7 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
     }
     HSTAMP(9);
     // (the copies of the next chunk landed before the C.B^T wait; this step's y stores stay in flight)
-    if (!RARE && (c + 1) * HQ <= L) HEAD_BARRIER(4 * PT);
+    if (UNTRACKED && (c + 1) * HQ <= L) HEAD_BARRIER(4 * PT);
     else HEAD_BARRIER(0);
   }
 #ifdef TV_HEAD_STAMP

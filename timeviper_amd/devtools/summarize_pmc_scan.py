@@ -15,8 +15,9 @@ from bench import scan_source_id  # noqa: E402
 
 tag, impl = sys.argv[1], int(sys.argv[2])
 tokens = int(sys.argv[3]) if len(sys.argv) > 3 else 163940
-KERNELS = ["ssd_slice_kernel", "ssd_cb_kernel", "ssd_correct_kernel", "ssd_seg_combine_kernel",
-           "ssd_chunk_decay_kernel", "ssd_decay_prefix_kernel"]
+KERNELS = ["ssd_head_kernel<5, 4, 2, false>", "ssd_head_kernel<5, 4, 2, true>", "ssd_slice_kernel", "ssd_cb_kernel",
+           "ssd_correct_kernel", "ssd_seg_chain_kernel", "ssd_seg_combine_kernel", "ssd_chunk_decay_kernel",
+           "ssd_decay_prefix_kernel"]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))     # kernel -> counter -> per-dispatch sums
 names = {}
 for f in sorted(glob.glob(str(ROOT / "gpurun_out/pmc_slice*/**/p_counter_collection.csv"), recursive=True)):
@@ -25,7 +26,7 @@ for f in sorted(glob.glob(str(ROOT / "gpurun_out/pmc_slice*/**/p_counter_collect
         k = next((n for n in KERNELS if n in r["Kernel_Name"]), None)
         if k is None:
             continue
-        m_ = re.search(k + r"(<[^>]*>)?", r["Kernel_Name"])
+        m_ = re.search(re.escape(k) + r"(<[^>]*>)?", r["Kernel_Name"])
         names[k] = m_.group(0) if m_ else k
         per[(k, r["Dispatch_Id"])][r["Counter_Name"]] += float(r["Counter_Value"])
     for (k, _), cs in per.items():
@@ -44,7 +45,7 @@ for k, m in mean.items():
     if "WRITE_SIZE" in m:
         hbm[f"{k}_write"] = m["WRITE_SIZE"] * 1024
 hbm["total"] = sum(hbm.values())
-out = [f"# rocprofv3 --pmc passes on `python3 timeviper_amd/devtools/bench_ops.py --ops scan --impl {impl}` "
+out = [f"# rocprofv3 --pmc passes on `python3 timeviper_amd/devtools/bench_ops.py --ops scan --model-dt --impl {impl}` "
        f"({tokens} tokens, Nano-9B dims), {tag}\n",
        "One counter set per pass, no tracing (`timeviper_amd/devtools/pmc_scan.sh`); mean per launch, summed over the rows "
        "rocprofv3 reports per dispatch (`timeviper_amd/devtools/summarize_pmc_scan.py`).\n"]
@@ -69,6 +70,6 @@ out.append(f"\n## HBM traffic per tv_ssd_scan_fwd call\n\nalgorithmic bytes {alg
     "kernel": " + ".join(names[k] for k in KERNELS if k in names), "scan_impl": impl, "scan_source_id": scan_source_id(),
     "tokens": tokens, "algorithmic_bytes": alg, "hbm_bytes": hbm, "hbm_over_algorithmic": hbm["total"] / alg,
     "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, timeviper_amd/devtools/pmc_scan.sh) on "
-           f"bench_ops.py --ops scan --impl {impl}; KiB units; FETCH_SIZE x2 (gfx950 correction for 16 B/lane streaming "
+           f"bench_ops.py --ops scan --model-dt --impl {impl}; KiB units; FETCH_SIZE x2 (gfx950 correction for 16 B/lane streaming "
            "reads, MI355X_MICROARCH.md); every kernel of the call summed (one launch each per call)"}, indent=1) + "\n")
 print("\n".join(out))

@@ -17,11 +17,14 @@ the 8 GPUs with RCCL all-gather of the SSM states over xGMI".  One process per G
     (tv_ssd_state_correction; it stops at each head's decay horizon).
   * attention (4 layers): K/V all-gather (variable shard lengths), causal attention of the
     local queries against the keys up to the shard's end (bottom-right aligned mask).
-  * TransV / pdrop: "uni" indices are computed identically on every rank; "attn" scores
-    need one softmax over all keys -> per-head (max, sum-exp) partials are all-gathered,
-    the per-token scores are all-gathered, every rank runs the same stable top-k and keeps
-    its own rows; the dropped rows' K/V for the TransV cross-attention are all-gathered to
-    the rank that owns the trailing text.
+  * TransV / pdrop: "uni" indices are computed identically on every rank; "attn" scores need one
+    softmax over all keys -> every rank computes the logits of ITS keys (tv_attn_rank_logits), the
+    (keys, heads) pieces are all-gathered, and every rank runs tv_attn_rank_scores_from_logits + the
+    same stable sort on the identical array — the single-GPU kernels on the same numbers, so one GPU
+    and N GPUs keep the same tokens bit for bit; every rank keeps its own rows; the dropped rows' K/V
+    for the TransV cross-attention are gathered to the rank that owns the trailing text.
+    Shards are not re-balanced after an "attn" stage (the kept tokens of a real checkpoint may
+    cluster; an all-to-all of rows would be the fix — not built).
 """
 from __future__ import annotations
 
@@ -114,6 +117,14 @@ def split_frames(n_frames: int, world: int, causal_skew: float = 0.0, align: int
         cuts = [0] + [max(c, 0) for c in cuts] + [n_frames]
         for i in range(1, len(cuts)):
             cuts[i] = max(cuts[i], cuts[i - 1])
+        if n_frames >= align * world and any(cuts[i + 1] == cuts[i] for i in range(world)):
+            # rounding emptied a shard although every rank could have a whole clip: hand out whole clips evenly
+            clips = n_frames // align
+            per, rem = divmod(clips, world)
+            cuts = [0]
+            for r in range(world):
+                cuts.append(cuts[-1] + (per + (1 if r < rem else 0)) * align)
+            cuts[-1] = n_frames
         return [(cuts[i], cuts[i + 1]) for i in range(world)]
     out, lo_f = [], 0
     for n in sizes:
@@ -353,6 +364,8 @@ class SequenceParallelTimeViper:
         if "uni" in ctype:
             top_h = torch.linspace(0, image_tokens - 1, keep, dtype=torch.long) + vis0
             pos = torch.searchsorted(top_h, torch.tensor(edges)).tolist()
+            top = top_h.to(dev)      # ONE source for the boundaries and the gathered rows (the kernel reproduces it bit for bit,
+                                     # tests/test_ops_gpu.py; a disagreement would index rows outside the shard)
         else:
             pos = torch.searchsorted(top, torch.tensor(edges, device=dev)).tolist()
         kept_per_rank = [pos[r + 1] - pos[r] for r in range(self.world)]

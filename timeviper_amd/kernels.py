@@ -378,13 +378,14 @@ def selective_state_update(state, x, dt, A, B, C, D=None, z=None, dt_bias=None,
 
 
 def ssd_scan_set_impl(impl: int) -> None:
-    """0 auto, 1 generic fp32-recurrence kernel, 2 MFMA chunk-march kernel, 3 MFMA slice-march
-    kernel (C.B^T pre-pass + state-in-accumulator slice waves)."""
+    """0 auto (= 6 where it applies, else 4, 3, 2, 1), 1 generic fp32-recurrence kernel, 2 MFMA chunk-march kernel,
+    3 MFMA slice march with two work-groups per head, 4 / 5 whole-head slice march (8 / 12 waves) x sequence
+    segments, 6 head-per-wave march (ssd_head.hip).  Process-global (dev tools and tests)."""
     _capi.lib().tv_ssd_scan_set_impl(int(impl))
 
 
 # ------------------------------------------------------------------ attention
-_ATTN_FP8 = {"on": False, "min_keys": 4096}
+_ATTN_FP8 = {"on": False, "min_keys": 4096, "min_queries": 64}
 
 
 class fp8_attention:
@@ -393,11 +394,15 @@ class fp8_attention:
     default: the reference's attention arithmetic is bf16.  Key sequences shorter than `min_keys`
     stay on the bf16 kernel: the ViT towers (<= 1 025 keys per frame / tube; measured 2.3 ms fp8
     against 1.5 ms bf16 per 256 SigLIP frames — the quantisation pre-pass and head_dim 72 -> 128
-    padding cost more than the MFMAs save) and the single-query decode step.  The long causal LM
-    attention is where the fp8 matrix rate pays (131 172 tokens, 28/4 x 128: 83 ms against 122 ms)."""
+    padding cost more than the MFMAs save); calls with fewer than `min_queries` queries stay there too: the
+    decode step (one query against the whole cache: the quantisation pre-pass over the cache would cost
+    more than the attention, with per-head scales that differ from the prefill's).  The long causal LM
+    attention is where the fp8 matrix rate pays (131 172 tokens, 28/4 x 128: 83 ms against 122 ms).
+    The switch is process-global state (like `ssd_scan_set_impl`): right for an evaluation process, not for
+    two models with different settings in one process."""
 
-    def __init__(self, on: bool = True, min_keys: int = 4096):
-        self.new = {"on": bool(on), "min_keys": int(min_keys)}
+    def __init__(self, on: bool = True, min_keys: int = 4096, min_queries: int = 64):
+        self.new = {"on": bool(on), "min_keys": int(min_keys), "min_queries": int(min_queries)}
 
     def __enter__(self):
         self.old = dict(_ATTN_FP8)
@@ -443,7 +448,10 @@ def flash_attn_func(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False,
     _gpu(q, k, v)
     B, Lq, Hq, D = q.shape
     Lk, Hkv = k.shape[1], k.shape[2]
-    if _ATTN_FP8["on"] and Lk >= _ATTN_FP8["min_keys"] and D <= 128 and q.dtype in (torch.bfloat16, torch.float16):
+    # (Lq >= 64: a decode step against a long cache stays on the bf16 kernel — the fp8 path would re-quantise and
+    # transpose the whole K / V cache for one query, with a scale that differs from the prefill's)
+    if _ATTN_FP8["on"] and Lk >= _ATTN_FP8["min_keys"] and Lq >= _ATTN_FP8["min_queries"] and D <= 128 \
+            and q.dtype in (torch.bfloat16, torch.float16):
         return flash_attn_fp8_func(q, k, v, softmax_scale, causal, return_lse)
     fix = lambda t: t if t.stride(-1) == 1 else t.contiguous()
     q, k, v = fix(q), fix(k), fix(v)
