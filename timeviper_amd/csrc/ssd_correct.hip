@@ -7,8 +7,8 @@
 // known the outputs are completed by this term.  It is the Y_off term of modeling_nano.py:833-836
 // with the chunk-local decay replaced by the decay from the range start.
 //
-// The factor exp(cs_t) only shrinks along the sequence (dt >= 0, A < 0); once cs_t * log2(e) < -40 the
-// term is below 1e-12 of |C_t . S_in| — far under the fp32 rounding of the sum it would enter, let alone
+// The factor exp(cs_t) only shrinks along the sequence (dt >= 0, A < 0); once cs_t * log2(e) < -32 the
+// term is below 2.5e-10 of |C_t . S_in| — far under the fp32 rounding of the sum it would enter, let alone
 // a bf16 ulp of y — and the kernel stops (C_UNDERFLOW; the reference's fp32 state passing loses such terms
 // in its own additions).  Heads that forget within a few hundred tokens cost a few chunks; a head that
 // never forgets costs the full range.
@@ -28,10 +28,10 @@ constexpr int CQ = 64;            // tokens per chunk
 constexpr int CN = 128;           // d_state
 constexpr int CSLOTS = 64;        // work-groups per (batch, head): a head that never forgets is walked by all of them
                                   // (measured with 8: the slowest heads set the launch time, 808 us in the 9B model)
-// The walk of a head ends where the factor 2^(cs_t log2 e) has fallen below 2^-40: the term is then < 1e-12 of
-// |C_t . S_in| — five orders of magnitude under the fp32 rounding of the sum it would be added to and nine
-// under a bf16 ulp of y; round 2 walked on to 2^-160 (exactly 0 in fp32), four times the distance.
-constexpr float C_UNDERFLOW = -40.f;
+// The walk of a head ends where the factor 2^(cs_t log2 e) has fallen below 2^-32: the term is then < 2.5e-10 of
+// |C_t . S_in| — two orders of magnitude under the fp32 rounding of the sum it would be added to and seven
+// under a bf16 ulp of y; round 2 walked on to 2^-160 (exactly 0 in fp32), five times the distance.
+constexpr float C_UNDERFLOW = -32.f;
 
 struct CorrArgs {
   bf16_t* y;

@@ -52,6 +52,10 @@ int tv_ssd_correct_all_launch(void* y, const void* dt, const void* A, const void
 #ifndef TV_HEAD_PIN
 #define TV_HEAD_PIN 0
 #endif
+// TV_HEAD_Y16: 1 = y leaves in 16-byte stores (two t-tiles joined by v_permlane16_swap), 0 = 8-byte stores
+#ifndef TV_HEAD_Y16
+#define TV_HEAD_Y16 1
+#endif
 namespace {
 using namespace ssdk;
 
@@ -290,6 +294,7 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
   const int xv_lo = lc * XROW + 8 * kq;
   bf16_t* const ygs = a.y + (int64_t)b * a.ysb + (int64_t)t_first * a.ysl + (int64_t)h * P;
   const unsigned yoff0 = (unsigned)((lc * a.ysl + 4 * kq) * 2);
+  unsigned yoff16 = (unsigned)(((16 * (kq & 1) + lc) * a.ysl + 8 * (kq >> 1)) * 2);     // 16-byte form (TV_HEAD_Y16)
   auto store_y_tile = [&](const void* yrow, bool ok, int ct, u32x2 v) {      // yrow: row 16 ti of the chunk, columns of this head
     if (ok) asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3" :: "v"(yoff0), "v"(v), "s"(yrow), "n"(32 * ct) : "memory");
   };
@@ -692,21 +697,43 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
         typedef __attribute__((address_space(3))) const u32x2 lds_u32x2;
         xrv[ti][ct] = *(lds_u32x2*)(xt + xv_lo + 32 * ct + ti * (16 * XROW));
       }
+    auto finish = [&](int ct, int ti) {       // the lane's 8 bytes of y: columns 16 ct + 4 kq + 0..3 of token 16 ti + lc
+      typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+      const u32x2 xr = xrv[ti][ct];
+      const f32x2 e2 = {ev[ti], ev[ti]};
+      const f32x2 y0 = __builtin_elementwise_fma(f32x2{yo[ct][ti][0], yo[ct][ti][1]}, e2, dh2 * f32x2{bf16_lo(xr[0]), bf16_hi(xr[0])});
+      const f32x2 y1 = __builtin_elementwise_fma(f32x2{yo[ct][ti][2], yo[ct][ti][3]}, e2, dh2 * f32x2{bf16_lo(xr[1]), bf16_hi(xr[1])});
+      const bf16x2 p01 = {(bf16_t)y0[0], (bf16_t)y0[1]}, p23 = {(bf16_t)y1[0], (bf16_t)y1[1]};
+      return u32x2{__builtin_bit_cast(unsigned, p01), __builtin_bit_cast(unsigned, p23)};
+    };
+#if TV_HEAD_Y16
+    // Two t-tiles at a time: v_permlane16_swap exchanges the odd 16-lane rows of one register with the even rows of the
+    // other, after which a lane holds 16 contiguous bytes — columns 16 ct + 8 (kq >> 1) + 0..7 of token
+    // 16 (tp + (kq & 1)) + lc — and the chunk leaves in 2 PT stores of 16 bytes instead of 4 PT of 8 (the epilogue is
+    // bound by the issue of its stores).
+    const unsigned yo16 = yoff16;      // (an asm operand alone does not capture the variable in a generic lambda)
+#pragma unroll
+    for (int tp = 0; tp < 4; tp += 2) {
+      const void* yrow = uniform_ptr(ygs + (int64_t)(c * HQ + 16 * tp) * a.ysl);
+      const bool ok = (full || c * HQ + 16 * tp + 16 * (kq & 1) + lc < L) && !HDBG(a, 4);
+#pragma unroll
+      for (int ct = 0; ct < PT; ++ct) {
+        const u32x2 ya = finish(ct, tp), yb = finish(ct, tp + 1);
+        const auto s0 = __builtin_amdgcn_permlane16_swap(ya[0], yb[0], false, false);
+        const auto s1 = __builtin_amdgcn_permlane16_swap(ya[1], yb[1], false, false);
+        const u32x4v w = {s0[0], s1[0], s0[1], s1[1]};
+        if (ok) asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3" :: "v"(yo16), "v"(w), "s"(yrow), "n"(32 * ct) : "memory");
+      }
+    }
+#else
 #pragma unroll
     for (int ti = 0; ti < 4; ++ti) {
       const void* yrow = uniform_ptr(ygs + (int64_t)(c * HQ + 16 * ti) * a.ysl);
       const bool ok = (full || c * HQ + 16 * ti + lc < L) && !HDBG(a, 4);
 #pragma unroll
-      for (int ct = 0; ct < PT; ++ct) {
-        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-        const u32x2 xr = xrv[ti][ct];
-        const f32x2 e2 = {ev[ti], ev[ti]};
-        const f32x2 y0 = __builtin_elementwise_fma(f32x2{yo[ct][ti][0], yo[ct][ti][1]}, e2, dh2 * f32x2{bf16_lo(xr[0]), bf16_hi(xr[0])});
-        const f32x2 y1 = __builtin_elementwise_fma(f32x2{yo[ct][ti][2], yo[ct][ti][3]}, e2, dh2 * f32x2{bf16_lo(xr[1]), bf16_hi(xr[1])});
-        const bf16x2 p01 = {(bf16_t)y0[0], (bf16_t)y0[1]}, p23 = {(bf16_t)y1[0], (bf16_t)y1[1]};
-        store_y_tile(yrow, ok, ct, u32x2{__builtin_bit_cast(unsigned, p01), __builtin_bit_cast(unsigned, p23)});
-      }
+      for (int ct = 0; ct < PT; ++ct) store_y_tile(yrow, ok, ct, finish(ct, ti));
     }
+#endif
   };
 
   for (int c = 0; c < nchunks; ++c) {
@@ -720,7 +747,7 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
     }
     HSTAMP(9);
     // (the copies of the next chunk landed before the C.B^T wait; this step's y stores stay in flight)
-    if (UNTRACKED && (c + 1) * HQ <= L) HEAD_BARRIER(4 * PT);
+    if (UNTRACKED && (c + 1) * HQ <= L) HEAD_BARRIER(TV_HEAD_Y16 ? 2 * PT : 4 * PT);
     else HEAD_BARRIER(0);
   }
 #ifdef TV_HEAD_STAMP
@@ -731,18 +758,22 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
   {
     const float sc = __builtin_amdgcn_exp2f(E);
     float* fin = a.nseg > 1 ? a.seg_state + (int64_t)seg * gridDim.y * a.H * P * HN : a.final_state;
+    // (the lane's indices are formed again behind the loop: held across it they cost the fast kernel its only spill)
+    int lane_e = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane_e));
+    const int lc_e = lane_e & 15, kq_e = lane_e >> 4;
     if (fin) {
 #pragma unroll
       for (int ct = 0; ct < PT; ++ct)
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const f32x4 v = xacc[ct][i];
-          *(f32x4*)(fin + (((int64_t)b * a.H + h) * P + 16 * ct + lc) * HN + 32 * (i >> 1) + 8 * kq + 4 * (i & 1)) =
+          *(f32x4*)(fin + (((int64_t)b * a.H + h) * P + 16 * ct + lc_e) * HN + 32 * (i >> 1) + 8 * kq_e + 4 * (i & 1)) =
               f32x4{v[0] * sc, v[1] * sc, v[2] * sc, v[3] * sc};
         }
     }
     float* td = a.nseg > 1 ? a.seg_decay + (int64_t)seg * gridDim.y * a.H : a.total_decay;
-    if (td && lane == 0) td[(int64_t)b * a.H + h] = decay_total;
+    if (td && lane_e == 0) td[(int64_t)b * a.H + h] = decay_total;
   }
 }
 
@@ -812,8 +843,8 @@ bool tv_ssd_head_supported(int seqlen, int nheads, int headdim, int ngroups, int
                            const void* x, const void* Bm, const void* Cm, const void* y) {
   if (dtype != TV_BF16 || dstate != HN || seqlen < 1) return false;
   if (headdim != 32 && headdim != 64 && headdim != 80) return false;
-  if (xsl % 8 || bsl % 8 || csl % 8 || bsg % 8 || csg % 8 || ysl % 4) return false;
-  if (((uintptr_t)x & 15) || ((uintptr_t)Bm & 15) || ((uintptr_t)Cm & 15) || ((uintptr_t)y & 7)) return false;
+  if (xsl % 8 || bsl % 8 || csl % 8 || bsg % 8 || csg % 8 || ysl % 8) return false;
+  if (((uintptr_t)x & 15) || ((uintptr_t)Bm & 15) || ((uintptr_t)Cm & 15) || ((uintptr_t)y & 15)) return false;
   if (64 * xsl * 2 >= (1ll << 31) || 64 * bsl * 2 >= (1ll << 31) || 64 * csl * 2 >= (1ll << 31) ||
       64 * ysl * 2 >= (1ll << 31))
     return false;
