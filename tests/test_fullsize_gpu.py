@@ -46,10 +46,17 @@ def test_scan_full_length_properties(K):
     x, dt, A, Bm, Cm, D, bias = scan_inputs(L_FULL)
     y, fin, dec = run(K, x, dt, A, Bm, Cm, D, bias)
     assert torch.isfinite(y.float()).all() and torch.isfinite(fin).all()
-    # (1) y and the final state are linear in x: scaling by 2 is exact in bf16 and fp32
+    # (1) y and the final state are linear in x: scaling by 2 is exact in bf16 and fp32 — up to the contributions that a
+    # reset step of the head-per-wave march builds at the bottom of the exponent range (a chunk that decays by more than
+    # 2^-64 starts its state in the frame E = 100: weights below 2^-126, i.e. tokens whose true weight is < 2^-26 of the
+    # chunk's last, are flushed, and whether a product lands above or below that line depends on the scale of x): the last
+    # bit of a sum may differ, nothing more
     y2, fin2, _ = run(K, x * 2, dt, A, Bm, Cm, D, bias)
-    assert torch.equal(y2, y * 2) and torch.equal(fin2, fin * 2)
-    del y2, fin2
+    ne = (y2 != y * 2)
+    assert ne.float().mean() < 1e-3, ne.float().mean()
+    assert ((y2.float() - 2 * y.float()).abs() <= 2.0 ** -7 * (2 * y.float()).abs() + 1e-30).all()      # one bf16 step
+    assert rel(fin2, fin * 2) < 1e-6
+    del y2, fin2, ne
     # (2) shard chaining: two shards with the state handed over == one pass
     s = 81 * 1000 + 37                                   # not a multiple of the chunk length
     ya, fa, da = run(K, x[:, :s], dt[:, :s], A, Bm[:, :s], Cm[:, :s], D, bias)

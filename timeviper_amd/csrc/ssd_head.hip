@@ -47,7 +47,8 @@ int tv_ssd_correct_all_launch(void* y, const void* dt, const void* A, const void
                               float* total_decay, const float* chunk_tot, int batch, int seqlen, int nheads,
                               int headdim, int ngroups, int nseg, int seg_chunks, int64_t ysb, int64_t ysl,
                               int64_t dsb, int64_t dsl, int64_t csb, int64_t csl, int64_t csg, int dt_softplus,
-                              float dt_min, float dt_max, int group_map, void* workspace, hipStream_t st);
+                              float dt_min, float dt_max, int group_map, void* workspace, hipStream_t st,
+                              const int* gate, int gate_run_if);
 
 #ifndef TV_HEAD_PIN
 #define TV_HEAD_PIN 0
@@ -55,6 +56,12 @@ int tv_ssd_correct_all_launch(void* y, const void* dt, const void* A, const void
 // TV_HEAD_Y16: 1 = y leaves in 16-byte stores (two t-tiles joined by v_permlane16_swap), 0 = 8-byte stores
 #ifndef TV_HEAD_Y16
 #define TV_HEAD_Y16 1
+#endif
+// TV_HEAD_RESET: 1 = a chunk that decays by more than 2^-RESET_THR starts the state anew (its carry-over, < 2^-RESET_THR of
+// the old state, is dropped): the first k-step of the state update accumulates onto zero, the new state is built
+// directly in the frame E = RMAX, and the re-basing pass such a head would need on every step never runs
+#ifndef TV_HEAD_RESET
+#define TV_HEAD_RESET 1
 #endif
 namespace {
 using namespace ssdk;
@@ -64,6 +71,7 @@ constexpr int HN = 128;           // d_state
 constexpr int NFR = 6;            // causal (t-tile, s-pair) fragments of a 64x64 chunk: (0,0) (1,0) (2,0) (2,1) (3,0) (3,1)
 constexpr int CBE = NFR * 512;    // bf16 elements of C.B^T per (chunk, group)
 constexpr float RMAX = 100.f;     // the floating frame stays within 2^(+-RMAX)
+constexpr float RESET_THR = 64.f; // log2 decay of a chunk from which on the carried state is dropped (TV_HEAD_RESET)
 
 struct HeadArgs {
   const bf16_t *x, *dt, *Bm, *Cm, *cb;
@@ -72,6 +80,8 @@ struct HeadArgs {
   float *final_state, *total_decay;
   float *seg_state, *seg_decay, *chunk_tot;     // nseg > 1: per-segment results for the combine / correction pass
   int* redo;                                    // per work-group: 1 = the complete kernel has to march this work-group again
+  const int* gate;                              // optional: the kernel returns at once unless (*gate != 0) == gate_run_if
+  int gate_run_if;
   int nseg, seg_chunks;
   int L, H, P, G, nchunks;
   int64_t xsb, xsl, dsb, dsl, bsb, bsl, bsg, csb, csl, csg, ysb, ysl;
@@ -102,6 +112,7 @@ struct __attribute__((aligned(16))) HeadVec {   // per-chunk vectors of one head
   float dtv[HQ];      // discretised dt
   float ut[HQ];       // 2^(cs_t - cs_{16 (t/16)}): row factor of the separable off-diagonal mask blocks
   float wts[HQ];      // weight of token s in the state update (frame-dependent)
+  float wtd[2][HQ];   // (by chunk parity: prep of the next chunk runs before this chunk's Ydiag) reset steps: weight of token s in Ydiag (the floating frame's; wts then builds the new state at E = RMAX)
   float ecs[HQ];      // 2^(cs_t + E): row factor of Yoff
   float ws[128];      // column factors of the separable blocks: t-tile 1 at [0,16), 2 at [16,48), 3 at [48,96)
 };
@@ -169,6 +180,7 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
   const int t_first = c_first * HQ;
   const int nchunks = min(a.seg_chunks, a.nchunks - c_first);
   const int L = min(a.L - t_first, nchunks * HQ);
+  if (a.gate && (*a.gate != 0) != (a.gate_run_if != 0)) return;
   int* const redo = a.redo + ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
   if (RARE && *redo == 0) return;
   HeadVec& vec = sm.v[wave];
@@ -320,6 +332,7 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
   //   1  floating step after the frame has been re-based to E ~ +RMAX: the caller multiplies the state by 2^f (f = -m, an
   //      integer) first;
   //   2  standard step (one chunk decays by more than 2^(2 RMAX)): X' *= f = 2^(E + cs_Q) inside the step, true mask.
+  bool reset_next = false, reset_cur = false;     // (wave-uniform)
   auto prep = [&](int c, unsigned raw_bits, float& f_out) __attribute__((always_inline)) {
     const int t = c * HQ + lane;
     float d = 0.f;
@@ -344,7 +357,10 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
     vec.cs[lane] = cs2;
     vec.dtv[lane] = d;
     vec.ecs[lane] = __builtin_amdgcn_exp2f(cs2 + Euse);
-    vec.wts[lane] = __builtin_amdgcn_exp2f(mode == 2 ? cl2 - cs2 : -cs2 - Euse) * d;
+    const bool rst = TV_HEAD_RESET && mode != 2 && cl2 <= -RESET_THR;
+    reset_next = rst;
+    vec.wts[lane] = __builtin_amdgcn_exp2f(mode == 2 ? cl2 - cs2 : rst ? cl2 - cs2 - RMAX : -cs2 - Euse) * d;
+    if (rst) vec.wtd[c & 1][lane] = __builtin_amdgcn_exp2f(-cs2 - Euse) * d;
     if (a.chunk_tot && lane == 0) a.chunk_tot[((int64_t)b * a.H + h) * a.nchunks + c_first + c] = cl2;
     if (__builtin_expect(mode == 2, 0)) {
       // separable factors of the off-diagonal mask blocks (pivot = first token of a t-tile): standard steps only
@@ -356,7 +372,7 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
       if (lane < 48) vec.ws[48 + lane] = __builtin_amdgcn_exp2f(fminf(p3 - cs2, 0.f)) * d;
     }
     decay_total += cl;
-    E = mode == 2 ? 0.f : Euse + cl2;
+    E = mode == 2 ? 0.f : rst ? RMAX : Euse + cl2;
     return __builtin_amdgcn_readfirstlane(mode);
   };
 
@@ -458,6 +474,7 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(dt_next) :: "memory");
   float f_step;
   int mode = prep(0, dt_next, f_step);
+  reset_cur = __builtin_amdgcn_readfirstlane((int)reset_next) != 0;
   if (mode == 1) rebase_state((int)f_step);
   dt_next = load_dt(min(1, nchunks - 1));
   HEAD_BARRIER(0);
@@ -474,6 +491,7 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
   // reuse; quarter 1: C.B^T of this chunk, x of the next; quarter 2: B / C of the next chunk, dt of the one after.
   auto step = [&](int c, bool more, auto STDT) __attribute__((always_inline)) {
     constexpr bool STD = decltype(STDT)::value;
+    const bool reset_step = reset_cur;       // this chunk builds its state anew (its own value: prep below sets the next chunk's)
     const unsigned char* Bt = reinterpret_cast<const unsigned char*>(sm.bt[c % NB]);
     const unsigned char* Ct = reinterpret_cast<const unsigned char*>(sm.ct[c % NB]);
     const unsigned xt = lds_xr + (c & 1) * XSLOT;
@@ -532,8 +550,13 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
         } else {
           const int ks = (j - 4) >> 1, ii = (j - 4) & 1;
           const bf16x8 bfrag = cat4(bt2[ii][2 * ks], bt2[ii][2 * ks + 1]);
+          if (TV_HEAD_RESET && !STD && ks == 0 && reset_step) {
 #pragma unroll
-          for (int ct = 0; ct < PT; ++ct) xacc[ct][2 * q + ii] = mfma16(bfrag, xw[ct][ks], xacc[ct][2 * q + ii]);
+            for (int ct = 0; ct < PT; ++ct) xacc[ct][2 * q + ii] = mfma16(bfrag, xw[ct][0], f32x4{0.f, 0.f, 0.f, 0.f});
+          } else {
+#pragma unroll
+            for (int ct = 0; ct < PT; ++ct) xacc[ct][2 * q + ii] = mfma16(bfrag, xw[ct][ks], xacc[ct][2 * q + ii]);
+          }
         }
         if (q < 3 && j < PT) sbn[j] = snap_tile(q + 1, j);
         filler(j);
@@ -592,6 +615,31 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
     }
     quarter(3, cq[1], bq[1], sbq[1], sbq[0], [&](int) {}, false);
     HSTAMP(5);
+    if (TV_HEAD_RESET && !STD && reset_step) {
+      // the state update ran on x~ in the NEW frame; Ydiag shares the accumulators with Yoff and needs the old frame's
+      asm volatile("; reset step: x~ for Ydiag" ::);
+      f32x4 wq[2][2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        wq[ks][0] = *(const f32x4*)(&vec.wtd[c & 1][32 * ks + 8 * kq]);
+        wq[ks][1] = *(const f32x4*)(&vec.wtd[c & 1][32 * ks + 8 * kq + 4]);
+      }
+#pragma unroll
+      for (int ct = 0; ct < PT; ++ct)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const u32x4v u = __builtin_bit_cast(u32x4v, read_xf(xt, ct, ks));
+          u32x4v o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+            const f32x2 pr = f32x2{bf16_lo(u[e]), bf16_hi(u[e])} * f32x2{wq[ks][e >> 1][(2 * e) & 3], wq[ks][e >> 1][(2 * e + 1) & 3]};
+            const bf16x2 pk = {(bf16_t)pr[0], (bf16_t)pr[1]};
+            o[e] = __builtin_bit_cast(unsigned, pk);
+          }
+          xw[ct][ks] = __builtin_bit_cast(bf16x8, o);
+        }
+    }
     // C.B^T has landed; what was issued behind it (the last x copies, dt) may stay in flight
     if (UNTRACKED && more && (c + 2) * HQ <= L) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NXG > 2 ? NXI - 8 : 0) + 1) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -683,6 +731,7 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
     if (c + 1 < nchunks) {
       if (STD) mode_next = prep(c + 1, dt_raw, f_step);
       mode = mode_next;
+      reset_cur = __builtin_amdgcn_readfirstlane((int)reset_next) != 0;
       if (mode == 1) rebase_state((int)f_step);
     }
     HSTAMP(8);
@@ -695,7 +744,7 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
 #pragma unroll
       for (int ct = 0; ct < PT; ++ct) {
         typedef __attribute__((address_space(3))) const u32x2 lds_u32x2;
-        xrv[ti][ct] = *(lds_u32x2*)(xt + xv_lo + 32 * ct + ti * (16 * XROW));
+        xrv[ti][ct] = *(lds_u32x2*)(size_t)(xt + xv_lo + 32 * ct + ti * (16 * XROW));
       }
     auto finish = [&](int ct, int ti) {       // the lane's 8 bytes of y: columns 16 ct + 4 kq + 0..3 of token 16 ti + lc
       typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -777,6 +826,36 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
   }
 }
 
+// Does any chunk of this call need a standard step (decay of more than 2^(2 RMAX - 1) inside one chunk)?  grid (nchunks,
+// ceil(H / 4), B), 4 waves: wave = head, lane = token of the chunk.  tv_ssd_scan_fwd (automatic mode) launches the
+// head-per-wave kernels and the slice-march kernels behind this check and lets the sequence that fits the data run: the
+// fast head kernel cannot take such chunks, its complete variant takes them at a third of the slice march's speed.
+struct StdCheckArgs {
+  const bf16_t* dt;
+  const float *A, *dt_bias;
+  int* flag;
+  int L, H;
+  int64_t dsb, dsl;
+  int softplus;
+  float dt_min, dt_max;
+};
+__global__ __launch_bounds__(256) void ssd_std_check_kernel(StdCheckArgs a) {
+  const int c = blockIdx.x, b = blockIdx.z;
+  const int h = blockIdx.y * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (h >= a.H) return;
+  const int t = c * HQ + lane;
+  float d = 0.f;
+  if (t < a.L) {
+    d = (float)a.dt[(int64_t)b * a.dsb + (int64_t)t * a.dsl + h] + (a.dt_bias ? a.dt_bias[h] : 0.f);
+    if (a.softplus) d = softplus_fast(d);
+    d = fminf(fmaxf(d, a.dt_min), a.dt_max);
+  }
+  const float cl2 = wave_sum(d) * a.A[h] * 1.4426950408889634f;
+  // (a margin of 2 against the march's own sum, which adds in another order: a chunk this close to the limit that the
+  // fast kernel still refuses is caught by its flag and the complete kernel)
+  if (lane == 0 && -cl2 > 2.f * RMAX - 3.f) *a.flag = 1;
+}
+
 // heads of one group per work-group: 4, 2 or 1
 int pick_nw(int hpg) { return hpg % 4 == 0 ? 4 : hpg % 2 == 0 ? 2 : 1; }
 
@@ -826,7 +905,9 @@ hipError_t launch_head(const HeadArgs& a, dim3 grid, hipStream_t st) {
   e = hipMemsetAsync(a.redo, only_rare ? 1 : 0, sizeof(int) * grid.x * grid.y * grid.z, st);
   if (e != hipSuccess) return e;
   if (!only_rare) ssd_head_kernel<PT, NW, NB, false><<<grid, NW * 64, sizeof(Smem), st>>>(a);
-  ssd_head_kernel<PT, NW, NB, true><<<grid, NW * 64, sizeof(Smem), st>>>(a);
+  // (behind the automatic mode's check no chunk needs a standard step — its margin covers the difference between its
+  // sum and the march's — so the complete kernel has nothing to do and is not launched)
+  if (!a.gate) ssd_head_kernel<PT, NW, NB, true><<<grid, NW * 64, sizeof(Smem), st>>>(a);
   return hipSuccess;
 }
 
@@ -862,7 +943,7 @@ int tv_ssd_head_launch(const void* x, const void* dt, const void* A, const void*
                        int ngroups, int64_t xsb, int64_t xsl, int64_t dsb, int64_t dsl, int64_t bsb,
                        int64_t bsl, int64_t bsg, int64_t csb, int64_t csl, int64_t csg, int64_t ysb,
                        int64_t ysl, int dt_softplus, float dt_min, float dt_max, int group_map,
-                       void* workspace, size_t workspace_bytes, const void* cb_pre, hipStream_t st) {
+                       void* workspace, size_t workspace_bytes, const void* cb_pre, hipStream_t st, int* gate) {
   const HeadLayout lay = head_layout(batch, seqlen, nheads, headdim, ngroups);
   TV_CHECK_ARG(workspace && workspace_bytes >= lay.total && (((uintptr_t)workspace) & 15) == 0,
                "ssd_head: workspace of %zu bytes (16-byte aligned) required, got %zu", lay.total, workspace_bytes);
@@ -880,6 +961,14 @@ int tv_ssd_head_launch(const void* x, const void* dt, const void* A, const void*
   a.seg_decay = lay.nseg > 1 ? (float*)(wsb + lay.seg_decay) : nullptr;
   a.chunk_tot = lay.nseg > 1 ? (float*)(wsb + lay.ctot) : nullptr;
   a.redo = (int*)(wsb + lay.redo);
+  a.gate = gate; a.gate_run_if = 0;      // behind the check: run only when no chunk needs a standard step
+  if (gate) {
+    if (hipMemsetAsync(gate, 0, sizeof(int), st) != hipSuccess) { tv_set_error("ssd_head: memset failed"); return TV_ERR_LAUNCH; }
+    StdCheckArgs ca;
+    ca.dt = (const bf16_t*)dt; ca.A = (const float*)A; ca.dt_bias = (const float*)dt_bias; ca.flag = gate;
+    ca.L = seqlen; ca.H = nheads; ca.dsb = dsb; ca.dsl = dsl; ca.softplus = dt_softplus; ca.dt_min = dt_min; ca.dt_max = dt_max;
+    ssd_std_check_kernel<<<dim3((seqlen + HQ - 1) / HQ, (nheads + 3) / 4, batch), 256, 0, st>>>(ca);
+  }
   a.xsb = xsb; a.xsl = xsl; a.dsb = dsb; a.dsl = dsl; a.bsb = bsb; a.bsl = bsl; a.bsg = bsg;
   a.csb = csb; a.csl = csl; a.csg = csg; a.ysb = ysb; a.ysl = ysl;
   a.softplus = dt_softplus; a.group_map = group_map; a.dt_min = dt_min; a.dt_max = dt_max;
@@ -913,7 +1002,7 @@ int tv_ssd_head_launch(const void* x, const void* dt, const void* A, const void*
     const int rc = tv_ssd_correct_all_launch(y, dt, A, Cm, dt_bias, a.seg_state, a.seg_decay, (float*)final_state,
                                              (float*)total_decay, a.chunk_tot, batch, seqlen, nheads, headdim,
                                              ngroups, a.nseg, a.seg_chunks, ysb, ysl, dsb, dsl, csb, csl, csg,
-                                             dt_softplus, dt_min, dt_max, group_map, wsb + lay.corr, st);
+                                             dt_softplus, dt_min, dt_max, group_map, wsb + lay.corr, st, gate, 0);
     if (rc != TV_OK) return rc;
   }
   TV_LAUNCH_CHECK();

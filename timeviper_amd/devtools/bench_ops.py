@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--impl", type=int, default=0)
     ap.add_argument("--token-major", action="store_true", help="B/C as column slices of the conv rows")
     ap.add_argument("--model-dt", action="store_true", help="dt_bias / dt as in the 9B model's init (slowly forgetting heads)")
+    ap.add_argument("--dt-std", type=float, default=0.02, help="with --model-dt: standard deviation of the raw dt (the synthetic 9B model: ~1.3)")
     ap.add_argument("--no-cb", action="store_true", help="scan recomputes C.B^T in its pre-pass (round 2)")
     a = ap.parse_args()
     L = a.tokens
@@ -68,7 +69,7 @@ def main():
         if a.model_dt:      # the 9B model's initialisation (modeling_nano.py:1345-1357): dt in [1e-3, 0.1], slow heads exist
             dtv = torch.exp(torch.rand(H, device=dev, generator=g) * (math.log(0.1) - math.log(1e-3)) + math.log(1e-3))
             dtb = dtv + torch.log(-torch.expm1(-dtv))
-            dt = (dt.float() * 0.02).bfloat16()
+            dt = (dt.float() * a.dt_std).bfloat16()
         else:
             dtb = torch.full((H,), -3.0, device=dev)
         fn = lambda: K.mamba_chunk_scan_combined(x.view(1, L, H, P), dt, A, Bm, Cm,
