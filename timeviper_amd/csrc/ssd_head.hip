@@ -826,8 +826,7 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
   }
 }
 
-// Does any chunk of this call need a standard step (decay of more than 2^(2 RMAX - 1) inside one chunk)?  grid (nchunks,
-// ceil(H / 4), B), 4 waves: wave = head, lane = token of the chunk.  tv_ssd_scan_fwd (automatic mode) launches the
+// Does any chunk of this call need a standard step (decay of more than 2^(2 RMAX - 1) inside one chunk)?  tv_ssd_scan_fwd (automatic mode) launches the
 // head-per-wave kernels and the slice-march kernels behind this check and lets the sequence that fits the data run: the
 // fast head kernel cannot take such chunks, its complete variant takes them at a third of the slice march's speed.
 struct StdCheckArgs {
@@ -839,21 +838,24 @@ struct StdCheckArgs {
   int softplus;
   float dt_min, dt_max;
 };
-__global__ __launch_bounds__(256) void ssd_std_check_kernel(StdCheckArgs a) {
-  const int c = blockIdx.x, b = blockIdx.z;
-  const int h = blockIdx.y * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+__global__ __launch_bounds__(128) void ssd_std_check_kernel(StdCheckArgs a) {
+  // grid (nchunks, ceil(H / 128), B): thread = head (the heads of a token are contiguous: every load of a wave is one
+  // 128-byte line; with lane = token the 2-byte loads were 64 lines apart and the check took 91 us for 42 MB)
+  const int c = blockIdx.x, b = blockIdx.z, h = blockIdx.y * 128 + threadIdx.x;
   if (h >= a.H) return;
-  const int t = c * HQ + lane;
-  float d = 0.f;
-  if (t < a.L) {
-    d = (float)a.dt[(int64_t)b * a.dsb + (int64_t)t * a.dsl + h] + (a.dt_bias ? a.dt_bias[h] : 0.f);
+  const float bias = a.dt_bias ? a.dt_bias[h] : 0.f;
+  const int t0 = c * HQ, n = min(HQ, a.L - t0);
+  const bf16_t* p = a.dt + (int64_t)b * a.dsb + (int64_t)t0 * a.dsl + h;
+  float sum = 0.f;
+#pragma unroll 8
+  for (int t = 0; t < n; ++t) {
+    float d = (float)p[(int64_t)t * a.dsl] + bias;
     if (a.softplus) d = softplus_fast(d);
-    d = fminf(fmaxf(d, a.dt_min), a.dt_max);
+    sum += fminf(fmaxf(d, a.dt_min), a.dt_max);
   }
-  const float cl2 = wave_sum(d) * a.A[h] * 1.4426950408889634f;
-  // (a margin of 2 against the march's own sum, which adds in another order: a chunk this close to the limit that the
-  // fast kernel still refuses is caught by its flag and the complete kernel)
-  if (lane == 0 && -cl2 > 2.f * RMAX - 3.f) *a.flag = 1;
+  const float cl2 = sum * a.A[h] * 1.4426950408889634f;
+  // (a margin of 2 against the march's own sum, which adds in another order)
+  if (-cl2 > 2.f * RMAX - 3.f) *a.flag = 1;
 }
 
 // heads of one group per work-group: 4, 2 or 1
@@ -967,7 +969,7 @@ int tv_ssd_head_launch(const void* x, const void* dt, const void* A, const void*
     StdCheckArgs ca;
     ca.dt = (const bf16_t*)dt; ca.A = (const float*)A; ca.dt_bias = (const float*)dt_bias; ca.flag = gate;
     ca.L = seqlen; ca.H = nheads; ca.dsb = dsb; ca.dsl = dsl; ca.softplus = dt_softplus; ca.dt_min = dt_min; ca.dt_max = dt_max;
-    ssd_std_check_kernel<<<dim3((seqlen + HQ - 1) / HQ, (nheads + 3) / 4, batch), 256, 0, st>>>(ca);
+    ssd_std_check_kernel<<<dim3((seqlen + HQ - 1) / HQ, (nheads + 127) / 128, batch), 128, 0, st>>>(ca);
   }
   a.xsb = xsb; a.xsl = xsl; a.dsb = dsb; a.dsl = dsl; a.bsb = bsb; a.bsl = bsl; a.bsg = bsg;
   a.csb = csb; a.csl = csl; a.csg = csg; a.ysb = ysb; a.ysl = ysl;
