@@ -67,8 +67,8 @@ def test_head_scan_fast_kernels_spill_nothing(tmp_path):
     assert len(fast4) >= 3, list(md)
     for k, v in fast4.items():
         assert v.get("private_segment_fixed_size") == 0 and v.get("vgpr_spill_count", 0) == 0, (k, v)
-    # the complete kernels may spill (they use ordinary loads); they must exist
-    assert any("Lb1E" in k for k in md)
+    # (other variants — fewer waves per work-group, the complete kernel of a -DTV_HEAD_UNISTD=0 build — may spill: they use
+    # ordinary loads)
 
 
 @needs_tools

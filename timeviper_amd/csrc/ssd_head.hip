@@ -63,6 +63,17 @@ int tv_ssd_correct_all_launch(void* y, const void* dt, const void* A, const void
 #ifndef TV_HEAD_RESET
 #define TV_HEAD_RESET 1
 #endif
+// TV_HEAD_UNISTD: 1 = the fast kernel takes standard steps itself, as three side blocks of the one step body (scaled
+// accumulators, per-head mask built into the C.B^T registers, raw x fragments) — no complete kernel, no check;
+// 0 = round 3's first scheme (flag + complete kernel, or the device-side check of the automatic mode)
+// TV_HEAD_UNTRACKED: 1 = the C.B^T / dt loads of the 4-wave fast kernels are inline asm with counted waits (needs a
+// kernel without scratch), 0 = ordinary loads
+#ifndef TV_HEAD_UNTRACKED
+#define TV_HEAD_UNTRACKED 1
+#endif
+#ifndef TV_HEAD_UNISTD
+#define TV_HEAD_UNISTD 1
+#endif
 namespace {
 using namespace ssdk;
 
@@ -160,7 +171,7 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
   // register with such a load in flight may otherwise be saved before its data has arrived (seen: the complete kernel
   // read stale C.B^T fragments that way).  Only the 4-wave fast kernels are held to zero scratch
   // (tests/test_build_cpu.py reads it off the code object); every other variant uses ordinary loads and full waits.
-  constexpr bool UNTRACKED = !RARE && NW == 4;
+  constexpr bool UNTRACKED = TV_HEAD_UNTRACKED && !RARE && NW == 4;
   constexpr int BD = NB - 1;            // B/C prefetch distance (chunks)
   static_assert(BD == 1, "the waits below are counted for a B/C ring of 2");
   constexpr int P = PT * 16;
@@ -332,7 +343,7 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
   //   1  floating step after the frame has been re-based to E ~ +RMAX: the caller multiplies the state by 2^f (f = -m, an
   //      integer) first;
   //   2  standard step (one chunk decays by more than 2^(2 RMAX)): X' *= f = 2^(E + cs_Q) inside the step, true mask.
-  bool reset_next = false, reset_cur = false;     // (wave-uniform)
+  bool reset_next = false, reset_cur = false, std_next = false, std_cur = false;     // (wave-uniform)
   auto prep = [&](int c, unsigned raw_bits, float& f_out) __attribute__((always_inline)) {
     const int t = c * HQ + lane;
     float d = 0.f;
@@ -345,7 +356,7 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
     const float cl = rdlane(cs, 63);
     const float cs2 = cs * 1.4426950408889634f, cl2 = cl * 1.4426950408889634f;
     int mode = -(E + cl2) <= RMAX ? 0 : -cl2 <= 2.f * RMAX - 1.f ? 1 : 2;
-    if (!RARE && mode == 2) {          // not this kernel's business: flag the work-group, go on with a re-basing step
+    if (!RARE && !TV_HEAD_UNISTD && mode == 2) {          // not this kernel's business: flag the work-group, go on with a re-basing step
       if (lane == 0) *redo = 1;
       mode = 1;
     }
@@ -358,7 +369,9 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
     vec.dtv[lane] = d;
     vec.ecs[lane] = __builtin_amdgcn_exp2f(cs2 + Euse);
     const bool rst = TV_HEAD_RESET && mode != 2 && cl2 <= -RESET_THR;
-    reset_next = rst;
+    const bool ustd = !RARE && TV_HEAD_UNISTD && mode == 2;     // standard step inside the fast kernel: always a reset step
+    reset_next = rst || ustd;
+    std_next = ustd;
     vec.wts[lane] = __builtin_amdgcn_exp2f(mode == 2 ? cl2 - cs2 : rst ? cl2 - cs2 - RMAX : -cs2 - Euse) * d;
     if (rst) vec.wtd[c & 1][lane] = __builtin_amdgcn_exp2f(-cs2 - Euse) * d;
     if (a.chunk_tot && lane == 0) a.chunk_tot[((int64_t)b * a.H + h) * a.nchunks + c_first + c] = cl2;
@@ -373,7 +386,7 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
     }
     decay_total += cl;
     E = mode == 2 ? 0.f : rst ? RMAX : Euse + cl2;
-    return __builtin_amdgcn_readfirstlane(mode);
+    return __builtin_amdgcn_readfirstlane(ustd ? 0 : mode);
   };
 
   // ------------------------------------------------------------------ state, fragment addresses
@@ -475,6 +488,7 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
   float f_step;
   int mode = prep(0, dt_next, f_step);
   reset_cur = __builtin_amdgcn_readfirstlane((int)reset_next) != 0;
+  std_cur = __builtin_amdgcn_readfirstlane((int)std_next) != 0;
   if (mode == 1) rebase_state((int)f_step);
   dt_next = load_dt(min(1, nchunks - 1));
   HEAD_BARRIER(0);
@@ -492,6 +506,7 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
   auto step = [&](int c, bool more, auto STDT) __attribute__((always_inline)) {
     constexpr bool STD = decltype(STDT)::value;
     const bool reset_step = reset_cur;       // this chunk builds its state anew (its own value: prep below sets the next chunk's)
+    const bool ustd_step = !STD && TV_HEAD_UNISTD && std_cur;     // ... and is a standard step done by this (the one) step body
     const unsigned char* Bt = reinterpret_cast<const unsigned char*>(sm.bt[c % NB]);
     const unsigned char* Ct = reinterpret_cast<const unsigned char*>(sm.ct[c % NB]);
     const unsigned xt = lds_xr + (c & 1) * XSLOT;
@@ -589,7 +604,7 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
     read_b2(Bt, 6, bq[1]);
     quarter(2, cq[0], bq[0], sbq[0], sbq[1], [&](int j) {           // the rest of x, dt of the chunk after the next
       if (more && j == 0 && NXG > 1 && !HDBG(a, 32)) issue_x(c + 1, 1);
-      if (j == 2 && !STD && !HDBG(a, 8)) {       // C.B^T of this chunk
+      if (j == 5 && !STD && !HDBG(a, 8)) {       // C.B^T of this chunk (behind the last x copies: only dt is issued after it)
 #pragma unroll
         for (int f = 0; f < NFR; ++f) {
           u32x4v r;
@@ -609,13 +624,13 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
     // floating steps: the vectors of the NEXT chunk are prepared here, in one scheduling region with the MFMAs of the last
     // quarter (everything that reads this chunk's vectors has been read; the re-basing of the frame waits for the quarter)
     int mode_next = 0;
-    if (!STD && c + 1 < nchunks) {
+    if (!STD && !ustd_step && c + 1 < nchunks) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       mode_next = prep(c + 1, dt_raw, f_step);
     }
     quarter(3, cq[1], bq[1], sbq[1], sbq[0], [&](int) {}, false);
     HSTAMP(5);
-    if (TV_HEAD_RESET && !STD && reset_step) {
+    if (TV_HEAD_RESET && !STD && reset_step && !ustd_step) {
       // the state update ran on x~ in the NEW frame; Ydiag shares the accumulators with Yoff and needs the old frame's
       asm volatile("; reset step: x~ for Ydiag" ::);
       f32x4 wq[2][2];
@@ -641,13 +656,103 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
         }
     }
     // C.B^T has landed; what was issued behind it (the last x copies, dt) may stay in flight
-    if (UNTRACKED && more && (c + 2) * HQ <= L) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NXG > 2 ? NXI - 8 : 0) + 1) : "memory");
+    if (UNTRACKED && more && (c + 2) * HQ <= L) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (!STD) {
 #pragma unroll
       for (int f = 0; f < NFR; ++f) asm volatile("" : "+v"(cbv[f]));
     }
     HSTAMP(6);
+    if (ustd_step) {
+      // ---- standard step inside the one step body (a chunk that decays by more than 2^-199: no single frame holds its
+      // weights).  Three side blocks turn the common Ydiag below into the true-mask form:
+      //   (1) the accumulators get their row factor NOW (2^(cs_t + E); tiles that the old state no longer reaches
+      //       become zeros), by hand like every vector access of accumulation registers in this kernel;
+      //   (2) the per-head mask M = CB .* 2^(cs_t - cs_s) dt_s [s <= t] replaces C.B^T in its registers: diagonal
+      //       16x16 blocks one exponential per element (by lane half: fragments (0,0) / (1,0) and (2,1) / (3,1)), the
+      //       other blocks separable around the first token of their t-tile, ut[t] ws[s];
+      //   (3) the A operand becomes the raw x fragments.
+      // The state update of such a chunk ran with the standard weights 2^(cs_Q - cs_s) dt_s onto zero (reset: E = 0).
+      asm volatile("; standard step" ::);
+#pragma unroll
+      for (int ct = 0; ct < PT; ++ct)
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) {
+          float e0 = yo[ct][ti][0], e1 = yo[ct][ti][1], e2 = yo[ct][ti][2], e3 = yo[ct][ti][3], t0, t1, t2, t3;
+          asm volatile("v_accvgpr_read_b32 %4, %0\n\tv_accvgpr_read_b32 %5, %1\n\tv_accvgpr_read_b32 %6, %2\n\tv_accvgpr_read_b32 %7, %3\n\t"
+                       "v_mul_f32 %4, %8, %4\n\tv_mul_f32 %5, %8, %5\n\tv_mul_f32 %6, %8, %6\n\tv_mul_f32 %7, %8, %7\n\t"
+                       "v_accvgpr_write_b32 %0, %4\n\tv_accvgpr_write_b32 %1, %5\n\tv_accvgpr_write_b32 %2, %6\n\tv_accvgpr_write_b32 %3, %7"
+                       : "+a"(e0), "+a"(e1), "+a"(e2), "+a"(e3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3) : "v"(ev[ti]));
+          yo[ct][ti] = f32x4{e0, e1, e2, e3};
+        }
+      asm volatile("s_nop 7" ::: "memory");
+      {
+        const int hi = kq >> 1;
+        auto diag = [&](int t, int s0, float (&e)[8]) {       // e[j] = 2^(cs_t - cs_(s0 + j)) dt_(s0 + j) for s0 + j <= t, else 0
+          const float cst = vec.cs[t];
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            const f32x4 cv = *(const f32x4*)(&vec.cs[s0 + 4 * hh]), dv = *(const f32x4*)(&vec.dtv[s0 + 4 * hh]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              e[4 * hh + j] = __builtin_amdgcn_exp2f(s0 + 4 * hh + j <= t ? cst - cv[j] : -__builtin_inff()) * dv[j];
+          }
+        };
+        auto sepf = [&](int t, int wofs, float (&e)[8]) {      // e[j] = ut[t] ws[wofs + j]
+          const float u = vec.ut[t];
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            const f32x4 wv = *(const f32x4*)(&vec.ws[wofs + 4 * hh]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e[4 * hh + j] = u * wv[j];
+          }
+        };
+        auto apply = [&](int f, const float (&fac)[8]) {       // cbv[f] <- bf16(CB_f .* fac)
+          const u32x4v cw = __builtin_bit_cast(u32x4v, cbv[f]);
+          u32x4v o;
+#pragma unroll
+          for (int jp = 0; jp < 4; ++jp) {
+            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+            const bf16x2 pk = {(bf16_t)(bf16_lo(cw[jp]) * fac[2 * jp]), (bf16_t)(bf16_hi(cw[jp]) * fac[2 * jp + 1])};
+            o[jp] = __builtin_bit_cast(unsigned, pk);
+          }
+          cbv[f] = __builtin_bit_cast(bf16x8, o);
+        };
+        float eD[8], eS[8], fac[8];
+        const int sA = 8 * kq;
+        diag(16 * hi + lc, sA, eD);                           // diagonal blocks of fragments (0,0) [hi = 0] and (1,0) [hi = 1]
+#pragma unroll
+        for (int j = 0; j < 8; ++j) fac[j] = hi ? 0.f : eD[j];
+        apply(0, fac);
+        sepf(16 + lc, sA & 15, eS);                           // block (1,0)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) fac[j] = hi ? eD[j] : eS[j];
+        apply(1, fac);
+        sepf(32 + lc, 16 + sA, eS);                           // blocks (2,0), (2,1)
+        apply(2, eS);
+        diag(32 + 16 * hi + lc, 32 + sA, eD);                 // diagonal blocks of fragments (2,1) [hi = 0] and (3,1) [hi = 1]
+#pragma unroll
+        for (int j = 0; j < 8; ++j) fac[j] = hi ? 0.f : eD[j];
+        apply(3, fac);
+        sepf(48 + lc, 48 + sA, eS);                           // blocks (3,0), (3,1)
+        apply(4, eS);
+        sepf(48 + lc, 48 + 32 + (sA & 15), eS);               // block (3,2)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) fac[j] = hi ? eD[j] : eS[j];
+        apply(5, fac);
+      }
+#pragma unroll
+      for (int ct = 0; ct < PT; ++ct)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) xw[ct][ks] = read_xf(xt, ct, ks);
+#pragma unroll
+      for (int ti = 0; ti < 4; ++ti) ev[ti] = 1.f;
+      // the vectors of the next chunk (floating steps prepared them inside quarter 3; this step still needed its own)
+      if (c + 1 < nchunks) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        mode_next = prep(c + 1, dt_raw, f_step);
+      }
+    }
     if constexpr (!STD) {
       // ---- Ydiag on top of Yoff, same frame: the A operand is x~, the B operand the causal C.B^T fragment
 #pragma unroll
@@ -732,6 +837,7 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
       if (STD) mode_next = prep(c + 1, dt_raw, f_step);
       mode = mode_next;
       reset_cur = __builtin_amdgcn_readfirstlane((int)reset_next) != 0;
+      std_cur = __builtin_amdgcn_readfirstlane((int)std_next) != 0;
       if (mode == 1) rebase_state((int)f_step);
     }
     HSTAMP(8);
@@ -900,6 +1006,10 @@ hipError_t launch_head(const HeadArgs& a, dim3 grid, hipStream_t st) {
   hipError_t e = hipFuncSetAttribute((const void*)ssd_head_kernel<PT, NW, NB, false>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem));
   if (e != hipSuccess) return e;
+#if TV_HEAD_UNISTD
+  // one kernel takes every chunk (standard steps included): no flags, no second launch
+  ssd_head_kernel<PT, NW, NB, false><<<grid, NW * 64, sizeof(Smem), st>>>(a);
+#else
   e = hipFuncSetAttribute((const void*)ssd_head_kernel<PT, NW, NB, true>,
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem));
   if (e != hipSuccess) return e;
@@ -910,6 +1020,7 @@ hipError_t launch_head(const HeadArgs& a, dim3 grid, hipStream_t st) {
   // (behind the automatic mode's check no chunk needs a standard step — its margin covers the difference between its
   // sum and the march's — so the complete kernel has nothing to do and is not launched)
   if (!a.gate) ssd_head_kernel<PT, NW, NB, true><<<grid, NW * 64, sizeof(Smem), st>>>(a);
+#endif
   return hipSuccess;
 }
 
@@ -920,6 +1031,8 @@ extern "C" int tv_ssd_head_debug_stamps(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_head_phases), sizeof(g_head_phases));
 }
 #endif
+
+bool tv_ssd_head_takes_every_chunk() { return TV_HEAD_UNISTD != 0; }
 
 bool tv_ssd_head_supported(int seqlen, int nheads, int headdim, int ngroups, int dstate, int dtype,
                            int64_t xsl, int64_t bsl, int64_t bsg, int64_t csl, int64_t csg, int64_t ysl,

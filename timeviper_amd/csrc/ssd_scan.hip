@@ -57,6 +57,8 @@ int tv_ssd_head_launch(const void* x, const void* dt, const void* A, const void*
                        int64_t ysl, int dt_softplus, float dt_min, float dt_max, int group_map,
                        void* workspace, size_t workspace_bytes, const void* cb_pre, hipStream_t st, int* gate);
 
+bool tv_ssd_head_takes_every_chunk();
+
 // 0 auto, 1 generic recurrence, 2 chunk march (ssd_march.hip), 3 slice march, two work-groups per
 // head (ssd_slice.hip), 4 slice march, whole-head work-groups x concurrent sequence segments +
 // carried-in state correction (ssd_slice.hip + ssd_correct.hip), 8 waves with two column tiles per
@@ -123,7 +125,7 @@ static int scan_impl(const void* x, const void* dt, const void* A, const void* B
     // the slice march (impl 4) — launched behind it, gated the other way — takes the call then.  Nothing is read back:
     // both kernel sequences are always launched, one of them returns at once.  Forced (tv_ssd_scan_set_impl(6)): the
     // head march alone, with its complete kernel as the fallback.
-    const bool both = !forced && tv_ssd_slice_supported(seqlen, nheads, headdim, ngroups, dstate, dtype, x_stride_l, b_stride_l,
+    const bool both = !forced && !tv_ssd_head_takes_every_chunk() && tv_ssd_slice_supported(seqlen, nheads, headdim, ngroups, dstate, dtype, x_stride_l, b_stride_l,
                                                         b_stride_g, c_stride_l, c_stride_g, y_stride_l, x, Bm, Cm, y, 1) &&
                       workspace_bytes >= 512;
     int* gate = both ? (int*)((unsigned char*)workspace + (workspace_bytes / 256 - 1) * 256) : nullptr;
