@@ -71,6 +71,19 @@ int tv_ssd_correct_all_launch(void* y, const void* dt, const void* A, const void
 #ifndef TV_HEAD_UNTRACKED
 #define TV_HEAD_UNTRACKED 1
 #endif
+// TV_HEAD_XW_IN_Q0: 1 = x~ is formed tile by tile beside the Yoff MFMAs of quarter 0, 0 = all of it before the quarters
+#ifndef TV_HEAD_XW_IN_Q0
+#define TV_HEAD_XW_IN_Q0 1
+#endif
+// TV_HEAD_CBJ: the MFMA group of quarter 2 behind which the C.B^T loads are issued (5: behind the last x copies)
+#ifndef TV_HEAD_CBJ
+#define TV_HEAD_CBJ 5
+#endif
+// TV_HEAD_FENCE: 1 = a scheduling fence behind every group of PT MFMAs (pins the memory operations between them),
+// 0 = one fence per quarter
+#ifndef TV_HEAD_FENCE
+#define TV_HEAD_FENCE 1
+#endif
 #ifndef TV_HEAD_UNISTD
 #define TV_HEAD_UNISTD 1
 #endif
@@ -512,29 +525,31 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
     const unsigned xt = lds_xr + (c & 1) * XSLOT;
     // ---- x~ = w_s x on the fragments (element j of fragment ks is token 32 ks + 8 kq + j)
     bf16x8 xw[PT][2];
-    {
-      f32x4 wq[2][2];
+    f32x4 wq[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      wq[ks][0] = *(const f32x4*)(&vec.wts[32 * ks + 8 * kq]);
+      wq[ks][1] = *(const f32x4*)(&vec.wts[32 * ks + 8 * kq + 4]);
+    }
+    auto make_xw = [&](int ct) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        wq[ks][0] = *(const f32x4*)(&vec.wts[32 * ks + 8 * kq]);
-        wq[ks][1] = *(const f32x4*)(&vec.wts[32 * ks + 8 * kq + 4]);
-      }
+        const u32x4v u = __builtin_bit_cast(u32x4v, read_xf(xt, ct, ks));
+        u32x4v o;
 #pragma unroll
-      for (int ct = 0; ct < PT; ++ct)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const u32x4v u = __builtin_bit_cast(u32x4v, read_xf(xt, ct, ks));
-          u32x4v o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-            const f32x2 pr = f32x2{bf16_lo(u[e]), bf16_hi(u[e])} * f32x2{wq[ks][e >> 1][(2 * e) & 3], wq[ks][e >> 1][(2 * e + 1) & 3]};
-            const bf16x2 pk = {(bf16_t)pr[0], (bf16_t)pr[1]};
-            o[e] = __builtin_bit_cast(unsigned, pk);
-          }
-          xw[ct][ks] = __builtin_bit_cast(bf16x8, o);
+        for (int e = 0; e < 4; ++e) {
+          typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+          const f32x2 pr = f32x2{bf16_lo(u[e]), bf16_hi(u[e])} * f32x2{wq[ks][e >> 1][(2 * e) & 3], wq[ks][e >> 1][(2 * e + 1) & 3]};
+          const bf16x2 pk = {(bf16_t)pr[0], (bf16_t)pr[1]};
+          o[e] = __builtin_bit_cast(unsigned, pk);
         }
-    }
+        xw[ct][ks] = __builtin_bit_cast(bf16x8, o);
+      }
+    };
+#if !TV_HEAD_XW_IN_Q0
+#pragma unroll
+    for (int ct = 0; ct < PT; ++ct) make_xw(ct);
+#endif
     HSTAMP(1);
     // ---- Yoff^T = X'^T C^T and X' (= f X') += B^T x~, in quarters of 32 state rows; each quarter in 8 groups of PT MFMAs
     // with the bf16 copy of the next quarter's state rows and a few memory operations behind each group
@@ -574,9 +589,20 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
           }
         }
         if (q < 3 && j < PT) sbn[j] = snap_tile(q + 1, j);
+#if TV_HEAD_XW_IN_Q0
+        // x~ of column tile j beside the Yoff MFMAs of the first quarter (they do not need it; the state update, groups 4 - 7, does)
+        if (q == 0 && j < 4) {
+          if (j < PT) make_xw(j);
+          if (j == 3) {
+#pragma unroll
+            for (int ct = 4; ct < PT; ++ct) make_xw(ct);
+          }
+        }
+#endif
         filler(j);
-        if (fence) __builtin_amdgcn_sched_barrier(0);
+        if (fence && TV_HEAD_FENCE) __builtin_amdgcn_sched_barrier(0);
       }
+      if (fence && !TV_HEAD_FENCE) __builtin_amdgcn_sched_barrier(0);
     };
     read_cq(Ct, 0, cq[0]);
     read_b2(Bt, 0, bq[0]);
@@ -604,7 +630,7 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
     read_b2(Bt, 6, bq[1]);
     quarter(2, cq[0], bq[0], sbq[0], sbq[1], [&](int j) {           // the rest of x, dt of the chunk after the next
       if (more && j == 0 && NXG > 1 && !HDBG(a, 32)) issue_x(c + 1, 1);
-      if (j == 5 && !STD && !HDBG(a, 8)) {       // C.B^T of this chunk (behind the last x copies: only dt is issued after it)
+      if (j == TV_HEAD_CBJ && !STD && !HDBG(a, 8)) {       // C.B^T of this chunk (behind the last x copies: only dt is issued after it)
 #pragma unroll
         for (int f = 0; f < NFR; ++f) {
           u32x4v r;
@@ -656,7 +682,7 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
         }
     }
     // C.B^T has landed; what was issued behind it (the last x copies, dt) may stay in flight
-    if (UNTRACKED && more && (c + 2) * HQ <= L) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    if (UNTRACKED && more && (c + 2) * HQ <= L) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TV_HEAD_CBJ >= 4 ? 1 : (NXG > 2 ? NXI - 8 : 0) + 1) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (!STD) {
 #pragma unroll

@@ -10,6 +10,6 @@ for set in "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "FETCH_SIZE" \
   i=$((i+1))
   if [ $i -lt ${2:-1} ] || [ $i -gt ${3:-9} ]; then continue; fi
   rm -rf gpurun_out/pmc_slice$i
-  timeout 150 rocprofv3 --pmc $set -d gpurun_out/pmc_slice$i -o p --output-format csv -- python3 timeviper_amd/devtools/bench_ops.py --ops scan --model-dt --impl $IMPL > gpurun_out/pmc_slice$i.log 2>&1
+  timeout 150 rocprofv3 --pmc $set -d gpurun_out/pmc_slice$i -o p --output-format csv -- python3 timeviper_amd/devtools/bench_ops.py --ops scan --model-dt --dt-std 1.3 --impl $IMPL > gpurun_out/pmc_slice$i.log 2>&1
   echo "pass $i rc=$?"; tail -1 gpurun_out/pmc_slice$i.log
 done

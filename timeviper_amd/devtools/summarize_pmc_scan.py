@@ -45,7 +45,7 @@ for k, m in mean.items():
     if "WRITE_SIZE" in m:
         hbm[f"{k}_write"] = m["WRITE_SIZE"] * 1024
 hbm["total"] = sum(hbm.values())
-out = [f"# rocprofv3 --pmc passes on `python3 timeviper_amd/devtools/bench_ops.py --ops scan --model-dt --impl {impl}` "
+out = [f"# rocprofv3 --pmc passes on `python3 timeviper_amd/devtools/bench_ops.py --ops scan --model-dt --dt-std 1.3 --impl {impl}` "
        f"({tokens} tokens, Nano-9B dims), {tag}\n",
        "One counter set per pass, no tracing (`timeviper_amd/devtools/pmc_scan.sh`); mean per launch, summed over the rows "
        "rocprofv3 reports per dispatch (`timeviper_amd/devtools/summarize_pmc_scan.py`).\n"]
@@ -70,6 +70,6 @@ out.append(f"\n## HBM traffic per tv_ssd_scan_fwd call\n\nalgorithmic bytes {alg
     "kernel": " + ".join(names[k] for k in KERNELS if k in names), "scan_impl": impl, "scan_source_id": scan_source_id(),
     "tokens": tokens, "algorithmic_bytes": alg, "hbm_bytes": hbm, "hbm_over_algorithmic": hbm["total"] / alg,
     "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, timeviper_amd/devtools/pmc_scan.sh) on "
-           f"bench_ops.py --ops scan --model-dt --impl {impl}; KiB units; FETCH_SIZE x2 (gfx950 correction for 16 B/lane streaming "
+           f"bench_ops.py --ops scan --model-dt --dt-std 1.3 --impl {impl}; KiB units; FETCH_SIZE x2 (gfx950 correction for 16 B/lane streaming "
            "reads, MI355X_MICROARCH.md); every kernel of the call summed (one launch each per call)"}, indent=1) + "\n")
 print("\n".join(out))
