@@ -42,6 +42,7 @@ using ssdk::settle;
 template <typename T> struct Frag;
 template <> struct Frag<bf16_t> {
   typedef bf16x8 v8; typedef bf16x4 v4;
+  static constexpr bool is_bf16 = true;
   static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
   }
@@ -54,6 +55,7 @@ template <> struct Frag<bf16_t> {
 };
 template <> struct Frag<f16_t> {
   typedef f16x8 v8; typedef f16x4 v4;
+  static constexpr bool is_bf16 = false;
   static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
   }
@@ -749,6 +751,406 @@ __global__ __launch_bounds__(512) void flash_fwd_stream_kernel(AttnArgs a) {
 #endif
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// ViT-sized heads (head_dim <= 80), non-causal, many short sequences: 64 QUERY ROWS PER WAVE at ONE wave per SIMD.
+// The streaming kernel above runs two waves of 32 rows per SIMD; its three phases (QK^T, softmax, PV) then share the
+// matrix pipe, the VALU and the LDS one after the other (6 000 cycles a tile for 2 100 of MFMA).  Here a
+// work-group is 4 waves, a wave owns two 32-row query halves A and B and the whole 512-register file, and the halves
+// run half a tile apart so that every segment of the instruction stream pairs the MFMAs of one half with the softmax of
+// the other, placed gap by gap (sched_barrier fences):
+//     segment 1 of tile n:  MFMA  S_B(n) = K(n) Q_B^T,  O_B += V(n-1) P_B(n-1)   |  VALU  P_A(n) = exp2(S_A(n) c - m_A)
+//     segment 2 of tile n:  MFMA  S_A(n+1) = K(n+1) Q_A^T,  O_A += V(n) P_A(n)   |  VALU  P_B(n) = exp2(S_B(n) c - m_B)
+// * the row sums ride on the matrix pipe: one extra MFMA per 16 keys with an all-ones A operand adds sum_k P[k][q] (of
+//   the bf16-rounded P, the values the PV product uses) into an accumulator tile — no VALU adds, and the sums are
+//   rescaled with O;
+// * lazy rescale: the reference maximum m of a query row only moves when a tile's maximum exceeds it by more than
+//   2^TV_FA_W64_LAZY (P stays <= 2^8, fp32 sums and bf16 P hold that without loss); the decision is taken between
+//   two segments (wave-uniform branch), O is touched only then;
+// * K / V tiles of 64 keys by LDS-DMA into rings of 4 (K three tiles ahead, V two), one barrier per tile, the
+//   stream of tiles and the Q fragments run on across query blocks (the epilogue of half A sits one segment before
+//   that of half B).
+// Same LDS image, swizzles and fragment reads as the kernels above.  bf16 only.
+#ifndef TV_FA_W64_LAZY
+#define TV_FA_W64_LAZY 8.0f
+#endif
+#ifndef TV_FA_W64_KGAP
+#define TV_FA_W64_KGAP 3       // the gap of segment 1 that carries the four K copies
+#endif
+#ifndef TV_FA_W64_VGAP
+#define TV_FA_W64_VGAP 3       // the gap of segment 2 that carries the four V copies
+#endif
+__device__ __forceinline__ float w64_max3(float a, float b, float c) {
+  float d;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ float w64_fma(float a, float b, float c) {
+  float d;
+  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ unsigned w64_pk(float lo, float hi) {
+  unsigned d;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(d) : "v"(lo), "v"(hi));
+  return d;
+}
+
+template <int KS, int DT>
+__global__ __launch_bounds__(256) void flash_fwd_w64_kernel(AttnArgs a) {
+  typedef bf16_t T;
+  typedef bf16x8 v8;
+  typedef bf16x4 v4;
+  typedef Frag<bf16_t> F;
+  typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+  typedef unsigned u32x2s __attribute__((ext_vector_type(2)));
+  constexpr int NW = 4, KB = 64, ROWB = 256, TILEB = KB * ROWB, NS = 4, QB = 256, QW = 64;
+  constexpr int NM = 2 * KS + 4 * (DT + 1);          // MFMAs per segment
+  extern __shared__ __attribute__((aligned(16))) unsigned char fa_smem[];
+  const unsigned sK_off = (unsigned)(uintptr_t)(lds_u8*)fa_smem, sV_off = sK_off + NS * TILEB;
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int r = lane & 31, hh = lane >> 5;
+  const int D = a.D;
+  const int xcd = blockIdx.x & 7, step = gridDim.x >> 3;
+  const int nslots = a.ppx * a.nqb, npairs = a.nb * a.Hq;
+  int slot = blockIdx.x >> 3;
+  int pair = xcd * a.ppx + slot / a.nqb, qblk = slot % a.nqb;
+  if (slot >= nslots || pair >= npairs) return;
+  const int gq = a.Hq / a.Hkv;
+  const float c_ = a.scale_log2;
+  auto k_of = [&](int pr) { return (const T*)a.k + (int64_t)(pr / a.Hq) * a.ksb + (int64_t)((pr % a.Hq) / gq) * a.ksh; };
+  auto v_of = [&](int pr) { return (const T*)a.v + (int64_t)(pr / a.Hq) * a.vsb + (int64_t)((pr % a.Hq) / gq) * a.vsh; };
+
+  // ---- Q^T fragments of half X (B operand): lane (r, hh) holds Q[row][16 ks + 8 hh + j].  Ordinary loads (two per
+  // query block and half, at the seams): hipcc's own wait in front of `finish_q` over-waits on the copies in flight,
+  // never under-waits (vmcnt is in issue order), and the registers may be moved freely in between.
+  auto load_q = [&](int pr, int qb, int X, u32x4 (&raw)[KS]) __attribute__((always_inline)) {
+    const T* qp = (const T*)a.q + (int64_t)(pr / a.Hq) * a.qsb + (int64_t)(pr % a.Hq) * a.qsh;
+    const int qrow = qb * QB + wave * QW + 32 * X + r;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int d0 = ks * 16 + hh * 8;
+      raw[ks] = *(const u32x4*)((qrow < a.Lq && d0 < D) ? qp + (int64_t)qrow * a.qsl + d0 : qp);
+    }
+  };
+  auto finish_q = [&](int qb, int X, u32x4 (&raw)[KS]) __attribute__((always_inline)) {
+    const int qrow = qb * QB + wave * QW + 32 * X + r;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      raw[ks] = (qrow < a.Lq && ks * 16 + hh * 8 < D) ? raw[ks] : z;
+    }
+  };
+
+  // ---- copies: this wave's four pieces of a tile = key rows 16 wave .. + 15 (4 rows a piece, lane l: row + l / 16,
+  // LDS chunk l % 16, source chunk = chunk ^ swizzle; chunks past head_dim re-fetch chunk 0: finite pad).  Offsets are
+  // relative to the tile's first key and pre-corrected for the instruction offsets of the grouped copy; a second set
+  // serves the sequence's last tile, whose rows past the end repeat the last key (masked in the softmax).
+  const int ntiles = (a.Lk + KB - 1) / KB;             // >= 4 (launcher)
+  const int left_last = a.Lk - (ntiles - 1) * KB;
+  const int dchunks = D / 8;
+  unsigned offK[4], offV[4], offKl[4], offVl[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 16 * wave + 4 * i + (lane >> 4);
+    int ck = (lane & 15) ^ (row & 15), cv = (lane & 15) ^ (4 * (row & 3));
+    ck = ck < dchunks ? ck : 0;
+    cv = cv < dchunks ? cv : 0;
+    const int rl = min(row, left_last - 1);
+    offK[i] = (unsigned)(row * (int)a.ksl * 2 + ck * 16 - 1024 * i);
+    offV[i] = (unsigned)(row * (int)a.vsl * 2 + cv * 16 - 1024 * i);
+    offKl[i] = (unsigned)(rl * (int)a.ksl * 2 + ck * 16 - 1024 * i);
+    offVl[i] = (unsigned)(rl * (int)a.vsl * 2 + cv * 16 - 1024 * i);
+  }
+  const unsigned m0_wave = (unsigned)(wave * 4096);
+  // the grouped copy adds 1024 j to the source address of piece j: a clamped row may sit below that -> the last tile
+  // uses single copies (`copy_last`) instead
+  auto copy4 = [&](const T* base, int kt, int64_t sl, const unsigned (&off)[4], unsigned lds_dst) __attribute__((always_inline)) {
+    const void* sp = ssdk::uniform_ptr(base + (int64_t)kt * KB * sl);
+    ssdk::glds16x4(sp, off[0], off[1], off[2], off[3], lds_dst + m0_wave);
+  };
+  auto copy_last = [&](const T* base, int kt, int64_t sl, const unsigned (&off)[4], unsigned lds_dst) __attribute__((always_inline)) {
+    const void* sp = ssdk::uniform_ptr(base + (int64_t)kt * KB * sl);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ssdk::glds16(sp, off[i] + 1024u * i, lds_dst + m0_wave + 1024u * i);
+  };
+
+  int k_rd[KS];
+  const int kz = (hh ^ (r & 15)) << 4;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) k_rd[ks] = r * ROWB + ((32 * ks) ^ kz);
+  const int q4 = (lane & 15) >> 2, p4 = lane & 3;
+  int v_rd[DT];
+  {
+    const int cc = 2 * ((lane >> 4) & 1) + (p4 >> 1);
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+      v_rd[dt] = (4 * hh + q4) * ROWB + ((4 * (dt ^ q4) + cc) << 4) + (p4 & 1) * 8;
+  }
+
+  // ---- state of the two halves
+  f32x16 O[2][DT], Ls[2], S[2][2];
+  u32x4 Qf[2][KS];            // Q fragments (bit patterns of 8 bf16)
+  u32x4 Pf[2][4];             // P^T fragments of the tile in flight: k-step s = keys 16 s .. + 15 (in the accumulator's key order)
+  float mref[2] = {-INFINITY, -INFINITY}, tmax[2] = {-INFINITY, -INFINITY};
+  bool first[2] = {true, true};
+  v8 kf[3];
+  const u32x4 ones_u = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+  const v8 ones = __builtin_bit_cast(v8, ones_u);
+#pragma unroll
+  for (int X = 0; X < 2; ++X) {
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) O[X][dt][i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Ls[X][i] = 0.f;
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) Pf[X][s_] = u32x4{0u, 0u, 0u, 0u};
+  }
+
+  // ---- prologue: zero the rings (the first PV of half B multiplies P = 0 with whatever the slot holds), first tiles, Q
+  {
+    u32x4s* z = (u32x4s*)fa_smem;
+    for (int i = tid; i < 2 * NS * TILEB / 16; i += 256) z[i] = u32x4s{0u, 0u, 0u, 0u};
+  }
+  __syncthreads();
+  const T* kp = k_of(pair);
+  const T* vp = v_of(pair);
+  auto tile_copy_k = [&](const T* base, int kt, int stage) __attribute__((always_inline)) {
+    if (kt == ntiles - 1 && left_last < KB) copy_last(base, kt, a.ksl, offKl, sK_off + stage * TILEB);
+    else copy4(base, kt, a.ksl, offK, sK_off + stage * TILEB);
+  };
+  auto tile_copy_v = [&](const T* base, int kt, int stage) __attribute__((always_inline)) {
+    if (kt == ntiles - 1 && left_last < KB) copy_last(base, kt, a.vsl, offVl, sV_off + stage * TILEB);
+    else copy4(base, kt, a.vsl, offV, sV_off + stage * TILEB);
+  };
+  tile_copy_k(kp, 0, 0);
+  tile_copy_k(kp, 1, 1);
+  tile_copy_k(kp, 2, 2);
+  tile_copy_v(vp, 0, 0);
+  tile_copy_v(vp, 1, 1);
+  load_q(pair, qblk, 0, Qf[0]);
+  load_q(pair, qblk, 1, Qf[1]);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  finish_q(qblk, 0, Qf[0]);
+  finish_q(qblk, 1, Qf[1]);
+  __builtin_amdgcn_s_barrier();
+
+  auto kfrag = [&](unsigned cK, int m) __attribute__((always_inline)) {     // K fragment of QK^T MFMA m: sub-tile m & 1, k-step m >> 1
+    return F::row_read(lds_at(cK + (unsigned)k_rd[m >> 1]) + (m & 1) * (32 * ROWB));
+  };
+  // tile maximum of half X (raw scores), both key halves of the lane pair
+  auto tile_max = [&](int X) __attribute__((always_inline)) {
+    float m = fmaxf(S[X][0][0], S[X][0][1]);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int i = (t == 0 ? 2 : 0); i < 16; i += 2) m = w64_max3(m, S[X][t][i], S[X][t][i + 1]);
+    return fmaxf(m, __shfl_xor(m, 32, 64));
+  };
+  auto mask_tail = [&](int X, int kvalid) __attribute__((always_inline)) {   // keys >= kvalid of the tile -> -inf
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int key = t * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+        S[X][t][i] = key < kvalid ? S[X][t][i] : -INFINITY;
+      }
+  };
+  // between two segments: does half X's reference maximum have to move before its softmax?
+  auto decide = [&](int X) __attribute__((always_inline)) {
+    const float tm = tmax[X] * c_;
+    if (__builtin_amdgcn_ballot_w64(tm > mref[X] + TV_FA_W64_LAZY)) {
+      if (first[X]) {
+        mref[X] = tm;
+        first[X] = false;
+      } else {
+        const float mn = fmaxf(mref[X], tm);
+        const float al = __builtin_amdgcn_exp2f(mref[X] - mn);
+        mref[X] = mn;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) O[X][dt][i] *= al;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) Ls[X][i] *= al;
+      }
+    }
+  };
+
+  // One segment: MFMAs of half X (scores of the tile in K slot cK, PV of its previous P with the tile in V slot cV),
+  // elementwise softmax of half Y = 1 - X, tile maximum of X's new scores; COPY: 1 the K group, 2 the V group, 0 none.
+  // cKn: K slot whose first two fragments the NEXT segment starts with.
+  auto segment = [&](const int X, const bool MASK, const int kvalid, unsigned cK, unsigned cV, unsigned cKn,
+                     const int COPY, const T* cbase, int ckt, int cstage) __attribute__((always_inline)) {
+    const int Y = 1 - X;
+    const float nm = -mref[Y];
+    unsigned vb[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) vb[dt] = cV + (unsigned)v_rd[dt];
+    v4 vlo[2][DT], vhi[2][DT];
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+      // ---- the MFMA of this gap
+      if (m < 2 * KS) {
+        const int t = m & 1, ks = m >> 1;
+        const v8 qv = __builtin_bit_cast(v8, Qf[X][ks]);
+        if (ks == 0) {
+          const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          S[X][t] = F::mfma(kf[m % 3], qv, z);
+        } else {
+          S[X][t] = F::mfma(kf[m % 3], qv, S[X][t]);
+        }
+      } else {
+        const int j = m - 2 * KS, s_ = j / (DT + 1), w = j % (DT + 1);
+        const v8 pv = __builtin_bit_cast(v8, Pf[X][s_]);
+        if (w < DT) {
+          v8 vf;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { vf[e] = vlo[s_ & 1][w][e]; vf[4 + e] = vhi[s_ & 1][w][e]; }
+          O[X][w] = F::mfma(vf, pv, O[X][w]);
+        } else {
+          Ls[X] = F::mfma(ones, pv, Ls[X]);
+        }
+      }
+      // ---- fillers
+      if (m + 2 < 2 * KS) kf[(m + 2) % 3] = kfrag(cK, m + 2);
+      if (m >= NM - 2) kf[m - (NM - 2)] = kfrag(cKn, m - (NM - 2));        // the next segment's first two
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+          if (m == 2 * KS - 4 + (DT + 1) * s_ + dt) {
+            vlo[s_ & 1][dt] = F::tr_read(lds_at(vb[dt]) + s_ * (16 * ROWB));
+            vhi[s_ & 1][dt] = F::tr_read(lds_at(vb[dt]) + s_ * (16 * ROWB) + 8 * ROWB);
+          }
+      // softmax of Y: 16 pairs over the gaps 0 .. 2 KS - 1 (one each) and the even gaps behind
+      {
+        int pi = -1;
+        if (m < 2 * KS) pi = m;
+        else if ((m - 2 * KS) % 2 == 0 && 2 * KS + (m - 2 * KS) / 2 < 16) pi = 2 * KS + (m - 2 * KS) / 2;
+        if (pi >= 0 && pi < 16) {
+          const int t = pi >> 3, rr = 2 * (pi & 7);
+          const float e0 = w64_fma(S[Y][t][rr], c_, nm), e1 = w64_fma(S[Y][t][rr + 1], c_, nm);
+          const float p0 = __builtin_amdgcn_exp2f(e0), p1 = __builtin_amdgcn_exp2f(e1);
+          Pf[Y][pi >> 2][pi & 3] = w64_pk(p0, p1);
+        }
+      }
+      if (COPY && m == (COPY == 1 ? TV_FA_W64_KGAP : TV_FA_W64_VGAP)) {
+        if (COPY == 1) tile_copy_k(cbase, ckt, cstage);
+        else tile_copy_v(cbase, ckt, cstage);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (MASK) mask_tail(X, kvalid);
+    tmax[X] = tile_max(X);
+  };
+
+  // epilogue of half X of query block (pr, qb): O / l -> global, reset the half
+  auto epilogue = [&](int X, int pr, int qb) __attribute__((always_inline)) {
+    const int h = pr % a.Hq, b = pr / a.Hq;
+    const int qrow = qb * QB + wave * QW + 32 * X + r;
+    const float l_tot = Ls[X][0];
+    const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+    T* op = (T*)a.o + (int64_t)b * a.osb + (int64_t)min(qrow, a.Lq - 1) * a.osl + (int64_t)h * a.osh;
+    const bool rowok = qrow < a.Lq;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp) {
+        const int d_lo = dt * 32 + 16 * gp;
+        if (d_lo >= D) continue;
+        const u32x2s ua = {w64_pk(O[X][dt][8 * gp + 0] * inv, O[X][dt][8 * gp + 1] * inv), w64_pk(O[X][dt][8 * gp + 2] * inv, O[X][dt][8 * gp + 3] * inv)};
+        const u32x2s ub = {w64_pk(O[X][dt][8 * gp + 4] * inv, O[X][dt][8 * gp + 5] * inv), w64_pk(O[X][dt][8 * gp + 6] * inv, O[X][dt][8 * gp + 7] * inv)};
+        if (a.o16 && d_lo + 8 < D) {
+          const auto s0 = __builtin_amdgcn_permlane32_swap(ua[0], ub[0], false, false);
+          const auto s1 = __builtin_amdgcn_permlane32_swap(ua[1], ub[1], false, false);
+          const u32x4s w = {s0[0], s1[0], s0[1], s1[1]};
+          if (rowok) *(u32x4s*)(op + d_lo + 8 * hh) = w;
+        } else {
+          if (rowok) *(u32x2s*)(op + d_lo + 4 * hh) = ua;
+          if (rowok && d_lo + 8 + 4 * hh < D) *(u32x2s*)(op + d_lo + 8 + 4 * hh) = ub;
+        }
+      }
+    if (rowok && a.lse && hh == 0)
+      a.lse[((int64_t)b * a.Hq + h) * a.Lq + qrow] = l_tot > 0.f ? (mref[X] * 0.6931471805599453f + logf(l_tot)) : -INFINITY;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) O[X][dt][i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Ls[X][i] = 0.f;
+    mref[X] = -INFINITY;
+    first[X] = true;
+  };
+
+  // ---- segment 0 of the stream: S_A of tile 0
+  {
+    const unsigned cK = sK_off;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) S[0][t][i] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) S[0][t] = F::mfma(kfrag(cK, 2 * ks + t), __builtin_bit_cast(v8, Qf[0][ks]), S[0][t]);
+    }
+    tmax[0] = tile_max(0);
+    kf[0] = kfrag(cK, 0);
+    kf[1] = kfrag(cK, 1);
+  }
+
+  const bool tail = left_last < KB;        // the last tile of a sequence has masked keys
+  int n = 0;                               // tile counter of the stream (ring slots)
+  int pair_p = pair, qblk_p = qblk;        // half B's block (one segment behind at the seams)
+  bool have_prev = false;
+  for (;;) {
+    const int slot_n = slot + step;
+    const int pair_n = xcd * a.ppx + slot_n / a.nqb, qblk_n = slot_n % a.nqb;
+    const bool has_next = slot_n < nslots && pair_n < npairs;
+    const T* kp_n = has_next ? k_of(pair_n) : kp;
+    const T* vp_n = has_next ? v_of(pair_n) : vp;
+    for (int kt = 0; kt < ntiles; ++kt, ++n) {
+      const bool last = kt == ntiles - 1;
+      const unsigned cK0 = sK_off + (unsigned)((n & 3) * TILEB), cK1 = sK_off + (unsigned)(((n + 1) & 3) * TILEB);
+      const unsigned cV0 = sV_off + (unsigned)((n & 3) * TILEB), cVm = sV_off + (unsigned)(((n + 3) & 3) * TILEB);
+      // copies of this iteration: K three tiles ahead, V two
+      const bool kw = kt + 3 >= ntiles, vw = kt + 2 >= ntiles;
+      const T* ck = kw ? kp_n : kp;
+      const T* cv = vw ? vp_n : vp;
+      const int ckt = kw ? kt + 3 - ntiles : kt + 3, vkt = vw ? kt + 2 - ntiles : kt + 2;
+      // ---- segment 1
+      decide(0);
+      if (last && has_next) load_q(pair_n, qblk_n, 0, Qf[0]);      // Q_A's last use was the previous segment
+      if (last && tail) segment(1, true, left_last, cK0, cVm, cK1, 1, ck, ckt, (n + 3) & 3);
+      else segment(1, false, 0, cK0, cVm, cK1, 1, ck, ckt, (n + 3) & 3);
+      if (kt == 0 && have_prev) epilogue(1, pair_p, qblk_p);
+      if (last && has_next) finish_q(qblk_n, 0, Qf[0]);
+      // ---- segment 2
+      decide(1);
+      if (last && has_next) load_q(pair_n, qblk_n, 1, Qf[1]);      // Q_B's last use was segment 1
+      if (kt == ntiles - 2 && tail) segment(0, true, left_last, cK1, cV0, cK1, 2, cv, vkt, (n + 2) & 3);
+      else segment(0, false, 0, cK1, cV0, cK1, 2, cv, vkt, (n + 2) & 3);
+      if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (last) {
+        epilogue(0, pair, qblk);
+        if (has_next) finish_q(qblk_n, 1, Qf[1]);
+      }
+    }
+    pair_p = pair; qblk_p = qblk; have_prev = true;
+    if (!has_next) break;
+    slot = slot_n; pair = pair_n; qblk = qblk_n; kp = kp_n; vp = vp_n;
+  }
+  // ---- drain: the last PV of half B
+  segment(1, false, 0, sK_off + (unsigned)((n & 3) * TILEB), sV_off + (unsigned)(((n + 3) & 3) * TILEB),
+          sK_off + (unsigned)((n & 3) * TILEB), 0, kp, 0, 0);
+  epilogue(1, pair_p, qblk_p);
+}
+
 int tv_cu_count() {
   static const int n = [] {
     int dev = 0, cus = 0;
@@ -780,7 +1182,18 @@ int launch_fa_d(const AttnArgs& a, int B, hipStream_t st) {
         ax.o16 = ((uintptr_t)a.o % 16 == 0 && a.osb % 8 == 0 && a.osl % 8 == 0 && a.osh % 8 == 0) ? 1 : 0;
         static const int stream_ = [] { const char* v = getenv("TV_FA_STREAM"); return v ? atoi(v) : 1; }();
         const int64_t slots = (int64_t)ax.ppx * nqb;          // query blocks per XCD
-        if constexpr (KS > 6) {                                // head_dim 128: the second Q set does not fit the registers
+        static const int w64_ = [] { const char* v = getenv("TV_FA_W64"); return v ? atoi(v) : 1; }();
+        bool w64_ok = false;
+        if constexpr (KS == 5 && DT == 3 && sizeof(T) == 2 && Frag<T>::is_bf16)
+          w64_ok = w64_ && a.Lk >= 256 && a.ksl >= 128 && a.vsl >= 128 && slots > tv_cu_count() / 8;
+        if (w64_ok) {
+          if constexpr (KS == 5 && DT == 3 && Frag<T>::is_bf16) {
+            constexpr int lds4 = 2 * 4 * 64 * 256;             // K and V rings: 4 stages x 64 rows x 256 B
+            e = hipFuncSetAttribute((const void*)flash_fwd_w64_kernel<KS, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
+            if (e == hipSuccess)
+              flash_fwd_w64_kernel<KS, DT><<<dim3((unsigned)(8 * (tv_cu_count() / 8)), 1, 1), 256, lds4, st>>>(ax);
+          }
+        } else if constexpr (KS > 6) {                         // head_dim 128: the second Q set does not fit the registers
           flash_fwd_kernel<T, KS, DT, 8, KT><<<dim3((unsigned)(pairs * nqb), 1, 1), 512, lds, st>>>(ax);
         } else if (stream_ && a.Lk > 32 * KT && slots > tv_cu_count() / 8) {
           // one resident work-group per CU streams its share of the query blocks

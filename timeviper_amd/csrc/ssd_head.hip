@@ -75,9 +75,9 @@ int tv_ssd_correct_all_launch(void* y, const void* dt, const void* A, const void
 #ifndef TV_HEAD_XW_IN_Q0
 #define TV_HEAD_XW_IN_Q0 1
 #endif
-// TV_HEAD_CBJ: the MFMA group of quarter 2 behind which the C.B^T loads are issued (5: behind the last x copies)
+// TV_HEAD_CBJ: the MFMA group of quarter 2 behind which the C.B^T loads are issued (3: measured best by ~1 %; 5 = behind the last x copies)
 #ifndef TV_HEAD_CBJ
-#define TV_HEAD_CBJ 5
+#define TV_HEAD_CBJ 3
 #endif
 // TV_HEAD_FENCE: 1 = a scheduling fence behind every group of PT MFMAs (pins the memory operations between them),
 // 0 = one fence per quarter
