@@ -261,6 +261,13 @@ int tv_flash_attn_fwd(const void* q, const void* k, const void* v, void* o,
                       int64_t o_stride_l, int64_t o_stride_h,
                       float softmax_scale, int causal, int dtype, void* stream);
 
+/* Kernel variant for many short non-causal sequences of head_dim 65..80 (the SigLIP ViT frames; testing /
+ * benchmarking, process-global): 0 = auto (the streaming kernel: 8 waves x 32 query rows, two waves per SIMD),
+ * 1 = 4 waves x 64 query rows at one wave per SIMD with the two 32-row halves half a tile apart
+ * (flash_fwd_w64_kernel; bf16, >= 256 keys, row strides >= 128 elements; slower at head_dim 72 — DESIGN.md §5 —
+ * and therefore not the default).  Results agree within the operator's tolerance.  Initial value: env TV_FA_W64. */
+void tv_flash_attn_set_variant(int variant);
+
 /* The same operator with the QK^T and PV products on the FP8 matrix path of CDNA4
  * (v_mfma_f32_32x32x64_f8f6f4, OCP e4m3 operands, fp32 accumulation, fp32 softmax): BASELINE
  * config 5 ("fp8 MFMA attention path"; call sites modeling_qwen2.py:196-244,

@@ -364,6 +364,36 @@ def test_flash_attention_streaming(K, dtype, B, Lq, Lk, Hq, Hkv, D):
     assert torch.equal(o, o2)
 
 
+@pytest.mark.parametrize("B,Lq,Lk,Hq,Hkv,D", [
+    (24, 729, 729, 16, 16, 72),      # SigLIP frames: 3 query blocks, 12 key tiles, the last one holds 25 keys
+    (13, 300, 300, 13, 13, 72),      # 5 key tiles with a ragged tail, 2 query blocks, the last XCD's range ends early
+    (12, 768, 512, 16, 8, 80),       # GQA, head_dim 80 (no pad columns), Lk a multiple of the tile, Lq != Lk
+    (40, 260, 1000, 8, 8, 72),       # 2 query blocks of which the second holds 4 rows, 16 key tiles
+])
+def test_flash_attention_w64_variant(K, B, Lq, Lk, Hq, Hkv, D):
+    """`tv_flash_attn_set_variant(1)`: flash_fwd_w64_kernel (4 waves x 64 query rows, the halves of a wave half a tile
+    apart, lazy rescale, row sums on the matrix pipe) against the fp32 oracle and against the default kernel;
+    dominant keys in late tiles force the reference maximum to move by more than the lazy threshold."""
+    g = torch.Generator().manual_seed(Lq * 7 + Lk + D)
+    qkv = torch.randn(B, max(Lq, Lk), Hq + 2 * Hkv, D, generator=g).to(torch.bfloat16).to(DEV)
+    q, k, v = qkv[:, :Lq, :Hq], qkv[:, :Lk, Hq:Hq + Hkv], qkv[:, :Lk, Hq + Hkv:]
+    k[:, Lk - 1] *= 4.0
+    k[:, Lk // 2] *= 3.0
+    k[:, 70] *= 5.0
+    o_ref, lse_ref = R.attention_ref(q.float().cpu(), k.float().cpu(), v.float().cpu(), False)
+    o0 = K.flash_attn_func(q, k, v, causal=False)
+    K.flash_attn_set_variant(1)
+    try:
+        o, lse = K.flash_attn_func(q, k, v, causal=False, return_lse=True)
+        o2 = K.flash_attn_func(q, k, v, causal=False)
+    finally:
+        K.flash_attn_set_variant(0)
+    close(o, o_ref, 2e-2, 1e-2, "o")
+    close(lse, lse_ref, 1e-3, 2e-3, "lse")
+    close(o, o0.float().cpu(), 2e-2, 1e-2, "o vs default kernel")
+    assert torch.equal(o, o2)                 # no stale ring / staging state between calls
+
+
 def test_flash_attention_spiked_max(K):
     """force large running-max jumps at chosen tiles (guide rule 26)."""
     g = torch.Generator().manual_seed(0)

@@ -17,6 +17,7 @@
 // cross_attention.py:310-317 non-causal), flash_attn_varlen_qkvpacked_func
 // (flash_attention_class.py:59-66).
 #include "ssd_common.hpp"
+#include <atomic>
 
 namespace {
 
@@ -790,12 +791,60 @@ __device__ __forceinline__ float w64_fma(float a, float b, float c) {
   asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b), "v"(c));
   return d;
 }
+// (no inline-asm consumer may follow a transcendental directly: gfx950 needs a wait state between v_exp_f32 and a VALU
+// that reads its result, and hipcc's hazard recogniser does not look into asm statements — an asm v_cvt_pk_bf16_f32
+// behind the exponentials packed the exponent instead of the power; the conversions below are plain C++)
 __device__ __forceinline__ unsigned w64_pk(float lo, float hi) {
-  unsigned d;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(d) : "v"(lo), "v"(hi));
-  return d;
+  typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+  const b2 v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(unsigned, v);
 }
 
+// TV_FA_W64_ASM = 1: the MFMAs are asm statements with the accumulator TIED to its register ("+a" / "+v"); 0: builtins.
+// With asm the hazard recogniser does not see the MFMAs: nothing may write an A / B operand with a VALU in the two
+// instructions before one, and VALU reads of a result must sit >= 18 wait states behind it (`mfma_settle`).
+#ifndef TV_FA_W64_ASM
+#define TV_FA_W64_ASM 1
+#endif
+__device__ __forceinline__ void w64_mfma_v(f32x16& c, bf16x8 a, const ssdk::u32x4& b) {
+#if TV_FA_W64_ASM
+  asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+#else
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+#endif
+}
+__device__ __forceinline__ void w64_mfma_v0(f32x16& c, bf16x8 a, const ssdk::u32x4& b) {
+#if TV_FA_W64_ASM
+  asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
+#else
+  const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, b), z, 0, 0, 0);
+#endif
+}
+__device__ __forceinline__ void w64_mfma_a(f32x16& c, bf16x8 a, bf16x8 b) {
+#if TV_FA_W64_ASM
+  asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+#else
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#endif
+}
+__device__ __forceinline__ void w64_mfma_a1(f32x16& c, const ssdk::u32x4& ones, bf16x8 b) {
+#if TV_FA_W64_ASM
+  asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(ones), "v"(b));
+#else
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), b, c, 0, 0, 0);
+#endif
+}
+__device__ __forceinline__ void mfma_settle() { asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory"); }
+
+#ifndef W64_ABL
+#define W64_ABL 0        // dev: timing ablations (wrong results): 1 no copies, 2 no tile maximum, 4 no softmax, 8 no epilogue stores
+#endif
+#ifdef TV_FA_STAMP
+#define W64STAMP(ph) do { if (st_on) { const unsigned long long n__ = clock64(); st_acc[ph] += n__ - st_last; st_last = n__; } } while (0)
+#else
+#define W64STAMP(ph) do {} while (0)
+#endif
 template <int KS, int DT>
 __global__ __launch_bounds__(256) void flash_fwd_w64_kernel(AttnArgs a) {
   typedef bf16_t T;
@@ -806,6 +855,7 @@ __global__ __launch_bounds__(256) void flash_fwd_w64_kernel(AttnArgs a) {
   typedef unsigned u32x2s __attribute__((ext_vector_type(2)));
   constexpr int NW = 4, KB = 64, ROWB = 256, TILEB = KB * ROWB, NS = 4, QB = 256, QW = 64;
   constexpr int NM = 2 * KS + 4 * (DT + 1);          // MFMAs per segment
+
   extern __shared__ __attribute__((aligned(16))) unsigned char fa_smem[];
   const unsigned sK_off = (unsigned)(uintptr_t)(lds_u8*)fa_smem, sV_off = sK_off + NS * TILEB;
 
@@ -823,27 +873,24 @@ __global__ __launch_bounds__(256) void flash_fwd_w64_kernel(AttnArgs a) {
   auto k_of = [&](int pr) { return (const T*)a.k + (int64_t)(pr / a.Hq) * a.ksb + (int64_t)((pr % a.Hq) / gq) * a.ksh; };
   auto v_of = [&](int pr) { return (const T*)a.v + (int64_t)(pr / a.Hq) * a.vsb + (int64_t)((pr % a.Hq) / gq) * a.vsh; };
 
-  // ---- Q^T fragments of half X (B operand): lane (r, hh) holds Q[row][16 ks + 8 hh + j].  Ordinary loads (two per
-  // query block and half, at the seams): hipcc's own wait in front of `finish_q` over-waits on the copies in flight,
-  // never under-waits (vmcnt is in issue order), and the registers may be moved freely in between.
-  auto load_q = [&](int pr, int qb, int X, u32x4 (&raw)[KS]) __attribute__((always_inline)) {
+  // ---- Q^T fragments of half X (B operand): lane (r, hh) holds Q[row][16 ks + 8 hh + j].  They come through a
+  // wave-private 8 KiB staging tile in LDS (32 rows in the K tile's image and swizzle: 8 copy pieces, then five
+  // ds_read_b128): every global access of the kernel is then a hand-counted LDS-DMA copy — an ordinary load here made
+  // hipcc put its own vmcnt waits in front of the MFMAs of every segment, which drained the copy queue each time.
+  // Rows past Lq repeat the last row (never stored); columns past head_dim are zeroed in the registers.
+  const unsigned sQ_off = sV_off + NS * TILEB + (unsigned)(wave * 8192);
+  auto copy_q = [&](int pr, int qb, int X) __attribute__((always_inline)) {
     const T* qp = (const T*)a.q + (int64_t)(pr / a.Hq) * a.qsb + (int64_t)(pr % a.Hq) * a.qsh;
-    const int qrow = qb * QB + wave * QW + 32 * X + r;
+    const void* sp = ssdk::uniform_ptr(qp);
+    const int row0 = qb * QB + wave * QW + 32 * X;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int d0 = ks * 16 + hh * 8;
-      raw[ks] = *(const u32x4*)((qrow < a.Lq && d0 < D) ? qp + (int64_t)qrow * a.qsl + d0 : qp);
+    for (int i = 0; i < 8; ++i) {
+      const int rl = 4 * i + (lane >> 4);
+      int cq = (lane & 15) ^ (rl & 15);
+      cq = cq < D / 8 ? cq : 0;
+      ssdk::glds16(sp, (unsigned)(min(row0 + rl, a.Lq - 1) * (int)a.qsl * 2 + cq * 16), sQ_off + 1024u * i);
     }
   };
-  auto finish_q = [&](int qb, int X, u32x4 (&raw)[KS]) __attribute__((always_inline)) {
-    const int qrow = qb * QB + wave * QW + 32 * X + r;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const u32x4 z = {0u, 0u, 0u, 0u};
-      raw[ks] = (qrow < a.Lq && ks * 16 + hh * 8 < D) ? raw[ks] : z;
-    }
-  };
-
   // ---- copies: this wave's four pieces of a tile = key rows 16 wave .. + 15 (4 rows a piece, lane l: row + l / 16,
   // LDS chunk l % 16, source chunk = chunk ^ swizzle; chunks past head_dim re-fetch chunk 0: finite pad).  Offsets are
   // relative to the tile's first key and pre-corrected for the instruction offsets of the grouped copy; a second set
@@ -851,36 +898,67 @@ __global__ __launch_bounds__(256) void flash_fwd_w64_kernel(AttnArgs a) {
   const int ntiles = (a.Lk + KB - 1) / KB;             // >= 4 (launcher)
   const int left_last = a.Lk - (ntiles - 1) * KB;
   const int dchunks = D / 8;
-  unsigned offK[4], offV[4], offKl[4], offVl[4];
+  unsigned offK[4], offV0;
+  const unsigned dV = (unsigned)(4 * (int)a.vsl * 2 - 1024);       // piece i + 1 against piece i (V's swizzle repeats every 4 rows)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = 16 * wave + 4 * i + (lane >> 4);
-    int ck = (lane & 15) ^ (row & 15), cv = (lane & 15) ^ (4 * (row & 3));
+    int ck = (lane & 15) ^ (row & 15);
     ck = ck < dchunks ? ck : 0;
-    cv = cv < dchunks ? cv : 0;
-    const int rl = min(row, left_last - 1);
     offK[i] = (unsigned)(row * (int)a.ksl * 2 + ck * 16 - 1024 * i);
-    offV[i] = (unsigned)(row * (int)a.vsl * 2 + cv * 16 - 1024 * i);
-    offKl[i] = (unsigned)(rl * (int)a.ksl * 2 + ck * 16 - 1024 * i);
-    offVl[i] = (unsigned)(rl * (int)a.vsl * 2 + cv * 16 - 1024 * i);
+  }
+  {
+    const int row = 16 * wave + (lane >> 4);
+    int cv = (lane & 15) ^ (4 * (row & 3));
+    cv = cv < dchunks ? cv : 0;
+    offV0 = (unsigned)(row * (int)a.vsl * 2 + cv * 16);
   }
   const unsigned m0_wave = (unsigned)(wave * 4096);
-  // the grouped copy adds 1024 j to the source address of piece j: a clamped row may sit below that -> the last tile
-  // uses single copies (`copy_last`) instead
-  auto copy4 = [&](const T* base, int kt, int64_t sl, const unsigned (&off)[4], unsigned lds_dst) __attribute__((always_inline)) {
-    const void* sp = ssdk::uniform_ptr(base + (int64_t)kt * KB * sl);
-    ssdk::glds16x4(sp, off[0], off[1], off[2], off[3], lds_dst + m0_wave);
-  };
-  auto copy_last = [&](const T* base, int kt, int64_t sl, const unsigned (&off)[4], unsigned lds_dst) __attribute__((always_inline)) {
-    const void* sp = ssdk::uniform_ptr(base + (int64_t)kt * KB * sl);
+  // (the grouped copy adds 1024 j to the source address of piece j; in the sequence's last tile a clamped row may sit
+  // below that, so that tile — one per query block — goes piece by piece with its offsets computed on the spot)
+  auto tile_copy_k = [&](const T* base, int kt, int stage) __attribute__((always_inline)) {
+    const void* sp = ssdk::uniform_ptr(base + (int64_t)kt * KB * a.ksl);
+    const unsigned dst = sK_off + stage * TILEB + m0_wave;
+    if (kt == ntiles - 1 && left_last < KB) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ssdk::glds16(sp, off[i] + 1024u * i, lds_dst + m0_wave + 1024u * i);
+      for (int i = 0; i < 4; ++i) {
+        const int row = 16 * wave + 4 * i + (lane >> 4);
+        int ck = (lane & 15) ^ (row & 15);
+        ck = ck < dchunks ? ck : 0;
+        ssdk::glds16(sp, (unsigned)(min(row, left_last - 1) * (int)a.ksl * 2 + ck * 16), dst + 1024u * i);
+      }
+    } else {
+      ssdk::glds16x4(sp, offK[0], offK[1], offK[2], offK[3], dst);
+    }
+  };
+  auto tile_copy_v = [&](const T* base, int kt, int stage) __attribute__((always_inline)) {
+    const void* sp = ssdk::uniform_ptr(base + (int64_t)kt * KB * a.vsl);
+    const unsigned dst = sV_off + stage * TILEB + m0_wave;
+    if (kt == ntiles - 1 && left_last < KB) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = 16 * wave + 4 * i + (lane >> 4);
+        int cv = (lane & 15) ^ (4 * (row & 3));
+        cv = cv < dchunks ? cv : 0;
+        ssdk::glds16(sp, (unsigned)(min(row, left_last - 1) * (int)a.vsl * 2 + cv * 16), dst + 1024u * i);
+      }
+    } else {
+      ssdk::glds16x4(sp, offV0, offV0 + dV, offV0 + 2 * dV, offV0 + 3 * dV, dst);
+    }
   };
 
   int k_rd[KS];
   const int kz = (hh ^ (r & 15)) << 4;
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) k_rd[ks] = r * ROWB + ((32 * ks) ^ kz);
+  auto read_q = [&](int X, u32x4 (&qf)[KS]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      const u32x4 v = __builtin_bit_cast(u32x4, F::row_read(lds_at(sQ_off + (unsigned)k_rd[ks])));
+      qf[ks] = (ks * 16 + hh * 8 < D) ? v : z;
+    }
+  };
   const int q4 = (lane & 15) >> 2, p4 = lane & 3;
   int v_rd[DT];
   {
@@ -897,8 +975,11 @@ __global__ __launch_bounds__(256) void flash_fwd_w64_kernel(AttnArgs a) {
   float mref[2] = {-INFINITY, -INFINITY}, tmax[2] = {-INFINITY, -INFINITY};
   bool first[2] = {true, true};
   v8 kf[3];
-  const u32x4 ones_u = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
-  const v8 ones = __builtin_bit_cast(v8, ones_u);
+  // four bf16 ones per dword, made opaque: a constant is re-materialised (v_mov) right in front of the asm MFMA that
+  // reads it, inside the wait states a VALU write needs before an MFMA reads the register
+  u32x4 ones_u;
+  asm volatile("v_mov_b32 %0, 0x3f803f80\n\tv_mov_b32 %1, 0x3f803f80\n\tv_mov_b32 %2, 0x3f803f80\n\tv_mov_b32 %3, 0x3f803f80"
+               : "=v"(ones_u[0]), "=v"(ones_u[1]), "=v"(ones_u[2]), "=v"(ones_u[3]));
 #pragma unroll
   for (int X = 0; X < 2; ++X) {
 #pragma unroll
@@ -919,24 +1000,18 @@ __global__ __launch_bounds__(256) void flash_fwd_w64_kernel(AttnArgs a) {
   __syncthreads();
   const T* kp = k_of(pair);
   const T* vp = v_of(pair);
-  auto tile_copy_k = [&](const T* base, int kt, int stage) __attribute__((always_inline)) {
-    if (kt == ntiles - 1 && left_last < KB) copy_last(base, kt, a.ksl, offKl, sK_off + stage * TILEB);
-    else copy4(base, kt, a.ksl, offK, sK_off + stage * TILEB);
-  };
-  auto tile_copy_v = [&](const T* base, int kt, int stage) __attribute__((always_inline)) {
-    if (kt == ntiles - 1 && left_last < KB) copy_last(base, kt, a.vsl, offVl, sV_off + stage * TILEB);
-    else copy4(base, kt, a.vsl, offV, sV_off + stage * TILEB);
-  };
   tile_copy_k(kp, 0, 0);
   tile_copy_k(kp, 1, 1);
   tile_copy_k(kp, 2, 2);
   tile_copy_v(vp, 0, 0);
   tile_copy_v(vp, 1, 1);
-  load_q(pair, qblk, 0, Qf[0]);
-  load_q(pair, qblk, 1, Qf[1]);
+  copy_q(pair, qblk, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  finish_q(qblk, 0, Qf[0]);
-  finish_q(qblk, 1, Qf[1]);
+  read_q(0, Qf[0]);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  copy_q(pair, qblk, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  read_q(1, Qf[1]);
   __builtin_amdgcn_s_barrier();
 
   auto kfrag = [&](unsigned cK, int m) __attribute__((always_inline)) {     // K fragment of QK^T MFMA m: sub-tile m & 1, k-step m >> 1
@@ -971,6 +1046,7 @@ __global__ __launch_bounds__(256) void flash_fwd_w64_kernel(AttnArgs a) {
         const float mn = fmaxf(mref[X], tm);
         const float al = __builtin_amdgcn_exp2f(mref[X] - mn);
         mref[X] = mn;
+        mfma_settle();
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -984,26 +1060,23 @@ __global__ __launch_bounds__(256) void flash_fwd_w64_kernel(AttnArgs a) {
   // One segment: MFMAs of half X (scores of the tile in K slot cK, PV of its previous P with the tile in V slot cV),
   // elementwise softmax of half Y = 1 - X, tile maximum of X's new scores; COPY: 1 the K group, 2 the V group, 0 none.
   // cKn: K slot whose first two fragments the NEXT segment starts with.
-  auto segment = [&](const int X, const bool MASK, const int kvalid, unsigned cK, unsigned cV, unsigned cKn,
-                     const int COPY, const T* cbase, int ckt, int cstage) __attribute__((always_inline)) {
+  auto segment = [&](const int X, const bool masked, const int kvalid, unsigned cK, unsigned cV, unsigned cKn,
+                     const T* cbase, int ckt, int cstage) __attribute__((always_inline)) {
+    const int COPY = X == 1 ? 1 : 2;
+    float ew[32], pw[32], mx = 0.f;
     const int Y = 1 - X;
     const float nm = -mref[Y];
     unsigned vb[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) vb[dt] = cV + (unsigned)v_rd[dt];
     v4 vlo[2][DT], vhi[2][DT];
-#pragma unroll
+#pragma clang loop unroll(full)
     for (int m = 0; m < NM; ++m) {
       // ---- the MFMA of this gap
       if (m < 2 * KS) {
         const int t = m & 1, ks = m >> 1;
-        const v8 qv = __builtin_bit_cast(v8, Qf[X][ks]);
-        if (ks == 0) {
-          const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          S[X][t] = F::mfma(kf[m % 3], qv, z);
-        } else {
-          S[X][t] = F::mfma(kf[m % 3], qv, S[X][t]);
-        }
+        if (ks == 0) w64_mfma_v0(S[X][t], kf[m % 3], Qf[X][ks]);
+        else w64_mfma_v(S[X][t], kf[m % 3], Qf[X][ks]);
       } else {
         const int j = m - 2 * KS, s_ = j / (DT + 1), w = j % (DT + 1);
         const v8 pv = __builtin_bit_cast(v8, Pf[X][s_]);
@@ -1011,48 +1084,85 @@ __global__ __launch_bounds__(256) void flash_fwd_w64_kernel(AttnArgs a) {
           v8 vf;
 #pragma unroll
           for (int e = 0; e < 4; ++e) { vf[e] = vlo[s_ & 1][w][e]; vf[4 + e] = vhi[s_ & 1][w][e]; }
-          O[X][w] = F::mfma(vf, pv, O[X][w]);
+          w64_mfma_a(O[X][w], vf, pv);
         } else {
-          Ls[X] = F::mfma(ones, pv, Ls[X]);
+          w64_mfma_a1(Ls[X], ones_u, pv);
         }
       }
       // ---- fillers
-      if (m + 2 < 2 * KS) kf[(m + 2) % 3] = kfrag(cK, m + 2);
-      if (m >= NM - 2) kf[m - (NM - 2)] = kfrag(cKn, m - (NM - 2));        // the next segment's first two
+      if (!(W64_ABL & 32) && m + 2 < 2 * KS) kf[(m + 2) % 3] = kfrag(cK, m + 2);
+      if (!(W64_ABL & 32) && m >= NM - 2) kf[m - (NM - 2)] = kfrag(cKn, m - (NM - 2));        // the next segment's first two
 #pragma unroll
       for (int s_ = 0; s_ < 4; ++s_)
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
-          if (m == 2 * KS - 4 + (DT + 1) * s_ + dt) {
+          if (!(W64_ABL & 16) && m == 2 * KS - 4 + (DT + 1) * s_ + dt) {
             vlo[s_ & 1][dt] = F::tr_read(lds_at(vb[dt]) + s_ * (16 * ROWB));
             vhi[s_ & 1][dt] = F::tr_read(lds_at(vb[dt]) + s_ * (16 * ROWB) + 8 * ROWB);
           }
-      // softmax of Y: 16 pairs over the gaps 0 .. 2 KS - 1 (one each) and the even gaps behind
-      {
-        int pi = -1;
-        if (m < 2 * KS) pi = m;
-        else if ((m - 2 * KS) % 2 == 0 && 2 * KS + (m - 2 * KS) / 2 < 16) pi = 2 * KS + (m - 2 * KS) / 2;
-        if (pi >= 0 && pi < 16) {
-          const int t = pi >> 3, rr = 2 * (pi & 7);
-          const float e0 = w64_fma(S[Y][t][rr], c_, nm), e1 = w64_fma(S[Y][t][rr + 1], c_, nm);
-          const float p0 = __builtin_amdgcn_exp2f(e0), p1 = __builtin_amdgcn_exp2f(e1);
-          Pf[Y][pi >> 2][pi & 3] = w64_pk(p0, p1);
+      // softmax of Y, one element = three stages a gap apart (no v_exp_f32 result is read in the gap that makes it: no
+      // hazard nops): fma in gap f(e) = 3 e / 4, exp2 in f(e) + 1, the pair's bf16 pack in f(odd e) + 2 — at most two
+      // of each per gap.  The empty asm statements pin every stage to its gap (LLVM otherwise sinks them to the use).
+      if (!(W64_ABL & 4)) {
+        // elements with f(e) = g:  (4 g + 2) / 3 <= e <= (4 g + 3) / 3
+        if (m >= 2) {
+#pragma unroll
+          for (int e = (4 * (m - 2) + 2) / 3; e <= (4 * (m - 2) + 3) / 3; ++e)
+            if (e < 32 && (e & 1)) {
+              unsigned pk = w64_pk(pw[e - 1], pw[e]);
+              asm volatile("" : "+v"(pk));
+              Pf[Y][e >> 3][(e & 7) >> 1] = pk;
+            }
+        }
+        if (m >= 1) {
+#pragma unroll
+          for (int e = (4 * (m - 1) + 2) / 3; e <= (4 * (m - 1) + 3) / 3; ++e)
+            if (e < 32) {
+              pw[e] = __builtin_amdgcn_exp2f(ew[e]);
+              asm volatile("" : "+v"(pw[e]));
+            }
+        }
+#pragma unroll
+        for (int e = (4 * m + 2) / 3; e <= (4 * m + 3) / 3; ++e)
+          if (e < 32) {
+            ew[e] = w64_fma(S[Y][e >> 4][e & 15], c_, nm);
+            asm volatile("" : "+v"(ew[e]));
+          }
+      }
+      // tile maximum of X's new scores (complete two gaps behind the last QK^T MFMA): the 16 register pairs over the
+      // gaps 2 KS + 2 .. NM - 1 (two in each of the first ones), one v_max3_f32 a pair
+      if (!(W64_ABL & 2) && m >= 2 * KS + 2) {
+        constexpr int G0 = 2 * KS + 2, NG = NM - G0, DBL = 16 - NG;      // DBL gaps take two pairs
+        static_assert(NG >= 8 && NG <= 16, "tile-maximum schedule");
+        const int g = m - G0;
+        const int u0 = g < DBL ? 2 * g : g + DBL, u1 = g < DBL ? u0 + 2 : u0 + 1;
+#pragma unroll
+        for (int u = u0; u < u1; ++u) {
+          const int t = u >> 3, i2 = 2 * (u & 7);
+          if (u == 0) asm volatile("v_max_f32 %0, %1, %2" : "=v"(mx) : "v"(S[X][t][i2]), "v"(S[X][t][i2 + 1]));
+          else asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(mx) : "v"(S[X][t][i2]), "v"(S[X][t][i2 + 1]));
         }
       }
-      if (COPY && m == (COPY == 1 ? TV_FA_W64_KGAP : TV_FA_W64_VGAP)) {
+      if (!(W64_ABL & 1) && m == (COPY == 1 ? TV_FA_W64_KGAP : TV_FA_W64_VGAP)) {
         if (COPY == 1) tile_copy_k(cbase, ckt, cstage);
         else tile_copy_v(cbase, ckt, cstage);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (MASK) mask_tail(X, kvalid);
-    tmax[X] = tile_max(X);
+    if (masked) {                          // (wave-uniform; one tile in a sequence; the asm keeps it a branch)
+      asm volatile("; masked tail");
+      mask_tail(X, kvalid);
+      tmax[X] = tile_max(X);
+    } else if (!(W64_ABL & 2)) {
+      tmax[X] = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    }
   };
 
   // epilogue of half X of query block (pr, qb): O / l -> global, reset the half
   auto epilogue = [&](int X, int pr, int qb) __attribute__((always_inline)) {
     const int h = pr % a.Hq, b = pr / a.Hq;
     const int qrow = qb * QB + wave * QW + 32 * X + r;
+    mfma_settle();
     const float l_tot = Ls[X][0];
     const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
     T* op = (T*)a.o + (int64_t)b * a.osb + (int64_t)min(qrow, a.Lq - 1) * a.osl + (int64_t)h * a.osh;
@@ -1069,14 +1179,22 @@ __global__ __launch_bounds__(256) void flash_fwd_w64_kernel(AttnArgs a) {
           const auto s0 = __builtin_amdgcn_permlane32_swap(ua[0], ub[0], false, false);
           const auto s1 = __builtin_amdgcn_permlane32_swap(ua[1], ub[1], false, false);
           const u32x4s w = {s0[0], s1[0], s0[1], s1[1]};
-          if (rowok) *(u32x4s*)(op + d_lo + 8 * hh) = w;
+          if (rowok && !(W64_ABL & 8)) *(u32x4s*)(op + d_lo + 8 * hh) = w;
         } else {
-          if (rowok) *(u32x2s*)(op + d_lo + 4 * hh) = ua;
-          if (rowok && d_lo + 8 + 4 * hh < D) *(u32x2s*)(op + d_lo + 8 + 4 * hh) = ub;
+          if (rowok && !(W64_ABL & 8)) *(u32x2s*)(op + d_lo + 4 * hh) = ua;
+          if (rowok && !(W64_ABL & 8) && d_lo + 8 + 4 * hh < D) *(u32x2s*)(op + d_lo + 8 + 4 * hh) = ub;
         }
       }
+#if defined(TV_FA_W64_DBG) && TV_FA_W64_DBG == 1
+    if (rowok && a.lse && hh == 0) a.lse[((int64_t)b * a.Hq + h) * a.Lq + qrow] = mref[X];
+#elif defined(TV_FA_W64_DBG) && (TV_FA_W64_DBG == 2 || TV_FA_W64_DBG == 4)
+    if (rowok && a.lse && hh == 0) a.lse[((int64_t)b * a.Hq + h) * a.Lq + qrow] = l_tot;
+#elif defined(TV_FA_W64_DBG) && TV_FA_W64_DBG == 3
+    if (rowok && a.lse && hh == 0) a.lse[((int64_t)b * a.Hq + h) * a.Lq + qrow] = Ls[X][5];
+#else
     if (rowok && a.lse && hh == 0)
       a.lse[((int64_t)b * a.Hq + h) * a.Lq + qrow] = l_tot > 0.f ? (mref[X] * 0.6931471805599453f + logf(l_tot)) : -INFINITY;
+#endif
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -1093,63 +1211,91 @@ __global__ __launch_bounds__(256) void flash_fwd_w64_kernel(AttnArgs a) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) S[0][t][i] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) S[0][t] = F::mfma(kfrag(cK, 2 * ks + t), __builtin_bit_cast(v8, Qf[0][ks]), S[0][t]);
+      for (int ks = 0; ks < KS; ++ks) {
+        const v8 kx = kfrag(cK, 2 * ks + t);
+        if (ks == 0) w64_mfma_v0(S[0][t], kx, Qf[0][ks]);
+        else w64_mfma_v(S[0][t], kx, Qf[0][ks]);
+      }
     }
+    mfma_settle();
     tmax[0] = tile_max(0);
     kf[0] = kfrag(cK, 0);
     kf[1] = kfrag(cK, 1);
   }
 
   const bool tail = left_last < KB;        // the last tile of a sequence has masked keys
+#ifdef TV_FA_STAMP
+  const bool st_on = blockIdx.x == 0 && wave == 0;
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = clock64();
+#endif
   int n = 0;                               // tile counter of the stream (ring slots)
   int pair_p = pair, qblk_p = qblk;        // half B's block (one segment behind at the seams)
-  bool have_prev = false;
+  bool have_prev = false, valid = true;    // valid = false: the phantom block behind the last one (half B's last PV only)
   for (;;) {
     const int slot_n = slot + step;
     const int pair_n = xcd * a.ppx + slot_n / a.nqb, qblk_n = slot_n % a.nqb;
-    const bool has_next = slot_n < nslots && pair_n < npairs;
+    const bool has_next = valid && slot_n < nslots && pair_n < npairs;
     const T* kp_n = has_next ? k_of(pair_n) : kp;
     const T* vp_n = has_next ? v_of(pair_n) : vp;
+    bool done = false;
     for (int kt = 0; kt < ntiles; ++kt, ++n) {
       const bool last = kt == ntiles - 1;
       const unsigned cK0 = sK_off + (unsigned)((n & 3) * TILEB), cK1 = sK_off + (unsigned)(((n + 1) & 3) * TILEB);
       const unsigned cV0 = sV_off + (unsigned)((n & 3) * TILEB), cVm = sV_off + (unsigned)(((n + 3) & 3) * TILEB);
-      // copies of this iteration: K three tiles ahead, V two
+      // copies of this iteration: K three tiles ahead, V two (past the last block: harmless re-fetches)
       const bool kw = kt + 3 >= ntiles, vw = kt + 2 >= ntiles;
       const T* ck = kw ? kp_n : kp;
       const T* cv = vw ? vp_n : vp;
       const int ckt = kw ? kt + 3 - ntiles : kt + 3, vkt = vw ? kt + 2 - ntiles : kt + 2;
       // ---- segment 1
+      W64STAMP(0);
       decide(0);
-      if (last && has_next) load_q(pair_n, qblk_n, 0, Qf[0]);      // Q_A's last use was the previous segment
-      if (last && tail) segment(1, true, left_last, cK0, cVm, cK1, 1, ck, ckt, (n + 3) & 3);
-      else segment(1, false, 0, cK0, cVm, cK1, 1, ck, ckt, (n + 3) & 3);
+      if (last && has_next) copy_q(pair_n, qblk_n, 0);             // Q_A's last use was the previous segment
+      W64STAMP(1);
+      segment(1, last && tail, left_last, cK0, cVm, cK1, ck, ckt, (n + 3) & 3);
+      W64STAMP(2);
       if (kt == 0 && have_prev) epilogue(1, pair_p, qblk_p);
-      if (last && has_next) finish_q(qblk_n, 0, Qf[0]);
+      if (!valid) { done = true; break; }
+      if (last && has_next) {        // the 8 Q pieces are older than this segment's 4 K pieces
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        read_q(0, Qf[0]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the staging tile is written again below
+      }
       // ---- segment 2
+      W64STAMP(3);
       decide(1);
-      if (last && has_next) load_q(pair_n, qblk_n, 1, Qf[1]);      // Q_B's last use was segment 1
-      if (kt == ntiles - 2 && tail) segment(0, true, left_last, cK1, cV0, cK1, 2, cv, vkt, (n + 2) & 3);
-      else segment(0, false, 0, cK1, cV0, cK1, 2, cv, vkt, (n + 2) & 3);
+      if (last && has_next) copy_q(pair_n, qblk_n, 1);             // Q_B's last use was segment 1
+      W64STAMP(4);
+      segment(0, kt == ntiles - 2 && tail, left_last, cK1, cV0, cK1, cv, vkt, (n + 2) & 3);
+      W64STAMP(5);
       if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      W64STAMP(6);
       __builtin_amdgcn_s_barrier();
+      W64STAMP(7);
       if (last) {
         epilogue(0, pair, qblk);
-        if (has_next) finish_q(qblk_n, 1, Qf[1]);
+        if (has_next) {
+          read_q(1, Qf[1]);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
       }
     }
+    if (done) break;
     pair_p = pair; qblk_p = qblk; have_prev = true;
-    if (!has_next) break;
-    slot = slot_n; pair = pair_n; qblk = qblk_n; kp = kp_n; vp = vp_n;
+    if (has_next) { slot = slot_n; pair = pair_n; qblk = qblk_n; kp = kp_n; vp = vp_n; }
+    else valid = false;
   }
-  // ---- drain: the last PV of half B
-  segment(1, false, 0, sK_off + (unsigned)((n & 3) * TILEB), sV_off + (unsigned)(((n + 3) & 3) * TILEB),
-          sK_off + (unsigned)((n & 3) * TILEB), 0, kp, 0, 0);
-  epilogue(1, pair_p, qblk_p);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the phantom segment's copies
+#ifdef TV_FA_STAMP
+  if (st_on && lane == 0) {
+    for (int i = 0; i < 8; ++i) g_fa_stamps[i] = st_acc[i];
+    g_fa_stamps[8] = (unsigned long long)n;
+  }
+#endif
 }
+
+std::atomic<int> g_fa_variant{[] { const char* v = getenv("TV_FA_W64"); return v ? atoi(v) : 0; }()};
 
 int tv_cu_count() {
   static const int n = [] {
@@ -1182,13 +1328,14 @@ int launch_fa_d(const AttnArgs& a, int B, hipStream_t st) {
         ax.o16 = ((uintptr_t)a.o % 16 == 0 && a.osb % 8 == 0 && a.osl % 8 == 0 && a.osh % 8 == 0) ? 1 : 0;
         static const int stream_ = [] { const char* v = getenv("TV_FA_STREAM"); return v ? atoi(v) : 1; }();
         const int64_t slots = (int64_t)ax.ppx * nqb;          // query blocks per XCD
-        static const int w64_ = [] { const char* v = getenv("TV_FA_W64"); return v ? atoi(v) : 1; }();
+        const int w64_ = g_fa_variant.load(std::memory_order_relaxed);
         bool w64_ok = false;
         if constexpr (KS == 5 && DT == 3 && sizeof(T) == 2 && Frag<T>::is_bf16)
-          w64_ok = w64_ && a.Lk >= 256 && a.ksl >= 128 && a.vsl >= 128 && slots > tv_cu_count() / 8;
+          w64_ok = w64_ && a.Lk >= 256 && a.ksl >= 128 && a.vsl >= 128 && slots > tv_cu_count() / 8 &&
+                   (int64_t)a.Lq * a.qsl * 2 < (1ll << 31);
         if (w64_ok) {
           if constexpr (KS == 5 && DT == 3 && Frag<T>::is_bf16) {
-            constexpr int lds4 = 2 * 4 * 64 * 256;             // K and V rings: 4 stages x 64 rows x 256 B
+            constexpr int lds4 = 2 * 4 * 64 * 256 + 4 * 8192;  // K and V rings: 4 stages x 64 rows x 256 B; Q staging: 8 KiB a wave
             e = hipFuncSetAttribute((const void*)flash_fwd_w64_kernel<KS, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
             if (e == hipSuccess)
               flash_fwd_w64_kernel<KS, DT><<<dim3((unsigned)(8 * (tv_cu_count() / 8)), 1, 1), 256, lds4, st>>>(ax);
@@ -1241,6 +1388,8 @@ extern "C" int tv_fa_debug_stamps(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fa_stamps), sizeof(g_fa_stamps));
 }
 #endif
+
+extern "C" void tv_flash_attn_set_variant(int variant) { g_fa_variant.store(variant, std::memory_order_relaxed); }
 
 extern "C" int tv_flash_attn_fwd(const void* q, const void* k, const void* v, void* o, void* lse,
                                  int batch, int seqlen_q, int seqlen_k, int nheads_q,

@@ -385,6 +385,12 @@ def ssd_scan_set_impl(impl: int) -> None:
 
 
 # ------------------------------------------------------------------ attention
+def flash_attn_set_variant(variant: int) -> None:
+    """0 auto (ViT frames: the streaming kernel), 1 the 4 x 64-row one-wave-per-SIMD kernel where it applies
+    (non-causal bf16, head_dim 65..80, >= 256 keys; include/timeviper_hip.h).  Process-global (dev tools and tests)."""
+    _capi.lib().tv_flash_attn_set_variant(int(variant))
+
+
 _ATTN_FP8 = {"on": False, "min_keys": 4096, "min_queries": 64}
 
 
