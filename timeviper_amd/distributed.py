@@ -45,18 +45,19 @@ def all_gather_varlen(t: torch.Tensor, group=None, lens: Optional[List[int]] = N
     world = dist.get_world_size(group)
     if lens is None:
         n = torch.tensor([t.shape[0]], device=t.device, dtype=torch.int64)
-        ns = [torch.zeros_like(n) for _ in range(world)]
-        dist.all_gather(ns, n, group=group)
-        ns = [int(v) for v in ns]
+        ns = [int(v) for v in all_gather_stack(n, group).view(-1).tolist()]
     else:
         ns = [int(v) for v in lens]
         assert len(ns) == world and ns[dist.get_rank(group)] == t.shape[0], (ns, t.shape)
     mx = max(ns)
-    pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    if mx == 0:
+        return [t[:0] for _ in range(world)]
+    pad = torch.empty((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     pad[: t.shape[0]] = t
-    out = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(out, pad, group=group)
-    return [o[:k] for o, k in zip(out, ns)]
+    if t.shape[0] < mx:
+        pad[t.shape[0]:].zero_()
+    out = all_gather_stack(pad, group)          # one tensor (world, mx, ...): the returned pieces are views of it
+    return [out[r, :k] for r, k in enumerate(ns)]
 
 
 def all_gather_stack(t: torch.Tensor, group=None) -> torch.Tensor:
@@ -221,9 +222,7 @@ class SequenceParallelTimeViper:
             assert self.shard_lens[self.rank] == mine, (self.shard_lens, mine)
             return self.shard_lens
         n = torch.tensor([mine], device=device, dtype=torch.int64)
-        ns = [torch.zeros_like(n) for _ in range(self.world)]
-        dist.all_gather(ns, n, group=self.group)
-        return [int(v) for v in ns]
+        return [int(v) for v in all_gather_stack(n, self.group).view(-1).tolist()]
 
     # ---------------------------------------------------------------- mixers
     def _mamba(self, mixer, normed):
@@ -291,26 +290,35 @@ class SequenceParallelTimeViper:
         kvd = attn.num_key_value_heads * attn.head_dim
         lens = self._lens(L, normed.device)
         mx = max(lens)
-        # K and V of this shard in ONE padded buffer, gathered asynchronously (RCCL runs the
-        # collective on its own stream) while q_proj — the largest of the three GEMMs — computes
-        kv = torch.empty((2, mx, kvd), dtype=normed.dtype, device=normed.device)
-        kv[0, :L] = attn.k_proj(normed).view(L, kvd)
-        kv[1, :L] = attn.v_proj(normed).view(L, kvd)
+        # K and V of this shard in ONE padded buffer, rows interleaved (row i = [K_i | V_i]), gathered asynchronously
+        # (RCCL runs the collective on its own stream) while q_proj — the largest of the three GEMMs — computes.
+        # In the gathered buffer (world, mx, 2, kvd) the K rows of ALL ranks then have ONE row stride (2 kvd): when the
+        # shards before this one are full (balanced split: the usual case) the causal prefix "ranks <= r" is a strided
+        # VIEW of it — no compaction copy; tv_flash_attn_fwd takes the row stride.
+        Hkv, Dh = attn.num_key_value_heads, attn.head_dim
+        kv = torch.empty((mx, 2, kvd), dtype=normed.dtype, device=normed.device)
+        kv[:L, 0] = attn.k_proj(normed).view(L, kvd)
+        kv[:L, 1] = attn.v_proj(normed).view(L, kvd)
         if L < mx:
-            kv[:, L:].zero_()
+            kv[L:].zero_()
         q = None
         if rope is not None and L > 0:       # rotary embedding in place on q and on the k rows of the buffer
             q = attn.q_proj(normed).view(Bsz, L, attn.num_heads, attn.head_dim)
-            K.apply_rotary_pos_emb_(q, kv[0, :L].view(1, L, attn.num_key_value_heads, attn.head_dim), *rope)
+            K.apply_rotary_pos_emb_(q, kv[:L, 0].unflatten(-1, (Hkv, Dh)).unsqueeze(0), *rope)
         gathered = torch.empty((self.world, kv.numel()), dtype=kv.dtype, device=kv.device)
         work = dist.all_gather_into_tensor(gathered, kv.view(1, -1), group=self.group, async_op=True)
-        gathered = gathered.view((self.world,) + tuple(kv.shape))
         if q is None:
             q = attn.q_proj(normed).view(Bsz, L, attn.num_heads, attn.head_dim)
         work.wait()
-        upto = self.rank + 1
-        kf = torch.cat([gathered[r, 0, :lens[r]] for r in range(upto)]).view(1, -1, attn.num_key_value_heads, attn.head_dim)
-        vf = torch.cat([gathered[r, 1, :lens[r]] for r in range(upto)]).view(1, -1, attn.num_key_value_heads, attn.head_dim)
+        if all(lens[r] == mx for r in range(self.rank)):
+            rows = gathered.view(self.world * mx, 2, kvd)[:self.rank * mx + L]
+            kf = rows[:, 0].unflatten(-1, (Hkv, Dh)).unsqueeze(0)
+            vf = rows[:, 1].unflatten(-1, (Hkv, Dh)).unsqueeze(0)
+        else:                                # a ragged shard in front of this one: compact the prefix
+            g4 = gathered.view(self.world, mx, 2, kvd)
+            upto = self.rank + 1
+            kf = torch.cat([g4[r, :lens[r], 0] for r in range(upto)]).view(1, -1, Hkv, Dh)
+            vf = torch.cat([g4[r, :lens[r], 1] for r in range(upto)]).view(1, -1, Hkv, Dh)
         scale = getattr(attn, "scaling", None)
         o = K.flash_attn_func(q, kf, vf, softmax_scale=scale, causal=True)      # bottom-right aligned: Lk >= Lq
         return attn.o_proj(o.reshape(Bsz, L, attn.num_heads * attn.head_dim))
