@@ -87,7 +87,7 @@ class HostReadCounter:
             setattr(torch.Tensor, n, f)
 
 
-def worker(rank, world, port, merge, T, q, family="nano"):
+def worker(rank, world, port, merge, T, q, family="nano", rebalance=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2 if world <= 4 else 1)
@@ -101,7 +101,8 @@ def worker(rank, world, port, merge, T, q, family="nano"):
         with cpu_kernels(), torch.no_grad():
             # one case with the model-derived frame split, one with a strongly skewed split (4 + 1)
             runner = SequenceParallelTimeViper(vlm, rank, world,
-                                               causal_skew=10.0 if merge == "CrossAttention" else None)
+                                               causal_skew=10.0 if merge == "CrossAttention" else None,
+                                               rebalance=rebalance)
             lo, hi = runner.frame_range(T)
             if merge == "CrossAttention" and world == 2 and family == "nano":
                 assert runner.frame_split(T) == [(0, 4), (4, 5)]
@@ -130,7 +131,7 @@ def worker(rank, world, port, merge, T, q, family="nano"):
                 ref = vlm(input_ids=ids, pixel_values_videos=pix).logits
                 ref_trace = [t["kept"] for t in vlm.llm_backbone.llm.backbone.last_pdrop_trace]
                 q.put((logits.numpy(), ref.numpy(), [t.numpy() for t in trace],
-                       [t.numpy() for t in ref_trace]))
+                       [t.numpy() for t in ref_trace], runner.rebalanced, list(runner.final_lens)))
         dist.barrier()
     except BaseException:
         import traceback
@@ -140,20 +141,24 @@ def worker(rank, world, port, merge, T, q, family="nano"):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("merge,world,T,family", [("no_merge", 2, 5, "nano"), ("CrossAttention", 2, 5, "nano"),
-                                                  ("CrossAttention", 8, 21, "nano"), ("CrossAttention", 2, 7, "qwen2"),
-                                                  ("no_merge", 4, 9, "qwen2")])
-def test_sequence_parallel_matches_single_process(merge, world, T, family):
+@pytest.mark.parametrize("merge,world,T,family,rebalance", [
+    ("no_merge", 2, 5, "nano", None), ("CrossAttention", 2, 5, "nano", None), ("CrossAttention", 8, 21, "nano", None),
+    ("CrossAttention", 2, 7, "qwen2", None), ("no_merge", 4, 9, "qwen2", None),
+    # re-balancing after every token-drop stage that leaves the shards uneven (threshold 1.0 = any imbalance; the 4 + 1
+    # frame split and the ranking's clustered keep-sets make every stage uneven): rows move between the ranks, the
+    # trailing text may end up on two of them, kept tokens and logits stay those of one process
+    ("CrossAttention", 2, 5, "nano", 1.0), ("CrossAttention", 4, 9, "nano", 1.0), ("CrossAttention", 4, 9, "qwen2", 1.0)])
+def test_sequence_parallel_matches_single_process(merge, world, T, family, rebalance):
     """world 8 = the node size the driver scales to: eight ranks, unequal frame ranges; qwen2 = the
     decoder-only family of BASELINE config 5 (every layer gathers rotated K and V)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=worker, args=(r, world, port, merge, T, q, family)) for r in range(world)]
+    procs = [ctx.Process(target=worker, args=(r, world, port, merge, T, q, family, rebalance)) for r in range(world)]
     for p in procs:
         p.start()
     try:
-        logits, ref, trace, ref_trace = q.get(timeout=240)   # plain numpy: no shm handles to lose
+        logits, ref, trace, ref_trace, moved, lens = q.get(timeout=240)   # plain numpy: no shm handles to lose
     finally:
         for p in procs:
             p.join(60)
@@ -164,6 +169,62 @@ def test_sequence_parallel_matches_single_process(merge, world, T, family):
     trace, ref_trace = [torch.from_numpy(t) for t in trace], [torch.from_numpy(t) for t in ref_trace]
     assert all(torch.equal(a, b) for a, b in zip(trace, ref_trace)), "kept indices differ"
     assert torch.allclose(logits, ref, rtol=1e-4, atol=1e-5), (logits - ref).abs().max()
+    if rebalance is not None:
+        assert moved >= 1, "no stage moved rows: the case does not exercise rebalance_rows"
+        assert max(lens) - min(lens) <= 1, lens
+
+
+def rebalance_worker(rank, world, port, lens, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from timeviper_amd.distributed import rebalance_rows
+        total = sum(lens)
+        full = torch.arange(total * 3, dtype=torch.float32).view(total, 3)
+        lo = sum(lens[:rank])
+        x, new = rebalance_rows(full[lo:lo + lens[rank]].clone(), lens)
+        x2, tgt = rebalance_rows(x, new, target=lens)              # and back to where the rows came from
+        q.put((rank, x.numpy(), new, x2.numpy()))
+        dist.barrier()
+    except BaseException:
+        import traceback
+        traceback.print_exc()
+        os._exit(1)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("lens", [[50, 3, 0, 27], [0, 0, 9], [7, 7], [1, 0, 0, 0, 0, 0, 0, 30]])
+def test_rebalance_rows_keeps_the_order(lens):
+    """a deliberately clustered shard layout (what a top-k token drop can leave): one all-to-all of row ranges gives
+    every rank its slice of the even split, in the original order; empty senders / receivers included"""
+    from timeviper_amd.distributed import balanced_lens
+    world = len(lens)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=rebalance_worker, args=(r, world, port, lens, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        got = {r: (x, new, x2) for r, x, new, x2 in (q.get(timeout=120) for _ in range(world))}
+    finally:
+        for p in procs:
+            p.join(60)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs), "worker failed (see its traceback above)"
+    total = sum(lens)
+    full = np.arange(total * 3, dtype=np.float32).reshape(total, 3)
+    tgt = balanced_lens(total, world)
+    assert sum(tgt) == total and max(tgt) - min(tgt) <= 1 and (total == 0 or tgt[-1] > 0)
+    for r in range(world):
+        x, new, x2 = got[r]
+        assert list(new) == tgt
+        lo = sum(tgt[:r])
+        assert np.array_equal(x, full[lo:lo + tgt[r]])
+        lo0 = sum(lens[:r])
+        assert np.array_equal(x2, full[lo0:lo0 + lens[r]])
 
 
 def test_chain_states_and_split():

@@ -22,7 +22,7 @@ needs2 = pytest.mark.skipif(NGPU < 2, reason="needs two GPUs: RCCL refuses two r
 UNI3 = "uni_2_0.75-uni_3_0.5-uni_6_0.25"
 
 
-def worker(rank, world, port, merge, T, q, pd, family):
+def worker(rank, world, port, merge, T, q, pd, family, rebalance=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     torch.cuda.set_device(rank)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
@@ -47,7 +47,7 @@ def worker(rank, world, port, merge, T, q, pd, family):
         ids = torch.tensor([[5, 6, 7] + [tok] * T + [8, 9, 10, 11, 12]], device="cuda")
         pix = torch.randn(T, 3, 96, 96, generator=g).cuda().bfloat16()
         with torch.no_grad():
-            runner = SequenceParallelTimeViper(vlm, rank, world)
+            runner = SequenceParallelTimeViper(vlm, rank, world, rebalance=rebalance)
             lo, hi = runner.frame_range(T)
             logits = runner.forward(ids, pix[lo:hi], T)
             trace = [t.cpu().numpy() for t in runner.trace]
@@ -65,11 +65,11 @@ def worker(rank, world, port, merge, T, q, pd, family):
         dist.destroy_process_group()
 
 
-def run(world, merge, pd, family, T):
+def run(world, merge, pd, family, T, rebalance=None):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=worker, args=(r, world, port, merge, T, q, pd, family)) for r in range(world)]
+    procs = [ctx.Process(target=worker, args=(r, world, port, merge, T, q, pd, family, rebalance)) for r in range(world)]
     for p in procs:
         p.start()
     try:
@@ -85,11 +85,13 @@ def run(world, merge, pd, family, T):
 
 @needs2
 @pytest.mark.parametrize("world", [2] + ([8] if NGPU >= 8 else []))
-@pytest.mark.parametrize("merge,pd,family", [("no_merge", None, "nano"), ("CrossAttention", UNI3, "nano"),
-                                             ("CrossAttention", PD, "nano"), ("CrossAttention", UNI3, "qwen2")])
-def test_sequence_parallel_over_rccl_matches_single_gpu(world, merge, pd, family):
+@pytest.mark.parametrize("merge,pd,family,rebalance", [
+    ("no_merge", None, "nano", None), ("CrossAttention", UNI3, "nano", None), ("CrossAttention", PD, "nano", None),
+    ("CrossAttention", UNI3, "qwen2", None),
+    ("CrossAttention", UNI3, "nano", 1.0)])      # rows re-balanced (all_to_all_single over RCCL) after every uneven stage
+def test_sequence_parallel_over_rccl_matches_single_gpu(world, merge, pd, family, rebalance):
     T = 21 if world == 2 else 67           # ragged shards: 11 / 10 frames, or 8 ranks of 8-9 frames
-    logits, ref, trace, ref_trace = run(world, merge, pd, family, T)
+    logits, ref, trace, ref_trace = run(world, merge, pd, family, T, rebalance)
     logits, ref = torch.from_numpy(logits), torch.from_numpy(ref)
     assert logits.shape == ref.shape and torch.isfinite(logits).all()
     assert len(trace) == len(ref_trace) and all(a.shape == b.shape for a, b in zip(trace, ref_trace))

@@ -29,6 +29,7 @@ the 8 GPUs with RCCL all-gather of the SSM states over xGMI".  One process per G
 from __future__ import annotations
 
 import math
+import os
 from typing import List, Optional, Tuple
 
 import torch
@@ -69,6 +70,37 @@ def all_gather_stack(t: torch.Tensor, group=None) -> torch.Tensor:
     out = torch.empty((world, flat.shape[1]), dtype=t.dtype, device=t.device)
     dist.all_gather_into_tensor(out, flat, group=group)
     return out.view((world,) + tuple(t.shape))
+
+
+def balanced_lens(total: int, world: int) -> List[int]:
+    """contiguous shards of `total` rows as even as possible (the LAST total % world ranks hold one more: the last
+    rank, which owns the final token, is never the empty one)"""
+    return [total // world + (1 if r >= world - total % world else 0) for r in range(world)]
+
+
+def rebalance_rows(x: torch.Tensor, lens: List[int], group=None, target: Optional[List[int]] = None):
+    """Move the shard boundaries of a row-sharded sequence without changing its order: rank r holds rows
+    [sum(lens[:r]), sum(lens[:r+1])) in `x` (dim 0) and ends up with [sum(target[:r]), sum(target[:r+1]))
+    (default: `balanced_lens`).  One all-to-all of row ranges — a rank only exchanges rows with the ranks whose new
+    range overlaps its old one (after an "attn" token-drop stage whose kept tokens cluster on a few ranks, §6 of
+    DESIGN.md); every split size is a host integer derived from `lens`, no size exchange.  Returns (x', target)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    total = sum(lens)
+    target = balanced_lens(total, world) if target is None else [int(t) for t in target]
+    assert sum(target) == total and len(lens) == world == len(target) and lens[rank] == x.shape[0], (lens, target, x.shape)
+    if list(lens) == list(target):
+        return x, target
+    old_lo = [sum(lens[:r]) for r in range(world)]
+    new_lo = [sum(target[:r]) for r in range(world)]
+
+    def overlap(a_lo, a_n, b_lo, b_n):
+        return max(0, min(a_lo + a_n, b_lo + b_n) - max(a_lo, b_lo))
+    send = [overlap(old_lo[rank], lens[rank], new_lo[d], target[d]) for d in range(world)]     # in rank order = row order
+    recv = [overlap(old_lo[s], lens[s], new_lo[rank], target[rank]) for s in range(world)]
+    out = torch.empty((target[rank],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    dist.all_to_all_single(out, x.contiguous(), output_split_sizes=recv, input_split_sizes=send, group=group)
+    return out, target
 
 
 def chain_states(states: torch.Tensor, decays: torch.Tensor, rank: int) -> torch.Tensor:
@@ -170,11 +202,19 @@ def _global_rank(group, group_rank: int) -> int:
 
 
 class SequenceParallelTimeViper:
-    def __init__(self, vlm, rank: int, world: int, group=None, causal_skew: Optional[float] = None):
+    def __init__(self, vlm, rank: int, world: int, group=None, causal_skew: Optional[float] = None,
+                 rebalance: Optional[float] = None):
         """`causal_skew`: see `split_frames`; None = estimate it from the model (every rank computes
-        the same number from the same shapes), 0 = even frame split."""
+        the same number from the same shapes), 0 = even frame split.
+        `rebalance`: after a token-drop stage, move the shard boundaries back to an even split (`rebalance_rows`)
+        when the longest shard exceeds `rebalance` x the mean (e.g. 1.25); None (default, env TV_SP_REBALANCE) =
+        keep the shards as the stage leaves them."""
         self.vlm, self.rank, self.world, self.group = vlm, rank, world, group
         self.causal_skew = causal_skew
+        if rebalance is None and os.environ.get("TV_SP_REBALANCE"):
+            rebalance = float(os.environ["TV_SP_REBALANCE"])
+        self.rebalance = rebalance
+        self.rebalanced = 0                             # stages after which rows moved (tests, logs)
         self.shard_lens: Optional[List[int]] = None     # host-side shard lengths (set by forward)
         self.llm = vlm.llm_backbone.llm
         self.family = vlm.llm_backbone.llm_family
@@ -339,11 +379,14 @@ class SequenceParallelTimeViper:
         if "attn" in ctype:
             sa = bb._rank_attention(layer_idx)
             row = txt_len + image_tokens - 1                      # global index of the query token
-            # the query row lives on the last rank: broadcast its projected queries
+            # the query row lives on the last rank unless the shards were re-balanced and the trailing text spans more
+            # than one of them: its owner (host integers) broadcasts its projected queries
+            s_all = self._starts()
+            owner = max(r for r in range(self.world) if s_all[r] <= row)
             q_row = torch.empty((sa.num_heads, sa.head_dim), dtype=feats.dtype, device=dev)
-            if self.rank == self.world - 1:
+            if self.rank == owner:
                 q_row = sa.q_proj(feats[row - start: row - start + 1]).view(sa.num_heads, sa.head_dim).contiguous()
-            dist.broadcast(q_row, src=_global_rank(self.group, self.world - 1), group=self.group)
+            dist.broadcast(q_row, src=_global_rank(self.group, owner), group=self.group)
             n_local = max(0, min(L, row + 1 - start))             # local keys that take part
             k_loc = sa.k_proj(feats[:n_local]).view(n_local, sa.num_key_value_heads, sa.head_dim)
             # the SAME two kernels the unsharded model runs (tv_attn_rank_scores = logits of the keys,
@@ -405,7 +448,7 @@ class SequenceParallelTimeViper:
                 kd = vd = feats.new_empty((0, kvd))
             kd = torch.cat(all_gather_varlen(kd, self.group, n_drop))
             vd = torch.cat(all_gather_varlen(vd, self.group, n_drop))
-            if self.rank == self.world - 1 and n_text:
+            if n_text:               # (the last rank; after a re-balance possibly its neighbour too)
                 text = new[new.shape[0] - n_text:]
                 qd = mod.q_proj(text).view(1, n_text, mod.num_heads, mod.head_dim)
                 o = K.flash_attn_func(qd, kd.view(1, -1, mod.num_key_value_heads, mod.head_dim),
@@ -416,6 +459,11 @@ class SequenceParallelTimeViper:
                     for r, (s0, e0) in enumerate(zip(starts, ends))]
         assert new_lens[self.rank] == new.shape[0], (new_lens, new.shape)
         self.shard_lens = new_lens
+        if self.rebalance is not None and self.world > 1:
+            total = sum(new_lens)
+            if total and max(new_lens) * self.world > self.rebalance * total:
+                new, self.shard_lens = rebalance_rows(new, new_lens, self.group)
+                self.rebalanced += 1
         new_start = sum(self.shard_lens[: self.rank])
         return new.unsqueeze(0), new_start, top
 
@@ -451,7 +499,7 @@ class SequenceParallelTimeViper:
         meta = {"num_vision_tokens": n_frames * tpf, "vision_index": n_before,
                 "text_prompt_len": n_before + n_after}
         logits = self.run_layers(hidden, start, meta)
-        self.shard_lens = None
+        self.final_lens, self.shard_lens = list(self.shard_lens), None     # (final_lens: tests, logs)
         return logits
 
     def run_layers(self, hidden, start: int, meta):
