@@ -264,8 +264,10 @@ int tv_flash_attn_fwd(const void* q, const void* k, const void* v, void* o,
 /* Kernel variant for many short non-causal sequences of head_dim 65..80 (the SigLIP ViT frames; testing /
  * benchmarking, process-global): 0 = auto (the streaming kernel: 8 waves x 32 query rows, two waves per SIMD),
  * 1 = 4 waves x 64 query rows at one wave per SIMD with the two 32-row halves half a tile apart
- * (flash_fwd_w64_kernel; bf16, >= 256 keys, row strides >= 128 elements; slower at head_dim 72 — DESIGN.md §5 —
- * and therefore not the default).  Results agree within the operator's tolerance.  Initial value: env TV_FA_W64. */
+ * (flash_fwd_w64_kernel), 2 = the same in-wave pipeline on 16-row halves, 8 waves, two per SIMD
+ * (flash_fwd_w32_kernel); both bf16, >= 256 keys, row strides >= 128 elements; both slower at head_dim 72 —
+ * DESIGN.md §5 — and therefore not the default.  Results agree within the operator's tolerance.
+ * Initial value: env TV_FA_W64. */
 void tv_flash_attn_set_variant(int variant);
 
 /* The same operator with the QK^T and PV products on the FP8 matrix path of CDNA4

@@ -415,10 +415,12 @@ def test_flash_attention_streaming(K, dtype, B, Lq, Lk, Hq, Hkv, D):
     (12, 768, 512, 16, 8, 80),       # GQA, head_dim 80 (no pad columns), Lk a multiple of the tile, Lq != Lk
     (40, 260, 1000, 8, 8, 72),       # 2 query blocks of which the second holds 4 rows, 16 key tiles
 ])
-def test_flash_attention_w64_variant(K, B, Lq, Lk, Hq, Hkv, D):
+@pytest.mark.parametrize("variant", [1, 2])
+def test_flash_attention_w64_variant(K, variant, B, Lq, Lk, Hq, Hkv, D):
     """`tv_flash_attn_set_variant(1)`: flash_fwd_w64_kernel (4 waves x 64 query rows, the halves of a wave half a tile
-    apart, lazy rescale, row sums on the matrix pipe) against the fp32 oracle and against the default kernel;
-    dominant keys in late tiles force the reference maximum to move by more than the lazy threshold."""
+    apart, lazy rescale, row sums on the matrix pipe); `(2)`: flash_fwd_w32_kernel (the same pipeline on 16-row halves,
+    8 waves, two per SIMD) — against the fp32 oracle and against the default kernel; dominant keys in late tiles force
+    the reference maximum to move by more than the lazy threshold."""
     g = torch.Generator().manual_seed(Lq * 7 + Lk + D)
     qkv = torch.randn(B, max(Lq, Lk), Hq + 2 * Hkv, D, generator=g).to(torch.bfloat16).to(DEV)
     q, k, v = qkv[:, :Lq, :Hq], qkv[:, :Lk, Hq:Hq + Hkv], qkv[:, :Lk, Hq + Hkv:]
@@ -427,7 +429,7 @@ def test_flash_attention_w64_variant(K, B, Lq, Lk, Hq, Hkv, D):
     k[:, 70] *= 5.0
     o_ref, lse_ref = R.attention_ref(q.float().cpu(), k.float().cpu(), v.float().cpu(), False)
     o0 = K.flash_attn_func(q, k, v, causal=False)
-    K.flash_attn_set_variant(1)
+    K.flash_attn_set_variant(variant)
     try:
         o, lse = K.flash_attn_func(q, k, v, causal=False, return_lse=True)
         o2 = K.flash_attn_func(q, k, v, causal=False)

@@ -12,10 +12,12 @@ from timeviper_amd import _capi, kernels as K  # noqa: E402
 B, L, H, D = 256, 729, 16, 72
 qkv = torch.randn(B, L, 3, H, D, device="cuda", dtype=torch.bfloat16)
 q, k, v = qkv.unbind(2)
+K.flash_attn_set_variant(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 K.flash_attn_func(q, k, v)
 torch.cuda.synchronize()
 out = (ctypes.c_ulonglong * 256)()
-fn = ctypes.CDLL(str(Path(_capi.__file__).parent / "lib" / "libtimeviper_hip.so")).tv_fa_debug_stamps
+import os
+fn = ctypes.CDLL(os.environ.get("TIMEVIPER_HIP_LIB", str(Path(_capi.__file__).parent / "lib" / "libtimeviper_hip.so"))).tv_fa_debug_stamps
 fn.argtypes = [ctypes.c_void_p]
 assert fn(out) == 0
 tasks = (B * H * 3) // 256

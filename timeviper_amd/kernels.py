@@ -386,8 +386,9 @@ def ssd_scan_set_impl(impl: int) -> None:
 
 # ------------------------------------------------------------------ attention
 def flash_attn_set_variant(variant: int) -> None:
-    """0 auto (ViT frames: the streaming kernel), 1 the 4 x 64-row one-wave-per-SIMD kernel where it applies
-    (non-causal bf16, head_dim 65..80, >= 256 keys; include/timeviper_hip.h).  Process-global (dev tools and tests)."""
+    """0 auto (ViT frames: the streaming kernel), 1 the 4 x 64-row one-wave-per-SIMD kernel, 2 the 8 x 32-row
+    two-waves-per-SIMD kernel with 16-row halves, where they apply (non-causal bf16, head_dim 65..80, >= 256 keys;
+    include/timeviper_hip.h).  Process-global (dev tools and tests)."""
     _capi.lib().tv_flash_attn_set_variant(int(variant))
 
 
