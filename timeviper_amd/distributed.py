@@ -193,7 +193,14 @@ def estimate_causal_skew(vlm, tokens_per_frame: int) -> float:
             attn_pair += 4.0 * (tokens_per_frame * keep) ** 2 * mx.head_dim * mx.num_heads
     if flops_lin <= 0.0:
         return 0.0
-    return (attn_pair / _ATTN_RATE) / (flops_lin / _LINEAR_RATE)
+    # TV_SP_RATES="<linear TFLOP/s>,<causal-attention TFLOP/s>": the two kernel rates of the GPU at hand (the module
+    # constants are this repo's MI355X measurements); TV_SP_CAUSAL_SKEW=<k> overrides the estimate
+    if os.environ.get("TV_SP_CAUSAL_SKEW"):
+        return float(os.environ["TV_SP_CAUSAL_SKEW"])
+    lin_rate, attn_rate = _LINEAR_RATE, _ATTN_RATE
+    if os.environ.get("TV_SP_RATES"):
+        lin_rate, attn_rate = (float(v) * 1e12 for v in os.environ["TV_SP_RATES"].split(","))
+    return (attn_pair / attn_rate) / (flops_lin / lin_rate)
 
 
 def _global_rank(group, group_rank: int) -> int:
