@@ -341,7 +341,10 @@ int tv_ssd_correct_all_launch(void* y, const void* dt, const void* A, const void
                                                                          total_decay, nseg, bh, per_head, gate, gate_run_if);
   if (nsegc > 0) {
     ssd_decay_prefix_kernel<<<dim3(nheads, batch * nsegc), 64, 0, st>>>(a);
-    int slots = seg_chunks < 8 ? seg_chunks : 8;       // (measured at 8 segments of the 9B model: 4: 311 us, 8: 274, 16: 336, 32: 533)
+    // work-groups per (head, boundary): every one of them loads the 20 KB of S_in, most leave at once (the carried-in
+    // term has underflowed).  Whole scan at 163 940 / 32 868 tokens, bench-like dt: 1: 2 560 / 754 us, 2: 2 507 / 706,
+    // 4: 2 454 / 694, 6: 2 458 / 681, 8: 2 499 / 699, 16: 2 613 / 785, 32: 2 827 / 961; slowly decaying dt: 6 is best
+    int slots = seg_chunks < 6 ? seg_chunks : 6;
     if (const char* e = getenv("TV_CORR_SLOTS")) slots = atoi(e) > 0 ? atoi(e) : slots;      // dev tool
     launch_correct_pt(a, dim3(slots, nheads, batch * nsegc), headdim, st);
   }
