@@ -1185,16 +1185,8 @@ __global__ __launch_bounds__(256) void flash_fwd_w64_kernel(AttnArgs a) {
           if (rowok && !(W64_ABL & 8) && d_lo + 8 + 4 * hh < D) *(u32x2s*)(op + d_lo + 8 + 4 * hh) = ub;
         }
       }
-#if defined(TV_FA_W64_DBG) && TV_FA_W64_DBG == 1
-    if (rowok && a.lse && hh == 0) a.lse[((int64_t)b * a.Hq + h) * a.Lq + qrow] = mref[X];
-#elif defined(TV_FA_W64_DBG) && (TV_FA_W64_DBG == 2 || TV_FA_W64_DBG == 4)
-    if (rowok && a.lse && hh == 0) a.lse[((int64_t)b * a.Hq + h) * a.Lq + qrow] = l_tot;
-#elif defined(TV_FA_W64_DBG) && TV_FA_W64_DBG == 3
-    if (rowok && a.lse && hh == 0) a.lse[((int64_t)b * a.Hq + h) * a.Lq + qrow] = Ls[X][5];
-#else
     if (rowok && a.lse && hh == 0)
       a.lse[((int64_t)b * a.Hq + h) * a.Lq + qrow] = l_tot > 0.f ? (mref[X] * 0.6931471805599453f + logf(l_tot)) : -INFINITY;
-#endif
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
