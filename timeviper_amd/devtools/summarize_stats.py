@@ -25,14 +25,14 @@ def share(pred):
 
 
 print()
-for pat in ("ssd_slice_kernel", "ssd_cb_kernel"):
+for pat in ("ssd_head_kernel", "ssd_slice_kernel", "ssd_cb_kernel", "ssd_correct_kernel", "ssd_seg_chain", "ssd_decay_prefix"):
     for r in rows:
         if pat in r["Name"]:
             print(f"- `{r['Name'][:60]}`: {r['Calls']} calls, avg {float(r['AverageNs']) / 1e3:.1f} µs, "
                   f"max {float(r['MaxNs']) / 1e3:.1f} µs")
 rf = line["roofline"]
 print(f"\n`bench.py` measured the scan with events on the launch stream: {rf['launches']} launches, avg "
-      f"{rf['avg_launch_us']} µs (both kernels), {rf['achieved']} GB/s algorithmic = **{100 * rf['frac']:.1f} % of "
+      f"{rf['avg_launch_us']} µs (all kernels of the operator), {rf['achieved']} GB/s algorithmic = **{100 * rf['frac']:.1f} % of "
       f"{rf['peak'] / 1000:.0f} TB/s**; HBM traffic {rf['traffic']} GB/s ({rf.get('traffic_source', '')}).\n")
 print("Share of GPU time: hipBLASLt GEMMs %.1f %%, attention kernels %.1f %%, GELU %.1f %%, LayerNorm %.1f %%, "
       "patch embed %.1f %%, ToMe %.1f %%, Mamba kernels (scan, conv, gated norm) %.1f %%." % (
