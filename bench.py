@@ -103,9 +103,33 @@ class OpTimers:
             flops = 2.0 * F_ * n * Cin * pp * pp * weight.shape[0]
             byts = F_ * (Cin * Hh * Ww + n * weight.shape[0]) * pixels.element_size()
             return ("patch_embed", (flops, byts))
+        # HBM-bound companions of the scan (bytes per token and Mamba layer) and the ViT's element-wise passes:
+        # key[1] = algorithmic bytes of the call
+        def conv(xBC, weight, bias, d_inner, ngroups, dstate, *a, **kw):
+            return ("conv", xBC.shape[0] * xBC.shape[1] * 2 * xBC.shape[2] * xBC.element_size())   # xBC read, x|B|C written
+
+        def gnorm(x, weight, bias=None, z=None, *a, **kw):
+            rows = x.numel() // x.shape[-1]
+            return ("gated_norm", rows * x.shape[-1] * x.element_size() * (3 if z is not None else 2))
+
+        def rms(x, weight, eps, residual=None, return_sum=False):
+            n = x.numel() * x.element_size()
+            return ("rmsnorm", n * (2 + (residual is not None) + bool(return_sum and residual is not None)))
+
+        def ln(x, weight, bias, eps, residual=None, return_sum=False, row_bias=None):
+            n = x.numel() * x.element_size()
+            return ("layernorm", n * (2 + (residual is not None) + bool(return_sum and residual is not None)))
+
+        def gelu(x, inplace=False):
+            return ("gelu", 2 * x.numel() * x.element_size())
         self._wrap("mamba_chunk_scan_combined", scan)
         self._wrap("flash_attn_func", attn)
         self._wrap("patch_embed", patch)
+        self._wrap("causal_conv1d_xbc", conv)
+        self._wrap("rmsnorm_fn", gnorm)
+        self._wrap("rms_norm", rms)
+        self._wrap("layer_norm", ln)
+        self._wrap("gelu", gelu)
         return self
 
     def __exit__(self, *exc):
@@ -138,8 +162,8 @@ class OpTimers:
                 src = (f"profiles/{files[-1].name} was taken on other scan kernels (source id "
                        f"{tf.get('scan_source_id')}, tree {scan_source_id()}): re-run devtools/pmc_scan.sh")
         return {"bound": "hbm", "kernel": "ssd_scan (tv_ssd_scan_cb_fwd: ssd_head_kernel<5,4,2> head-per-wave march x 8-16 "
-                                          "segments (+ its complete variant for flagged work-groups) + ssd_seg_chain + "
-                                          "ssd_decay_prefix + ssd_correct kernels)",
+                                          "sequence segments (floating, reset and standard steps in the one kernel) + "
+                                          "ssd_seg_chain + ssd_decay_prefix + ssd_correct kernels)",
                 "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "traffic_source": src, "launches": len(r),
                 "avg_launch_us": round(ms * 1e3 / len(r), 1), "bytes_per_token": bytes_per_token}
@@ -168,11 +192,45 @@ class OpTimers:
                 dict(base, bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                      frac=round(gbs / HBM_PEAK_GBS, 4))]
 
-    def all_rooflines(self, bytes_per_token):
+    def hbm_roofline(self, key, kernel):
+        ms, r = self._ms(key)
+        if not r:
+            return None
+        gbs = sum(b for _, _, b in r) / (ms * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": kernel, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "launches": len(r),
+                "avg_launch_us": round(ms * 1e3 / len(r), 1)}
+
+    def mixer_trio_roofline(self, cfg):
+        """conv + scan + gated norm of the Mamba layers as ONE operator against SURVEY 8d's fused lower bound: read
+        xBC + dt + gate, write the normed y (65 792 B per token and layer at Nano dims).  Work that moves between the
+        three kernels (C.B^T into the conv, the carried-in correction into the norm, ...) stays inside this entry."""
+        ms = sum(self._ms(k)[0] for k in ("conv", "scan", "gated_norm"))
+        _, r = self._ms("scan")
+        if not r or not ms:
+            return None
+        H, P, G, N = cfg.mamba_num_heads, cfg.mamba_head_dim, cfg.n_groups, cfg.ssm_state_size
+        per_token = 2 * ((H * P + 2 * G * N) + H + H * P) + 2 * H * P
+        gbs = sum(n for _, _, n in r) * per_token / (ms * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": "Mamba mixer trio: causal_conv1d_xbc(+C.B^T) + mamba_chunk_scan_combined + rmsnorm_fn, "
+                                          "against the fused bound (read xBC, dt, gate; write y)",
+                "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                "traffic": None, "launches": len(r), "avg_launch_us": round(ms * 1e3 / len(r), 1),
+                "bytes_per_token": per_token}
+
+    def all_rooflines(self, bytes_per_token, cfg=None):
         out = [self.scan_roofline(bytes_per_token),
                self.mfma_roofline("attn_vit", "flash_fwd_stream_kernel, ViT frames (non-causal, head_dim 72; useful FLOPs)"),
                self.mfma_roofline("attn_causal", "flash_fwd_kernel, causal GQA (LLM attention layers; useful FLOPs)")]
-        return [o for o in out if o] + self.patch_rooflines()
+        out += self.patch_rooflines()
+        out += [self.hbm_roofline("conv", "conv1d_xbc_kernel + conv1d_bc_cb_kernel (tv_causal_conv1d_xbc_cb_fwd: conv + SiLU + "
+                                          "x|B|C split + causal C.B^T fragments; bytes: xBC read, x|B|C written)"),
+                self.hbm_roofline("gated_norm", "rmsnorm_gated_kernel (tv_rmsnorm_gated_fwd; bytes: y, gate read, out written)"),
+                self.mixer_trio_roofline(cfg) if cfg is not None else None,
+                self.hbm_roofline("rmsnorm", "rmsnorm_kernel (tv_rmsnorm_fwd, residual add fused; bytes: every row read / written once)"),
+                self.hbm_roofline("layernorm", "layernorm_wave_kernel (tv_layernorm_fwd, ViT; bytes: every row read / written once)"),
+                self.hbm_roofline("gelu", "gelu_kernel (tv_gelu_fwd, in place: ViT MLP and projector; bytes: read + write)")]
+        return [o for o in out if o]
 
 
 def cpu_baseline(cfg, frames_sample=256, vit_frames=16):
@@ -441,7 +499,7 @@ def main():
             # the kernel north_star names (dominant among the hand-written HBM-bound ones) ...
             "roofline": st.scan_roofline(scan_bytes_per_token(cfg)),
             # ... and every kernel with a stated roof, all event-timed inside the timed steps
-            "rooflines": st.all_rooflines(scan_bytes_per_token(cfg)),
+            "rooflines": st.all_rooflines(scan_bytes_per_token(cfg), cfg),
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)

@@ -163,6 +163,19 @@ int tv_rmsnorm_gated_fwd(const void* x, const void* z, const void* weight,
  * workspace: tv_ssd_scan_workspace_bytes() bytes of device memory (may be 0 /
  * NULL: the workspace-free kernels are used then); nothing persists in it
  * between calls.  seqlen == 0 is valid (the state passes through).
+ * Approximations of the default bf16 kernel (head-per-wave march, csrc/ssd_head.hip), all far below
+ * the bf16 rounding of y and bounded in tests/test_fullsize_gpu.py / test_ops_gpu.py:
+ *  - a 64-token chunk that decays the state by more than 2^-64 starts the state anew: what the old
+ *    state would have carried over (< 2^-64 of it) is dropped ("reset step");
+ *  - inside such a chunk, token weights below 2^-126 (tokens whose true weight is < 2^-26 of the
+ *    chunk's last token's) are flushed to zero;
+ *  - x~ = w_s x_s is rounded to bf16 in a frame that depends on where the march started, so two
+ *    marches over the same tokens from different starting points (sequence segments, shards) agree
+ *    on y to a bf16 ulp and on the final state to 5e-3 relative, not to fp32; linearity in x holds
+ *    up to the last bit of a sum;
+ *  - sequence segments > 0 (the kernel cuts a long sequence into up to 16 segments marched
+ *    concurrently from a zero state) are completed by tv_ssd_state_correction's operator, with its
+ *    2^-32 cut-off (below).
  * --------------------------------------------------------------------- */
 size_t tv_ssd_scan_workspace_bytes(int batch, int seqlen, int nheads,
                                    int headdim, int ngroups, int dstate,
@@ -204,9 +217,13 @@ int tv_ssd_scan_cb_fwd(const void* x, const void* dt, const void* A,
  * tv_ssd_scan_fwd; once the state entering it is known its outputs are completed in place,
  *   y_t += exp(sum_{j<=t} dt_j A_h) * C_t . state_in[h]        (dt discretised as in tv_ssd_scan_fwd)
  * y (B,L,H,P) `dtype`, read-modify-write; dt (B,L,H) raw; Cm (B,L,G,N) with a group stride;
- * state_in (B,H,P,N) fp32 contiguous.  Past a head's decay horizon (factor < 2^-48: the term is
- * under 4e-15 of |C_t . state_in|, far below the fp32 rounding of the sum) the kernel stops, so the
- * cost is that horizon, not L.
+ * state_in (B,H,P,N) fp32 contiguous.  Past a head's decay horizon (factor < 2^-32: the term is
+ * under 2.4e-10 of |C_t . state_in| — two orders of magnitude below the fp32 rounding of the sum it
+ * would enter, seven below a bf16 ulp of y; csrc/ssd_correct.hip C_UNDERFLOW) the kernel stops at the
+ * next chunk boundary, so the cost is that horizon, not L.  The dropped part is bounded by
+ * 2^-32 |C_t . state_in| per element (tests/test_ops_gpu.py::test_ssd_state_correction_truncation_bound).
+ * state_in enters the MFMA as bf16 (one rounding of the carried state, 2^-9 relative, like the
+ * bf16 state operand of the scan's own Y_off product).
  * bf16, d_state 128, headdim % 8 == 0 (<= 128).  workspace:
  * tv_ssd_state_correction_workspace_bytes() bytes (per-chunk log-decays and their prefix). */
 size_t tv_ssd_state_correction_workspace_bytes(int batch, int seqlen, int nheads);
@@ -220,13 +237,15 @@ int tv_ssd_state_correction(void* y, const void* dt, const void* A, const void* 
                             float dt_min, float dt_max, int group_map,
                             void* workspace, size_t workspace_bytes, void* stream);
 
-/* Force a particular implementation (testing/benchmarking):
- * 0 = auto (the slice march where it applies and a workspace is given, else the
+/* Force a particular implementation (testing/benchmarking; process-global):
+ * 0 = auto (6 where it applies and a workspace is given, else 4 / 3, else the
  *     chunk march, else the generic kernel),
  * 1 = generic fp32 recurrence kernel (any dtype / shape),
  * 2 = MFMA chunk-march kernel (bf16, d_state 128; needs no workspace),
- * 3 = MFMA slice-march kernel (bf16, d_state 128; C.B^T pre-pass into `workspace`,
- *     tv_ssd_scan_workspace_bytes() bytes, 16-byte aligned). */
+ * 3 = MFMA slice-march kernel, two work-groups per head (bf16, d_state 128; C.B^T
+ *     pre-pass into `workspace`, tv_ssd_scan_workspace_bytes() bytes, 16-byte aligned),
+ * 4 / 5 = whole-head slice march (8 / 12 waves) x sequence segments,
+ * 6 = head-per-wave march (csrc/ssd_head.hip; head_dim 32 / 64 / 80). */
 void tv_ssd_scan_set_impl(int impl);
 
 /* Single-token decode step, replaces selective_state_update (:528-539) with
@@ -269,6 +288,9 @@ int tv_flash_attn_fwd(const void* q, const void* k, const void* v, void* o,
  * DESIGN.md §5 — and therefore not the default.  Results agree within the operator's tolerance.
  * Initial value: env TV_FA_W64. */
 void tv_flash_attn_set_variant(int variant);
+/* 1 when the library was built with -DTV_FA_VARIANTS (the two variants above are compiled in), 0 in the
+ * shipped build, where tv_flash_attn_set_variant() is accepted and has no effect. */
+int tv_flash_attn_variants_built(void);
 
 /* The same operator with the QK^T and PV products on the FP8 matrix path of CDNA4
  * (v_mfma_f32_32x32x64_f8f6f4, OCP e4m3 operands, fp32 accumulation, fp32 softmax): BASELINE

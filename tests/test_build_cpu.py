@@ -5,7 +5,7 @@ Several kernels issue global loads from inline asm that the compiler does not tr
 `s_waitcnt vmcnt(N)` (ssdk::gload16_async for the Q fragments of the attention kernels; the C.B^T and dt loads of the
 head-per-wave scan).  That is only sound while the compiler never saves or copies the destination registers between the
 load and the wait — i.e. while the kernel SPILLS NOTHING: a spilled register with a load in flight is stored before its
-data arrives and reloaded stale (this happened in the scan's complete kernel, which is why that one uses ordinary loads).
+data arrives and reloaded stale (this happened in round 3's spilling 'complete' scan kernel, since removed).
 So every kernel that uses the idiom must have zero scratch; a compiler upgrade or a source edit that introduces a spill
 fails here instead of producing silently wrong numbers on the GPU."""
 import re
@@ -61,14 +61,13 @@ def kernel_metadata(src_name: str, tmp_path: Path) -> dict:
 
 @needs_tools
 def test_head_scan_fast_kernels_spill_nothing(tmp_path):
-    """ssd_head_kernel<PT, 4, 2, false> (the kernels that run in the 9B model) carry untracked loads: zero scratch."""
+    """ssd_head_kernel<PT, 4, 2> (the kernels that run in the 9B model) carry untracked loads: zero scratch."""
     md = kernel_metadata("ssd_head.hip", tmp_path)
-    fast4 = {k: v for k, v in md.items() if re.search(r"ssd_head_kernelILi\dELi4ELi2ELb0E", k)}
+    fast4 = {k: v for k, v in md.items() if re.search(r"ssd_head_kernelILi\dELi4ELi2E", k)}
     assert len(fast4) >= 3, list(md)
     for k, v in fast4.items():
         assert v.get("private_segment_fixed_size") == 0 and v.get("vgpr_spill_count", 0) == 0, (k, v)
-    # (other variants — fewer waves per work-group, the complete kernel of a -DTV_HEAD_UNISTD=0 build — may spill: they use
-    # ordinary loads)
+    # (the variants with fewer waves per work-group may spill: they use ordinary loads)
 
 
 @needs_tools

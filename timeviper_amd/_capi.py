@@ -42,6 +42,7 @@ SIGNATURES = {
     "tv_selective_state_update": (_i, [_p] * 9 + [_i] * 7 + [_p]),
     "tv_flash_attn_fwd": (_i, [_p] * 5 + [_i] * 6 + [_l] * 12 + [_f, _i, _i, _p]),
     "tv_flash_attn_set_variant": (None, [_i]),
+    "tv_flash_attn_variants_built": (_i, []),
     "tv_flash_attn_fp8_workspace_bytes": (_z, [_i] * 5),
     "tv_flash_attn_fp8_fwd": (_i, [_p] * 5 + [_i] * 6 + [_l] * 12 + [_f, _i, _i, _p, _z, _p]),
     "tv_attn_rank_workspace_bytes": (_z, [_i, _i]),

@@ -31,6 +31,8 @@ if os.environ.get("TV_MARCH_ABLATE"):   # dev only: compile the scan kernel's ab
     FLAGS.append("-DTV_MARCH_ABLATE")
 if os.environ.get("TV_FA_STAMP"):       # dev only: per-phase stamps in the streaming attention kernel
     FLAGS.append("-DTV_FA_STAMP")
+if os.environ.get("TV_FA_VARIANTS"):    # dev only: the two measured-slower ViT attention kernels (attention_variants.hpp)
+    FLAGS.append("-DTV_FA_VARIANTS")
 if os.environ.get("TV_SLICE_STAMP"):    # dev only: per-wave barrier-wait stamps in ssd_slice.hip
     FLAGS.append("-DTV_SLICE_STAMP")
 

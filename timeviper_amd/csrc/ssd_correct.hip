@@ -44,10 +44,6 @@ struct CorrArgs {
   // chunks [(si + first_seg) * seg_chunks, + seg_chunks) of the sequence, its entering state at state[si][b][h];
   // the stand-alone operator has one range = the whole sequence (nsegc 1, first_seg 0, seg_chunks = nchunks)
   int nsegc, first_seg, seg_chunks;
-  // optional gate: the kernels of this file return at once unless (*gate != 0) == gate_run_if (NULL: always run) —
-  // tv_ssd_scan_fwd launches two complete kernel sequences behind a device-side check and lets one of them run
-  const int* gate;
-  int gate_run_if;
   int64_t tot_stride;              // elements between the (b, h) rows of `tot`
   int64_t ysb, ysl, dsb, dsl, csb, csl, csg;
   int softplus, group_map;
@@ -62,10 +58,7 @@ __device__ __forceinline__ float disc_dt(const CorrArgs& a, float raw, int h) {
 
 // grid (nchunks, ceil(H / 4), B), 4 waves: wave = head, lane = token of the chunk
 // tot[b][h][c] = log2(e) * sum_{t in chunk} dt_t A_h
-__device__ __forceinline__ bool gated_off(const int* gate, int run_if) { return gate && (*gate != 0) != (run_if != 0); }
-
 __global__ __launch_bounds__(256) void ssd_chunk_decay_kernel(CorrArgs a) {
-  if (gated_off(a.gate, a.gate_run_if)) return;
   const int c = blockIdx.x, b = blockIdx.z;
   const int h = blockIdx.y * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (h >= a.H) return;
@@ -77,7 +70,6 @@ __global__ __launch_bounds__(256) void ssd_chunk_decay_kernel(CorrArgs a) {
 
 // grid (H, B * nsegc), one wave: pre[b][h][c] = sum_{first chunk of c's range <= c' < c} tot[b][h][c']
 __global__ __launch_bounds__(64) void ssd_decay_prefix_kernel(CorrArgs a) {
-  if (gated_off(a.gate, a.gate_run_if)) return;
   const int h = blockIdx.x, b = blockIdx.y / a.nsegc, si = blockIdx.y % a.nsegc, lane = threadIdx.x;
   const int cbeg = (si + a.first_seg) * a.seg_chunks;
   const int nch = min(a.seg_chunks, a.nchunks - cbeg);
@@ -99,7 +91,6 @@ __global__ __launch_bounds__(256) void ssd_correct_kernel(CorrArgs a) {
   constexpr int LDW = PT * 16 + 4;                  // padded fp32 row of the staging tile
   __shared__ float ef[CQ];
   __shared__ __attribute__((aligned(16))) float tile[CQ * LDW];
-  if (gated_off(a.gate, a.gate_run_if)) return;
   const int h = blockIdx.y, b = blockIdx.z / a.nsegc, si = blockIdx.z % a.nsegc;
   const int nslots = gridDim.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -221,8 +212,7 @@ __global__ __launch_bounds__(256) void ssd_seg_chain_kernel(const float* __restr
                                                             const float* __restrict__ seg_decay,
                                                             bf16_t* __restrict__ sin16, float* __restrict__ final_state,
                                                             float* __restrict__ total_decay, int nseg,
-                                                            int64_t bh, int64_t per_head, const int* gate, int gate_run_if) {
-  if (gated_off(gate, gate_run_if)) return;
+                                                            int64_t bh, int64_t per_head) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;      // float4 index
   const int64_t n4 = bh * per_head / 4;
   if (i < n4) {
@@ -278,9 +268,8 @@ int tv_ssd_correct_launch(void* y, const void* dt, const void* A, const void* Cm
                           int ngroups, int64_t ysb, int64_t ysl, int64_t dsb, int64_t dsl, int64_t csb,
                           int64_t csl, int64_t csg, int dt_softplus, float dt_min, float dt_max,
                           int group_map, void* workspace, const float* chunk_tot, int64_t chunk_tot_stride,
-                          hipStream_t st, const int* gate, int gate_run_if) {
+                          hipStream_t st) {
   CorrArgs a;
-  a.gate = gate; a.gate_run_if = gate_run_if;
   a.y = (bf16_t*)y; a.dt = (const bf16_t*)dt; a.Cm = (const bf16_t*)Cm;
   a.A = (const float*)A; a.dt_bias = (const float*)dt_bias; a.state = (const float*)state_in;
   a.L = seqlen; a.H = nheads; a.P = headdim; a.G = ngroups;
@@ -317,10 +306,8 @@ int tv_ssd_correct_all_launch(void* y, const void* dt, const void* A, const void
                               float* total_decay, const float* chunk_tot, int batch, int seqlen, int nheads,
                               int headdim, int ngroups, int nseg, int seg_chunks, int64_t ysb, int64_t ysl,
                               int64_t dsb, int64_t dsl, int64_t csb, int64_t csl, int64_t csg, int dt_softplus,
-                              float dt_min, float dt_max, int group_map, void* workspace, hipStream_t st,
-                              const int* gate, int gate_run_if) {
+                              float dt_min, float dt_max, int group_map, void* workspace, hipStream_t st) {
   CorrArgs a;
-  a.gate = gate; a.gate_run_if = gate_run_if;
   a.y = (bf16_t*)y; a.dt = (const bf16_t*)dt; a.Cm = (const bf16_t*)Cm;
   a.A = (const float*)A; a.dt_bias = (const float*)dt_bias; a.state = nullptr;
   a.L = seqlen; a.H = nheads; a.P = headdim; a.G = ngroups;
@@ -338,7 +325,7 @@ int tv_ssd_correct_all_launch(void* y, const void* dt, const void* A, const void
   const int64_t bh = (int64_t)batch * nheads, per_head = (int64_t)headdim * CN;
   const int64_t n4 = bh * per_head / 4;
   ssd_seg_chain_kernel<<<dim3((unsigned)((n4 + 255) / 256)), 256, 0, st>>>(seg_state, seg_decay, sin16, final_state,
-                                                                         total_decay, nseg, bh, per_head, gate, gate_run_if);
+                                                                         total_decay, nseg, bh, per_head);
   if (nsegc > 0) {
     ssd_decay_prefix_kernel<<<dim3(nheads, batch * nsegc), 64, 0, st>>>(a);
     // work-groups per (head, boundary): every one of them loads the 20 KB of S_in, most leave at once (the carried-in
@@ -382,5 +369,5 @@ extern "C" int tv_ssd_state_correction(void* y, const void* dt, const void* A, c
   return tv_ssd_correct_launch(y, dt, A, Cm, dt_bias, state_in, batch, seqlen, nheads, headdim, ngroups,
                                y_stride_b, y_stride_l, dt_stride_b, dt_stride_l, c_stride_b, c_stride_l,
                                c_stride_g, dt_softplus, dt_min, dt_max, group_map, workspace, nullptr, 0,
-                               (hipStream_t)stream, nullptr, 0);
+                               (hipStream_t)stream);
 }

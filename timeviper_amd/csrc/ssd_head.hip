@@ -47,8 +47,7 @@ int tv_ssd_correct_all_launch(void* y, const void* dt, const void* A, const void
                               float* total_decay, const float* chunk_tot, int batch, int seqlen, int nheads,
                               int headdim, int ngroups, int nseg, int seg_chunks, int64_t ysb, int64_t ysl,
                               int64_t dsb, int64_t dsl, int64_t csb, int64_t csl, int64_t csg, int dt_softplus,
-                              float dt_min, float dt_max, int group_map, void* workspace, hipStream_t st,
-                              const int* gate, int gate_run_if);
+                              float dt_min, float dt_max, int group_map, void* workspace, hipStream_t st);
 
 #ifndef TV_HEAD_PIN
 #define TV_HEAD_PIN 0
@@ -63,9 +62,10 @@ int tv_ssd_correct_all_launch(void* y, const void* dt, const void* A, const void
 #ifndef TV_HEAD_RESET
 #define TV_HEAD_RESET 1
 #endif
-// TV_HEAD_UNISTD: 1 = the fast kernel takes standard steps itself, as three side blocks of the one step body (scaled
-// accumulators, per-head mask built into the C.B^T registers, raw x fragments) — no complete kernel, no check;
-// 0 = round 3's first scheme (flag + complete kernel, or the device-side check of the automatic mode)
+// Standard steps (a chunk that decays by more than 2^(2 RMAX)) are taken by the one kernel itself, as three side blocks of
+// the one step body (scaled accumulators, per-head mask built into the C.B^T registers, raw x fragments).  Round 3's first
+// scheme — a flag per work-group + a second, complete kernel, or a device-side check that sent such calls to the slice
+// march — was measured (7.5 ms / 2.92 ms against 2.50 ms at 164 k tokens) and removed in round 4.
 // TV_HEAD_UNTRACKED: 1 = the C.B^T / dt loads of the 4-wave fast kernels are inline asm with counted waits (needs a
 // kernel without scratch), 0 = ordinary loads
 #ifndef TV_HEAD_UNTRACKED
@@ -84,9 +84,6 @@ int tv_ssd_correct_all_launch(void* y, const void* dt, const void* A, const void
 #ifndef TV_HEAD_FENCE
 #define TV_HEAD_FENCE 1
 #endif
-#ifndef TV_HEAD_UNISTD
-#define TV_HEAD_UNISTD 1
-#endif
 namespace {
 using namespace ssdk;
 
@@ -103,9 +100,6 @@ struct HeadArgs {
   bf16_t* y;
   float *final_state, *total_decay;
   float *seg_state, *seg_decay, *chunk_tot;     // nseg > 1: per-segment results for the combine / correction pass
-  int* redo;                                    // per work-group: 1 = the complete kernel has to march this work-group again
-  const int* gate;                              // optional: the kernel returns at once unless (*gate != 0) == gate_run_if
-  int gate_run_if;
   int nseg, seg_chunks;
   int L, H, P, G, nchunks;
   int64_t xsb, xsl, dsb, dsl, bsb, bsl, bsg, csb, csl, csg, ysb, ysl;
@@ -171,20 +165,14 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4v;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
-// RARE = false: the fast kernel — floating steps (and re-basing) only.  A wave that meets a chunk it cannot march that way
-// (mode 2: one chunk decays by more than 2^(2 RMAX - 1), dt |A| > 2.1 per token) raises its work-group's flag in `redo`
-// and carries on with numbers that no longer mean anything.  RARE = true: the complete kernel, standard steps included
-// (their code costs ~200 spilled registers in the whole loop: that is why it is a kernel of its own); it is launched
-// behind the fast one and its work-groups return at once unless their flag is up, in which case they march their
-// heads again from the start and overwrite what the fast kernel left.
-template <int PT, int NW, int NB, bool RARE>
+template <int PT, int NW, int NB>
 __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
   typedef HeadSmem<PT, NW, NB> Smem;
   // Loads the compiler does not track (inline asm + counted waits) are only safe in a kernel that spills NOTHING: a
-  // register with such a load in flight may otherwise be saved before its data has arrived (seen: the complete kernel
-  // read stale C.B^T fragments that way).  Only the 4-wave fast kernels are held to zero scratch
-  // (tests/test_build_cpu.py reads it off the code object); every other variant uses ordinary loads and full waits.
-  constexpr bool UNTRACKED = TV_HEAD_UNTRACKED && !RARE && NW == 4;
+  // register with such a load in flight may otherwise be saved before its data has arrived (seen: a spilling variant
+  // read stale C.B^T fragments that way).  Only the 4-wave kernels are held to zero scratch
+  // (tests/test_build_cpu.py reads it off the code object); the 2- and 1-wave variants use ordinary loads and full waits.
+  constexpr bool UNTRACKED = TV_HEAD_UNTRACKED && NW == 4;
   constexpr int BD = NB - 1;            // B/C prefetch distance (chunks)
   static_assert(BD == 1, "the waits below are counted for a B/C ring of 2");
   constexpr int P = PT * 16;
@@ -204,9 +192,6 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
   const int t_first = c_first * HQ;
   const int nchunks = min(a.seg_chunks, a.nchunks - c_first);
   const int L = min(a.L - t_first, nchunks * HQ);
-  if (a.gate && (*a.gate != 0) != (a.gate_run_if != 0)) return;
-  int* const redo = a.redo + ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-  if (RARE && *redo == 0) return;
   HeadVec& vec = sm.v[wave];
   // LDS byte addresses are formed from ONE cast of the array base (every generic -> LDS cast carries a null check; a
   // dozen of them under scalar-register pressure made the backend emit an illegal VALU compare with src_shared_base)
@@ -355,7 +340,8 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
   //   0  floating step in the current frame (f = 1);
   //   1  floating step after the frame has been re-based to E ~ +RMAX: the caller multiplies the state by 2^f (f = -m, an
   //      integer) first;
-  //   2  standard step (one chunk decays by more than 2^(2 RMAX)): X' *= f = 2^(E + cs_Q) inside the step, true mask.
+  //   2  standard step (one chunk decays by more than 2^(2 RMAX)): the old state is dropped (always a reset step), true mask;
+  //      reported to the caller as 0 (nothing to do to the state), `std_next` carries it.
   bool reset_next = false, reset_cur = false, std_next = false, std_cur = false;     // (wave-uniform)
   auto prep = [&](int c, unsigned raw_bits, float& f_out) __attribute__((always_inline)) {
     const int t = c * HQ + lane;
@@ -368,21 +354,16 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
     const float cs = wave_incl_scan_dpp(d * Ah);
     const float cl = rdlane(cs, 63);
     const float cs2 = cs * 1.4426950408889634f, cl2 = cl * 1.4426950408889634f;
-    int mode = -(E + cl2) <= RMAX ? 0 : -cl2 <= 2.f * RMAX - 1.f ? 1 : 2;
-    if (!RARE && !TV_HEAD_UNISTD && mode == 2) {          // not this kernel's business: flag the work-group, go on with a re-basing step
-      if (lane == 0) *redo = 1;
-      mode = 1;
-    }
+    const int mode = -(E + cl2) <= RMAX ? 0 : -cl2 <= 2.f * RMAX - 1.f ? 1 : 2;
     // mode 1: X' *= 2^-m with the integer m = floor(RMAX - E) (v_ldexp_f32: exact, no underflow on the way), E += m
     const float mshift = mode == 1 ? __builtin_floorf(RMAX - E) : 0.f;
     const float Euse = E + mshift;                           // frame in which this chunk reads the state
-    // (mode 2: the factor is handed over as its square root, scale_tile multiplies twice: 2^(E + cs_Q) may underflow)
-    f_out = mode == 1 ? -mshift : mode == 2 ? __builtin_amdgcn_exp2f(0.5f * (E + cl2)) : 1.f;
+    f_out = mode == 1 ? -mshift : 1.f;         // (mode 2 drops the old state: nothing to scale)
     vec.cs[lane] = cs2;
     vec.dtv[lane] = d;
     vec.ecs[lane] = __builtin_amdgcn_exp2f(cs2 + Euse);
     const bool rst = TV_HEAD_RESET && mode != 2 && cl2 <= -RESET_THR;
-    const bool ustd = !RARE && TV_HEAD_UNISTD && mode == 2;     // standard step inside the fast kernel: always a reset step
+    const bool ustd = mode == 2;                                // standard step: always a reset step
     reset_next = rst || ustd;
     std_next = ustd;
     vec.wts[lane] = __builtin_amdgcn_exp2f(mode == 2 ? cl2 - cs2 : rst ? cl2 - cs2 - RMAX : -cs2 - Euse) * d;
@@ -452,19 +433,6 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
       }
     asm volatile("s_nop 7" ::: "memory");
   };
-  // X'[tile] = (X'[tile] f) f (re-basing of the frame, standard steps): out of and back into the accumulation registers
-  // by hand — a vector-ALU use of the state that the compiler can see costs spills in the whole kernel (see above).  The
-  // factor comes as its square root: 2^(E - RMAX) itself may underflow.  Vector-ALU results are interlocked in hardware;
-  // the caller pads the last write against the next MFMA.
-  auto scale_tile = [&](f32x4& t, float f) {
-    float e0 = t[0], e1 = t[1], e2 = t[2], e3 = t[3], t0, t1, t2, t3;
-    asm volatile("v_accvgpr_read_b32 %4, %0\n\tv_accvgpr_read_b32 %5, %1\n\tv_accvgpr_read_b32 %6, %2\n\tv_accvgpr_read_b32 %7, %3\n\t"
-                 "v_mul_f32 %4, %8, %4\n\tv_mul_f32 %5, %8, %5\n\tv_mul_f32 %6, %8, %6\n\tv_mul_f32 %7, %8, %7\n\t"
-                 "v_mul_f32 %4, %8, %4\n\tv_mul_f32 %5, %8, %5\n\tv_mul_f32 %6, %8, %6\n\tv_mul_f32 %7, %8, %7\n\t"
-                 "v_accvgpr_write_b32 %0, %4\n\tv_accvgpr_write_b32 %1, %5\n\tv_accvgpr_write_b32 %2, %6\n\tv_accvgpr_write_b32 %3, %7"
-                 : "+a"(e0), "+a"(e1), "+a"(e2), "+a"(e3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3) : "v"(f));
-    t = f32x4{e0, e1, e2, e3};
-  };
   // State tiles 2m / 2m+1 hold the state rows n = 32m + 8kq + r / + 4 + r (r = accumulator register), so the pair is,
   // as an MFMA operand, the k slots n = 32m + 8kq + 0..7 — the order of a plain 16-byte row read of C.
   const int c_lo = lc * 256;
@@ -506,20 +474,19 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
   dt_next = load_dt(min(1, nchunks - 1));
   HEAD_BARRIER(0);
 
-  // One 64-token step.  STD = false: floating frame, the common case — the chunk's decay sits in the weights
+  // One 64-token step.  Floating frame, the common case — the chunk's decay sits in the weights
   // (w_s = 2^(-cs_s - E) dt_s) and in ONE row factor 2^(cs_t + E) applied at the very end, so Yoff and Ydiag accumulate
   // into the same tiles with no vector instruction in between, the mask is the causal C.B^T itself (the same for every
   // head of the group, taken from global memory as it is) and x~ serves the state update and Ydiag alike:
   //     y_t = 2^(cs_t + E) ( C_t . X' + sum_{s <= t} CB[t][s] x~_s ) + D x_t
-  // STD = true: a chunk that decays by more than 2^(2 RMAX) keeps round 2's form (true mask, X' *= f mid-step).
+  // A chunk that decays by more than 2^(2 RMAX) takes the true-mask form through three side blocks (`ustd_step`).
   // The step's memory operations are issued in small groups BETWEEN the MFMAs of the first three quarters (issued in a
   // burst they stalled the wave for ~5 000 cycles per step at the full queue of the copy path, the y stores for
   // another ~4 900): quarter 0: the y rows of the previous chunk, from the tile the x copies of the next chunk then
   // reuse; quarter 1: C.B^T of this chunk, x of the next; quarter 2: B / C of the next chunk, dt of the one after.
-  auto step = [&](int c, bool more, auto STDT) __attribute__((always_inline)) {
-    constexpr bool STD = decltype(STDT)::value;
+  auto step = [&](int c, bool more) __attribute__((always_inline)) {
     const bool reset_step = reset_cur;       // this chunk builds its state anew (its own value: prep below sets the next chunk's)
-    const bool ustd_step = !STD && TV_HEAD_UNISTD && std_cur;     // ... and is a standard step done by this (the one) step body
+    const bool ustd_step = std_cur;          // ... and is a standard step (side blocks below)
     const unsigned char* Bt = reinterpret_cast<const unsigned char*>(sm.bt[c % NB]);
     const unsigned char* Ct = reinterpret_cast<const unsigned char*>(sm.ct[c % NB]);
     const unsigned xt = lds_xr + (c & 1) * XSLOT;
@@ -562,14 +529,6 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
     bf16x4 bq[2][2][4];
     bf16x8 sbq[2][PT];
     bf16x8 cbv[NFR];                // causal C.B^T of this chunk (L2 / L1: every head of the group reads the same 6 KiB)
-    auto rescale = [&](int q) {     // standard step: X' *= 2^(E + cs_Q) (after the copy of these rows was taken)
-      if (!STD) return;
-#pragma unroll
-      for (int ct = 0; ct < PT; ++ct)
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii) scale_tile(xacc[ct][2 * q + ii], f_step);
-      asm volatile("s_nop 7" ::: "memory");
-    };
     auto quarter = [&](int q, const bf16x8 (&cf)[4], const bf16x4 (&bt2)[2][4], const bf16x8 (&sb)[PT], bf16x8 (&sbn)[PT],
                        auto filler, bool fence = true) {
 #pragma unroll
@@ -580,7 +539,7 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
         } else {
           const int ks = (j - 4) >> 1, ii = (j - 4) & 1;
           const bf16x8 bfrag = cat4(bt2[ii][2 * ks], bt2[ii][2 * ks + 1]);
-          if (TV_HEAD_RESET && !STD && ks == 0 && reset_step) {
+          if (TV_HEAD_RESET && ks == 0 && reset_step) {
 #pragma unroll
             for (int ct = 0; ct < PT; ++ct) xacc[ct][2 * q + ii] = mfma16(bfrag, xw[ct][0], f32x4{0.f, 0.f, 0.f, 0.f});
           } else {
@@ -608,14 +567,12 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
     read_b2(Bt, 0, bq[0]);
 #pragma unroll
     for (int ct = 0; ct < PT; ++ct) sbq[0][ct] = snap_tile(0, ct);
-    rescale(0);
     __builtin_amdgcn_sched_barrier(0);
     read_cq(Ct, 1, cq[1]);
     read_b2(Bt, 2, bq[1]);
     quarter(0, cq[0], bq[0], sbq[0], sbq[1], [&](int j) {           // B of the next chunk (late: the y stores of the last step drain first)
       if (more && j == 4 && !HDBG(a, 64)) issue_bc(c + 1, 0);
     });
-    rescale(1);
     HSTAMP(2);
     read_cq(Ct, 2, cq[0]);
     read_b2(Bt, 4, bq[0]);
@@ -624,13 +581,12 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
       if (more && j == 0 && !HDBG(a, 64)) issue_bc(c + 1, 1);
       if (more && j == 4 && NXG > 0 && !HDBG(a, 32)) issue_x(c + 1, 0);
     });
-    rescale(2);
     HSTAMP(3);
     read_cq(Ct, 3, cq[1]);
     read_b2(Bt, 6, bq[1]);
     quarter(2, cq[0], bq[0], sbq[0], sbq[1], [&](int j) {           // the rest of x, dt of the chunk after the next
       if (more && j == 0 && NXG > 1 && !HDBG(a, 32)) issue_x(c + 1, 1);
-      if (j == TV_HEAD_CBJ && !STD && !HDBG(a, 8)) {       // C.B^T of this chunk (behind the last x copies: only dt is issued after it)
+      if (j == TV_HEAD_CBJ && !HDBG(a, 8)) {       // C.B^T of this chunk (behind the last x copies: only dt is issued after it)
 #pragma unroll
         for (int f = 0; f < NFR; ++f) {
           u32x4v r;
@@ -642,7 +598,6 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
       if (more && j == 4 && NXG > 2 && !HDBG(a, 32)) issue_x(c + 1, 2);
       if (j == 6) dt_next = load_dt(min(c + 2, nchunks - 1));
     });
-    rescale(3);
     HSTAMP(4);
     float ev[4];                    // 2^(cs_t + E) of this lane's token 16 ti + lc
 #pragma unroll
@@ -650,13 +605,13 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
     // floating steps: the vectors of the NEXT chunk are prepared here, in one scheduling region with the MFMAs of the last
     // quarter (everything that reads this chunk's vectors has been read; the re-basing of the frame waits for the quarter)
     int mode_next = 0;
-    if (!STD && !ustd_step && c + 1 < nchunks) {
+    if (!ustd_step && c + 1 < nchunks) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       mode_next = prep(c + 1, dt_raw, f_step);
     }
     quarter(3, cq[1], bq[1], sbq[1], sbq[0], [&](int) {}, false);
     HSTAMP(5);
-    if (TV_HEAD_RESET && !STD && reset_step && !ustd_step) {
+    if (TV_HEAD_RESET && reset_step && !ustd_step) {
       // the state update ran on x~ in the NEW frame; Ydiag shares the accumulators with Yoff and needs the old frame's
       asm volatile("; reset step: x~ for Ydiag" ::);
       f32x4 wq[2][2];
@@ -684,10 +639,8 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
     // C.B^T has landed; what was issued behind it (the last x copies, dt) may stay in flight
     if (UNTRACKED && more && (c + 2) * HQ <= L) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TV_HEAD_CBJ >= 4 ? 1 : (NXG > 2 ? NXI - 8 : 0) + 1) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (!STD) {
 #pragma unroll
-      for (int f = 0; f < NFR; ++f) asm volatile("" : "+v"(cbv[f]));
-    }
+    for (int f = 0; f < NFR; ++f) asm volatile("" : "+v"(cbv[f]));
     HSTAMP(6);
     if (ustd_step) {
       // ---- standard step inside the one step body (a chunk that decays by more than 2^-199: no single frame holds its
@@ -779,7 +732,7 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
         mode_next = prep(c + 1, dt_raw, f_step);
       }
     }
-    if constexpr (!STD) {
+    {
       // ---- Ydiag on top of Yoff, same frame: the A operand is x~, the B operand the causal C.B^T fragment
 #pragma unroll
       for (int ti = 0; ti < 4; ++ti)
@@ -789,78 +742,11 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
       for (int ti = 2; ti < 4; ++ti)
 #pragma unroll
         for (int ct = 0; ct < PT; ++ct) yo[ct][ti] = mfma16(xw[ct][1], cbv[ti == 2 ? 3 : 5], yo[ct][ti]);
-    } else {
-      // ---- standard step (rare; written for few registers, not for speed): the accumulators get their row factor now,
-      // then the decay mask of this head, M = CB .* 2^(cs_t - cs_s) dt_s [s <= t], is built ONE fragment (lane (lc = t
-      // within the tile, kq) x 8 consecutive s) at a time and used at once with freshly read raw x fragments.  Diagonal
-      // 16x16 blocks take one exponential per element (by lane half: fragments (0,0) / (1,0) and (2,1) / (3,1)), the
-      // other blocks are separable around the first token of their t-tile, ut[t] ws[s].
-#pragma unroll
-      for (int ct = 0; ct < PT; ++ct)
-#pragma unroll
-        for (int ti = 0; ti < 4; ++ti) scale_tile(yo[ct][ti], __builtin_sqrtf(ev[ti]));      // (scale_tile squares its factor)
-      const int hi = kq >> 1;
-      auto diag = [&](int t, int s0, float (&e)[8]) {       // e[j] = 2^(cs_t - cs_(s0 + j)) dt_(s0 + j) for s0 + j <= t, else 0
-        const float cst = vec.cs[t];
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-          const f32x4 cv = *(const f32x4*)(&vec.cs[s0 + 4 * hh]), dv = *(const f32x4*)(&vec.dtv[s0 + 4 * hh]);
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            e[4 * hh + j] = __builtin_amdgcn_exp2f(s0 + 4 * hh + j <= t ? cst - cv[j] : -__builtin_inff()) * dv[j];
-        }
-      };
-      auto sepf = [&](int t, int wofs, float (&e)[8]) {      // e[j] = ut[t] ws[wofs + j]
-        const float u = vec.ut[t];
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-          const f32x4 wv = *(const f32x4*)(&vec.ws[wofs + 4 * hh]);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) e[4 * hh + j] = u * wv[j];
-        }
-      };
-      auto use_frag = [&](int f, const float (&fac)[8]) {    // Ydiag += x^T (CB_f .* fac) for every column tile
-        const u32x4v cw = __builtin_bit_cast(u32x4v, *(const bf16x8*)(cbg + (int64_t)c * CBE + f * 512));
-        bf16x8 mf;
-#pragma unroll
-        for (int jp = 0; jp < 4; ++jp) {
-          mf[2 * jp] = (bf16_t)(bf16_lo(cw[jp]) * fac[2 * jp]);
-          mf[2 * jp + 1] = (bf16_t)(bf16_hi(cw[jp]) * fac[2 * jp + 1]);
-        }
-        const int ti = f == 0 ? 0 : f == 1 ? 1 : f < 4 ? 2 : 3, sp = (f == 3 || f == 5) ? 1 : 0;
-#pragma unroll
-        for (int ct = 0; ct < PT; ++ct) yo[ct][ti] = mfma16(read_xf(xt, ct, sp), mf, yo[ct][ti]);
-      };
-      float eD[8], eS[8], fac[8];
-      const int sA = 8 * kq;
-      diag(16 * hi + lc, sA, eD);                           // diagonal blocks of fragments (0,0) [hi = 0] and (1,0) [hi = 1]
-#pragma unroll
-      for (int j = 0; j < 8; ++j) fac[j] = hi ? 0.f : eD[j];
-      use_frag(0, fac);
-      sepf(16 + lc, sA & 15, eS);                           // block (1,0)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) fac[j] = hi ? eD[j] : eS[j];
-      use_frag(1, fac);
-      sepf(32 + lc, 16 + sA, eS);                           // blocks (2,0), (2,1)
-      use_frag(2, eS);
-      diag(32 + 16 * hi + lc, 32 + sA, eD);                 // diagonal blocks of fragments (2,1) [hi = 0] and (3,1) [hi = 1]
-#pragma unroll
-      for (int j = 0; j < 8; ++j) fac[j] = hi ? 0.f : eD[j];
-      use_frag(3, fac);
-      sepf(48 + lc, 48 + sA, eS);                           // blocks (3,0), (3,1)
-      use_frag(4, eS);
-      sepf(48 + lc, 48 + 32 + (sA & 15), eS);               // block (3,2)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) fac[j] = hi ? eD[j] : eS[j];
-      use_frag(5, fac);
-#pragma unroll
-      for (int ti = 0; ti < 4; ++ti) ev[ti] = 1.f;
     }
     HSTAMP(7);
     // ---- vectors of the next chunk (every read of this chunk's is done; ev is in registers) and the re-basing of the
     // frame where it is due
     if (c + 1 < nchunks) {
-      if (STD) mode_next = prep(c + 1, dt_raw, f_step);
       mode = mode_next;
       reset_cur = __builtin_amdgcn_readfirstlane((int)reset_next) != 0;
       std_cur = __builtin_amdgcn_readfirstlane((int)std_next) != 0;
@@ -920,12 +806,7 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
   for (int c = 0; c < nchunks; ++c) {
     const bool more = c + 1 < nchunks;
     HSTAMP(0);
-    if constexpr (RARE) {
-      if (__builtin_expect(mode == 2, 0)) step(c, more, std::true_type{});
-      else step(c, more, std::false_type{});
-    } else {
-      step(c, more, std::false_type{});
-    }
+    step(c, more);
     HSTAMP(9);
     // (the copies of the next chunk landed before the C.B^T wait; this step's y stores stay in flight)
     if (UNTRACKED && (c + 1) * HQ <= L) HEAD_BARRIER(TV_HEAD_Y16 ? 2 * PT : 4 * PT);
@@ -958,38 +839,6 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
   }
 }
 
-// Does any chunk of this call need a standard step (decay of more than 2^(2 RMAX - 1) inside one chunk)?  tv_ssd_scan_fwd (automatic mode) launches the
-// head-per-wave kernels and the slice-march kernels behind this check and lets the sequence that fits the data run: the
-// fast head kernel cannot take such chunks, its complete variant takes them at a third of the slice march's speed.
-struct StdCheckArgs {
-  const bf16_t* dt;
-  const float *A, *dt_bias;
-  int* flag;
-  int L, H;
-  int64_t dsb, dsl;
-  int softplus;
-  float dt_min, dt_max;
-};
-__global__ __launch_bounds__(128) void ssd_std_check_kernel(StdCheckArgs a) {
-  // grid (nchunks, ceil(H / 128), B): thread = head (the heads of a token are contiguous: every load of a wave is one
-  // 128-byte line; with lane = token the 2-byte loads were 64 lines apart and the check took 91 us for 42 MB)
-  const int c = blockIdx.x, b = blockIdx.z, h = blockIdx.y * 128 + threadIdx.x;
-  if (h >= a.H) return;
-  const float bias = a.dt_bias ? a.dt_bias[h] : 0.f;
-  const int t0 = c * HQ, n = min(HQ, a.L - t0);
-  const bf16_t* p = a.dt + (int64_t)b * a.dsb + (int64_t)t0 * a.dsl + h;
-  float sum = 0.f;
-#pragma unroll 8
-  for (int t = 0; t < n; ++t) {
-    float d = (float)p[(int64_t)t * a.dsl] + bias;
-    if (a.softplus) d = softplus_fast(d);
-    sum += fminf(fmaxf(d, a.dt_min), a.dt_max);
-  }
-  const float cl2 = sum * a.A[h] * 1.4426950408889634f;
-  // (a margin of 2 against the march's own sum, which adds in another order)
-  if (-cl2 > 2.f * RMAX - 3.f) *a.flag = 1;
-}
-
 // heads of one group per work-group: 4, 2 or 1
 int pick_nw(int hpg) { return hpg % 4 == 0 ? 4 : hpg % 2 == 0 ? 2 : 1; }
 
@@ -1004,7 +853,7 @@ int pick_segments(int batch, int nheads, int nchunks) {
 }
 
 struct HeadLayout {
-  size_t cb, seg_state, seg_decay, ctot, corr, redo, total;
+  size_t cb, seg_state, seg_decay, ctot, corr, total;
   int nseg, seg_chunks;
 };
 HeadLayout head_layout(int batch, int seqlen, int nheads, int headdim, int ngroups) {
@@ -1019,8 +868,7 @@ HeadLayout head_layout(int batch, int seqlen, int nheads, int headdim, int ngrou
   l.seg_decay = l.seg_state + (l.nseg > 1 ? up(l.nseg * st) : 0);
   l.ctot = l.seg_decay + (l.nseg > 1 ? up((size_t)l.nseg * batch * nheads * sizeof(float)) : 0);
   l.corr = l.ctot + (l.nseg > 1 ? up((size_t)batch * nheads * nchunks * sizeof(float)) : 0);
-  l.redo = l.corr + (l.nseg > 1 ? up(tv_ssd_correct_all_workspace_bytes(batch, nheads, (int)nchunks, l.nseg, headdim)) : 0);
-  l.total = l.redo + up((size_t)batch * nheads * l.nseg * sizeof(int));       // (one flag per work-group: at most one per head and segment)
+  l.total = l.corr + (l.nseg > 1 ? up(tv_ssd_correct_all_workspace_bytes(batch, nheads, (int)nchunks, l.nseg, headdim)) : 0);
   return l;
 }
 
@@ -1029,24 +877,10 @@ hipError_t launch_head(const HeadArgs& a, dim3 grid, hipStream_t st) {
   constexpr int NB = 2;
   typedef HeadSmem<PT, NW, NB> Smem;
   static_assert(sizeof(Smem) <= 160 * 1024, "LDS budget");
-  hipError_t e = hipFuncSetAttribute((const void*)ssd_head_kernel<PT, NW, NB, false>,
+  hipError_t e = hipFuncSetAttribute((const void*)ssd_head_kernel<PT, NW, NB>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem));
   if (e != hipSuccess) return e;
-#if TV_HEAD_UNISTD
-  // one kernel takes every chunk (standard steps included): no flags, no second launch
-  ssd_head_kernel<PT, NW, NB, false><<<grid, NW * 64, sizeof(Smem), st>>>(a);
-#else
-  e = hipFuncSetAttribute((const void*)ssd_head_kernel<PT, NW, NB, true>,
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Smem));
-  if (e != hipSuccess) return e;
-  const bool only_rare = getenv("TV_HEAD_ONLY_RARE") != nullptr;      // dev tool: the complete kernel for every work-group
-  e = hipMemsetAsync(a.redo, only_rare ? 1 : 0, sizeof(int) * grid.x * grid.y * grid.z, st);
-  if (e != hipSuccess) return e;
-  if (!only_rare) ssd_head_kernel<PT, NW, NB, false><<<grid, NW * 64, sizeof(Smem), st>>>(a);
-  // (behind the automatic mode's check no chunk needs a standard step — its margin covers the difference between its
-  // sum and the march's — so the complete kernel has nothing to do and is not launched)
-  if (!a.gate) ssd_head_kernel<PT, NW, NB, true><<<grid, NW * 64, sizeof(Smem), st>>>(a);
-#endif
+  ssd_head_kernel<PT, NW, NB><<<grid, NW * 64, sizeof(Smem), st>>>(a);
   return hipSuccess;
 }
 
@@ -1057,8 +891,6 @@ extern "C" int tv_ssd_head_debug_stamps(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_head_phases), sizeof(g_head_phases));
 }
 #endif
-
-bool tv_ssd_head_takes_every_chunk() { return TV_HEAD_UNISTD != 0; }
 
 bool tv_ssd_head_supported(int seqlen, int nheads, int headdim, int ngroups, int dstate, int dtype,
                            int64_t xsl, int64_t bsl, int64_t bsg, int64_t csl, int64_t csg, int64_t ysl,
@@ -1084,7 +916,7 @@ int tv_ssd_head_launch(const void* x, const void* dt, const void* A, const void*
                        int ngroups, int64_t xsb, int64_t xsl, int64_t dsb, int64_t dsl, int64_t bsb,
                        int64_t bsl, int64_t bsg, int64_t csb, int64_t csl, int64_t csg, int64_t ysb,
                        int64_t ysl, int dt_softplus, float dt_min, float dt_max, int group_map,
-                       void* workspace, size_t workspace_bytes, const void* cb_pre, hipStream_t st, int* gate) {
+                       void* workspace, size_t workspace_bytes, const void* cb_pre, hipStream_t st) {
   const HeadLayout lay = head_layout(batch, seqlen, nheads, headdim, ngroups);
   TV_CHECK_ARG(workspace && workspace_bytes >= lay.total && (((uintptr_t)workspace) & 15) == 0,
                "ssd_head: workspace of %zu bytes (16-byte aligned) required, got %zu", lay.total, workspace_bytes);
@@ -1101,15 +933,6 @@ int tv_ssd_head_launch(const void* x, const void* dt, const void* A, const void*
   a.seg_state = lay.nseg > 1 ? (float*)(wsb + lay.seg_state) : nullptr;
   a.seg_decay = lay.nseg > 1 ? (float*)(wsb + lay.seg_decay) : nullptr;
   a.chunk_tot = lay.nseg > 1 ? (float*)(wsb + lay.ctot) : nullptr;
-  a.redo = (int*)(wsb + lay.redo);
-  a.gate = gate; a.gate_run_if = 0;      // behind the check: run only when no chunk needs a standard step
-  if (gate) {
-    if (hipMemsetAsync(gate, 0, sizeof(int), st) != hipSuccess) { tv_set_error("ssd_head: memset failed"); return TV_ERR_LAUNCH; }
-    StdCheckArgs ca;
-    ca.dt = (const bf16_t*)dt; ca.A = (const float*)A; ca.dt_bias = (const float*)dt_bias; ca.flag = gate;
-    ca.L = seqlen; ca.H = nheads; ca.dsb = dsb; ca.dsl = dsl; ca.softplus = dt_softplus; ca.dt_min = dt_min; ca.dt_max = dt_max;
-    ssd_std_check_kernel<<<dim3((seqlen + HQ - 1) / HQ, (nheads + 127) / 128, batch), 128, 0, st>>>(ca);
-  }
   a.xsb = xsb; a.xsl = xsl; a.dsb = dsb; a.dsl = dsl; a.bsb = bsb; a.bsl = bsl; a.bsg = bsg;
   a.csb = csb; a.csl = csl; a.csg = csg; a.ysb = ysb; a.ysl = ysl;
   a.softplus = dt_softplus; a.group_map = group_map; a.dt_min = dt_min; a.dt_max = dt_max;
@@ -1143,7 +966,7 @@ int tv_ssd_head_launch(const void* x, const void* dt, const void* A, const void*
     const int rc = tv_ssd_correct_all_launch(y, dt, A, Cm, dt_bias, a.seg_state, a.seg_decay, (float*)final_state,
                                              (float*)total_decay, a.chunk_tot, batch, seqlen, nheads, headdim,
                                              ngroups, a.nseg, a.seg_chunks, ysb, ysl, dsb, dsl, csb, csl, csg,
-                                             dt_softplus, dt_min, dt_max, group_map, wsb + lay.corr, st, gate, 0);
+                                             dt_softplus, dt_min, dt_max, group_map, wsb + lay.corr, st);
     if (rc != TV_OK) return rc;
   }
   TV_LAUNCH_CHECK();

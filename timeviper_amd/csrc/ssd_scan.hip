@@ -41,8 +41,7 @@ int tv_ssd_slice_launch(const void* x, const void* dt, const void* A, const void
                         int64_t xsb, int64_t xsl, int64_t dsb, int64_t dsl, int64_t bsb,
                         int64_t bsl, int64_t bsg, int64_t csb, int64_t csl, int64_t csg, int64_t ysb, int64_t ysl,
                         int dtype, int dt_softplus, float dt_min, float dt_max, int group_map,
-                        void* workspace, size_t workspace_bytes, int wide, const void* cb_pre, hipStream_t st,
-                        const int* gate, int gate_run_if);
+                        void* workspace, size_t workspace_bytes, int wide, const void* cb_pre, hipStream_t st);
 
 // ssd_head.hip
 bool tv_ssd_head_supported(int seqlen, int nheads, int headdim, int ngroups, int dstate, int dtype,
@@ -55,9 +54,7 @@ int tv_ssd_head_launch(const void* x, const void* dt, const void* A, const void*
                        int ngroups, int64_t xsb, int64_t xsl, int64_t dsb, int64_t dsl, int64_t bsb,
                        int64_t bsl, int64_t bsg, int64_t csb, int64_t csl, int64_t csg, int64_t ysb,
                        int64_t ysl, int dt_softplus, float dt_min, float dt_max, int group_map,
-                       void* workspace, size_t workspace_bytes, const void* cb_pre, hipStream_t st, int* gate);
-
-bool tv_ssd_head_takes_every_chunk();
+                       void* workspace, size_t workspace_bytes, const void* cb_pre, hipStream_t st);
 
 // 0 auto, 1 generic recurrence, 2 chunk march (ssd_march.hip), 3 slice march, two work-groups per
 // head (ssd_slice.hip), 4 slice march, whole-head work-groups x concurrent sequence segments +
@@ -77,7 +74,7 @@ extern "C" size_t tv_ssd_scan_workspace_bytes(int batch, int seqlen, int nheads,
   const size_t wide = tv_ssd_slice_workspace_bytes(batch, seqlen, nheads, headdim, ngroups, dstate, 1);
   const size_t head = tv_ssd_head_workspace_bytes(batch, seqlen, nheads, headdim, ngroups);
   const size_t m = narrow > wide ? narrow : wide;       // any variant may be selected (tv_ssd_scan_set_impl)
-  return ((m > head ? m : head) + 255) / 256 * 256 + 256;   // + the device-side flag of the automatic choice (last 256 bytes)
+  return ((m > head ? m : head) + 255) / 256 * 256;
 }
 
 static int scan_impl(const void* x, const void* dt, const void* A, const void* Bm,
@@ -120,26 +117,11 @@ static int scan_impl(const void* x, const void* dt, const void* A, const void* B
       tv_ssd_head_supported(seqlen, nheads, headdim, ngroups, dstate, dtype, x_stride_l, b_stride_l, b_stride_g,
                             c_stride_l, c_stride_g, y_stride_l, x, Bm, Cm, y);
   if (head_ok) {
-    // Automatic mode: the head-per-wave march takes the call unless some chunk decays by more than 2^-199 (dt |A| > 2.1
-    // per token over a whole chunk), which only its slow complete variant could march; a device-side check decides, and
-    // the slice march (impl 4) — launched behind it, gated the other way — takes the call then.  Nothing is read back:
-    // both kernel sequences are always launched, one of them returns at once.  Forced (tv_ssd_scan_set_impl(6)): the
-    // head march alone, with its complete kernel as the fallback.
-    const bool both = !forced && !tv_ssd_head_takes_every_chunk() && tv_ssd_slice_supported(seqlen, nheads, headdim, ngroups, dstate, dtype, x_stride_l, b_stride_l,
-                                                        b_stride_g, c_stride_l, c_stride_g, y_stride_l, x, Bm, Cm, y, 1) &&
-                      workspace_bytes >= 512;
-    int* gate = both ? (int*)((unsigned char*)workspace + (workspace_bytes / 256 - 1) * 256) : nullptr;
-    const size_t ws_usable = both ? (workspace_bytes / 256 - 1) * 256 : workspace_bytes;
-    int rc = tv_ssd_head_launch(x, dt, A, Bm, Cm, D, dt_bias, init_state, y, final_state, total_decay, batch, seqlen,
-                                nheads, headdim, ngroups, x_stride_b, x_stride_l, dt_stride_b, dt_stride_l, b_stride_b,
-                                b_stride_l, b_stride_g, c_stride_b, c_stride_l, c_stride_g, y_stride_b, y_stride_l,
-                                dt_softplus, dt_min, dt_max, group_map, workspace, ws_usable, cb, st, gate);
-    if (rc != TV_OK || !both) return rc;
-    return tv_ssd_slice_launch(x, dt, A, Bm, Cm, D, dt_bias, init_state, y, final_state, total_decay, batch, seqlen,
-                               nheads, headdim, ngroups, dstate, x_stride_b, x_stride_l, dt_stride_b, dt_stride_l,
-                               b_stride_b, b_stride_l, b_stride_g, c_stride_b, c_stride_l, c_stride_g, y_stride_b,
-                               y_stride_l, dtype, dt_softplus, dt_min, dt_max, group_map, workspace, ws_usable, 1,
-                               cb ? cb : workspace, st, gate, 1);     // (C.B^T: the caller's, or what the head launch's pre-pass left at the workspace's start)
+    // the head-per-wave march takes every chunk itself (floating, reset and standard steps in the one kernel)
+    return tv_ssd_head_launch(x, dt, A, Bm, Cm, D, dt_bias, init_state, y, final_state, total_decay, batch, seqlen,
+                              nheads, headdim, ngroups, x_stride_b, x_stride_l, dt_stride_b, dt_stride_l, b_stride_b,
+                              b_stride_l, b_stride_g, c_stride_b, c_stride_l, c_stride_g, y_stride_b, y_stride_l,
+                              dt_softplus, dt_min, dt_max, group_map, workspace, workspace_bytes, cb, st);
   }
   for (int wide = 2; wide >= 0; --wide) {       // impl 5 / 4 (and 6 where it does not apply): whole-head variants first, then two work-groups per head
     if (wide == 2 && impl != 5) continue;
@@ -152,7 +134,7 @@ static int scan_impl(const void* x, const void* dt, const void* A, const void* B
                                  x_stride_b, x_stride_l, dt_stride_b, dt_stride_l, b_stride_b,
                                  b_stride_l, b_stride_g, c_stride_b, c_stride_l, c_stride_g, y_stride_b, y_stride_l, dtype,
                                  dt_softplus, dt_min, dt_max, group_map, workspace, workspace_bytes,
-                                 wide, cb, st, nullptr, 0);
+                                 wide, cb, st);
     }
   }
   if (march) {

@@ -35,7 +35,7 @@ int tv_ssd_correct_launch(void* y, const void* dt, const void* A, const void* Cm
                           int ngroups, int64_t ysb, int64_t ysl, int64_t dsb, int64_t dsl, int64_t csb,
                           int64_t csl, int64_t csg, int dt_softplus, float dt_min, float dt_max,
                           int group_map, void* workspace, const float* chunk_tot, int64_t chunk_tot_stride,
-                          hipStream_t st, const int* gate, int gate_run_if);
+                          hipStream_t st);
 
 // TV_BSCALE (wide layouts): 1 = the B/C waves scale the B tile in place (B~ = w_t B) and the slice-waves run the
 // state update on raw x fragments; 0 = the slice-waves form x~ = w_t x on their own fragments (round 2)
@@ -176,8 +176,6 @@ struct SliceArgs {
   int softplus, group_map;
   float dt_min, dt_max;
   int dbg;
-  const int* gate;                 // optional: the kernel returns at once unless (*gate != 0) == gate_run_if
-  int gate_run_if;
 };
 
 // -DTV_MARCH_ABLATE builds ablation switches (env TV_MARCH_DBG) into the kernel:
@@ -281,7 +279,6 @@ __global__ __launch_bounds__((Roles<PW, W12>::NWAVES * 64)) void ssd_slice_kerne
   constexpr int STHREADS = RL::NWAVES * 64, NC = RL::NC;
   constexpr int NB = RG::NB, BD = RG::BD, DXS = RG::DXS, NXS = RG::NXS, NDT = RG::NDT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  if (a.gate && (*a.gate != 0) != (a.gate_run_if != 0)) return;
   Smem& sm = *reinterpret_cast<Smem*>(smem_raw);
   constexpr int NPC = PW / 8;          // 16-byte pieces per x / y row
   constexpr int NPI = PW / 8;          // wave-instructions per x / y tile (64 rows * NPC / 64)
@@ -1151,8 +1148,7 @@ __global__ __launch_bounds__(256) void ssd_seg_combine_kernel(const float* __res
                                                               const float* __restrict__ seg_decay,
                                                               float* __restrict__ sin, float* __restrict__ final_state,
                                                               float* __restrict__ total_decay, int nseg,
-                                                              int64_t bh, int64_t per_head, const int* gate, int gate_run_if) {
-  if (gate && (*gate != 0) != (gate_run_if != 0)) return;
+                                                              int64_t bh, int64_t per_head) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;      // float4 index
   const int64_t n4 = bh * per_head / 4;
   if (i < n4) {
@@ -1225,7 +1221,7 @@ int tv_ssd_slice_launch(const void* x, const void* dt, const void* A, const void
                         int64_t bsl, int64_t bsg, int64_t csb, int64_t csl, int64_t csg,
                         int64_t ysb, int64_t ysl, int dtype, int dt_softplus, float dt_min,
                         float dt_max, int group_map, void* workspace, size_t workspace_bytes,
-                        int wide, const void* cb_pre, hipStream_t st, const int* gate, int gate_run_if) {
+                        int wide, const void* cb_pre, hipStream_t st) {
   (void)dtype; (void)dstate;
   const SegLayout lay = seg_layout(batch, seqlen, nheads, headdim, ngroups, wide);
   const size_t need = lay.total;
@@ -1250,7 +1246,6 @@ int tv_ssd_slice_launch(const void* x, const void* dt, const void* A, const void
   a.csb = csb; a.csl = csl; a.csg = csg; a.ysb = ysb; a.ysl = ysl;
   a.softplus = dt_softplus; a.group_map = group_map; a.dt_min = dt_min; a.dt_max = dt_max;
   { const char* e = getenv("TV_MARCH_DBG"); a.dbg = e ? atoi(e) : 0; }
-  a.gate = gate; a.gate_run_if = gate_run_if;
 
   CbArgs ca;
   ca.Bm = a.Bm; ca.Cm = a.Cm; ca.cb = (bf16_t*)workspace;
@@ -1284,7 +1279,7 @@ int tv_ssd_slice_launch(const void* x, const void* dt, const void* A, const void
     float* sin = a.nseg > 2 ? (float*)(wsb + lay.sin) : nullptr;
     const int64_t n4 = bh * per_head / 4;
     ssd_seg_combine_kernel<<<dim3((unsigned)((n4 + 255) / 256)), 256, 0, st>>>(
-        a.seg_state, a.seg_decay, sin, (float*)final_state, (float*)total_decay, a.nseg, bh, per_head, gate, gate_run_if);
+        a.seg_state, a.seg_decay, sin, (float*)final_state, (float*)total_decay, a.nseg, bh, per_head);
     for (int s = 1; s < a.nseg; ++s) {
       const int64_t t0 = (int64_t)s * a.seg_chunks * SQ;
       if (t0 >= seqlen) break;
@@ -1294,7 +1289,7 @@ int tv_ssd_slice_launch(const void* x, const void* dt, const void* A, const void
                                            (const bf16_t*)Cm + t0 * csl, dt_bias, s_in, batch, len, nheads,
                                            headdim, ngroups, ysb, ysl, dsb, dsl, csb, csl, csg, dt_softplus,
                                            dt_min, dt_max, group_map, wsb + lay.corr,
-                                           a.chunk_tot + (int64_t)s * a.seg_chunks, a.nchunks, st, gate, gate_run_if);
+                                           a.chunk_tot + (int64_t)s * a.seg_chunks, a.nchunks, st);
       if (rc != TV_OK) return rc;
     }
   }

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void rank_logits_kernel(const T* __restrict__ 
                                                           float* __restrict__ logits,
                                                           int n_keys, int Hq, int Hkv, int D,
                                                           int64_t ksl, int64_t ksh,
-                                                          float scale) {
+                                                          float divisor) {
   extern __shared__ float qs[];  // Hq*D
   for (int i = threadIdx.x; i < Hq * D; i += blockDim.x) qs[i] = to_f32(q[i]);
   __syncthreads();
@@ -88,10 +88,11 @@ __global__ __launch_bounds__(256) void rank_logits_kernel(const T* __restrict__ 
       int j = 0;
       for (int d = lane; d < D && j < 4; d += 64, ++j) acc = fmaf(qs[h * D + d], kv[j], acc);
       acc = wave_sum(acc);
-      // the reference forms q.K^T and the 1/sqrt(d) scaling in the activation
-      // dtype (:1923-1927) before the fp32 softmax: round twice like it does
+      // the reference forms q.K^T and the "/ math.sqrt(head_dim)" in the activation dtype (:1923-1927) before the
+      // fp32 softmax: round twice like it does, and DIVIDE by the fp32 divisor like it does (a product with the
+      // reciprocal lands one fp32 ulp off for some values, which the second rounding turns into a bf16 step)
       acc = to_f32(from_f32<T>(acc));
-      if (lane == 0) logits[(int64_t)key * Hq + h] = to_f32(from_f32<T>(acc * scale));
+      if (lane == 0) logits[(int64_t)key * Hq + h] = to_f32(from_f32<T>(__fdiv_rn(acc, divisor)));
     }
   }
 }
@@ -157,8 +158,12 @@ int launch_gather(const void* src, const int64_t* index, void* dst, int64_t n, i
 template <typename T>
 int launch_rank_logits(const void* q, const void* k, float* logits, int n_keys, int Hq, int Hkv,
                        int D, int64_t ksl, int64_t ksh, float scale, hipStream_t s) {
+  // logits = (q . k) / divisor: the default scale 1 / sqrt(D) becomes the reference's own divisor, float(sqrt(D))
+  // (torch divides the bf16 tensor by the Python double rounded to fp32), any other scale its fp32 reciprocal
+  const double sq = sqrt((double)D);
+  const float divisor = fabs((double)scale * sq - 1.0) < 1e-6 ? (float)sq : (float)(1.0 / (double)scale);
   rank_logits_kernel<T><<<dim3((n_keys + 3) / 4), 256, (size_t)Hq * D * sizeof(float), s>>>(
-      (const T*)q, (const T*)k, logits, n_keys, Hq, Hkv, D, ksl, ksh, scale);
+      (const T*)q, (const T*)k, logits, n_keys, Hq, Hkv, D, ksl, ksh, divisor);
   TV_LAUNCH_CHECK();
 }
 

@@ -23,8 +23,13 @@ the 8 GPUs with RCCL all-gather of the SSM states over xGMI".  One process per G
     same stable sort on the identical array — the single-GPU kernels on the same numbers, so one GPU
     and N GPUs keep the same tokens bit for bit; every rank keeps its own rows; the dropped rows' K/V
     for the TransV cross-attention are gathered to the rank that owns the trailing text.
-    Shards are not re-balanced after an "attn" stage (the kept tokens of a real checkpoint may
-    cluster; an all-to-all of rows would be the fix — not built).
+    After a token-drop stage the shards can be moved back to an even split (`rebalance_rows`: ONE
+    all_to_all_single of contiguous row ranges, order kept; option `rebalance` / env TV_SP_REBALANCE,
+    off by default: uniform and synthetic "attn" stages leave the shards within a few percent of even;
+    the kept tokens of a real checkpoint may cluster).
+Collectives per Mamba layer: two — the conv halo (needed BEFORE the conv, whose output feeds the scan)
+and ONE gather of [S_r | L_r] packed in a single fp32 buffer (after the scan); the dependency
+in_proj -> halo -> conv -> scan -> state leaves no way to merge the two.
 """
 from __future__ import annotations
 
@@ -239,7 +244,15 @@ class SequenceParallelTimeViper:
             tpf = getattr(self.vlm, "num_compressed_tokens", 16)
             if hasattr(self.vlm.vision_backbone, "backbone_ids"):
                 tpf *= len(self.vlm.vision_backbone.backbone_ids)
-            self.causal_skew = estimate_causal_skew(self.vlm, tpf)
+            k = estimate_causal_skew(self.vlm, tpf)
+            # the estimate can be overridden from the environment (TV_SP_CAUSAL_SKEW / TV_SP_RATES), and a launcher may
+            # export different values to different ranks: rank 0's number is the one every rank uses — ranks that
+            # derived different splits would enter the host-sized collectives below with mismatched lengths
+            if self.world > 1 and dist.is_available() and dist.is_initialized():
+                box = [k]
+                dist.broadcast_object_list(box, src=_global_rank(self.group, 0), group=self.group)
+                k = float(box[0])
+            self.causal_skew = k
         # towers that regroup the frames of a clip into tubes (InternVideo2, alone or inside a dual
         # encoder) see the same clips as an unsharded run only if the shards start on clip boundaries
         vb = self.vlm.vision_backbone
@@ -306,14 +319,20 @@ class SequenceParallelTimeViper:
                                             d_in, mixer.n_groups, mixer.ssm_state_size,
                                             activation=mixer.activation, halo=halo, return_cb=True)
         xh = x.view(Bsz, L, mixer.num_heads, mixer.head_dim)
-        kw = dict(chunk_size=mixer.chunk_size, D=mixer.D, dt_bias=mixer.dt_bias, dt_softplus=True,
+        A, D32, dtb32 = mixer._consts()          # fp32, derived once per parameter version
+        kw = dict(chunk_size=mixer.chunk_size, D=D32, dt_bias=dtb32, dt_softplus=True,
                   return_final_states=True, group_map=mixer.group_map)
         if mixer.time_step_limit != (0.0, float("inf")):
             kw["dt_limit"] = mixer.time_step_limit
-        A = mixer._neg_A()
         y, S, dec = K.mamba_chunk_scan_combined(xh, dt, A, Bm, Cm, return_total_decay=True, cb=cb, **kw)
-        S_all = all_gather_stack(S, self.group)
-        d_all = all_gather_stack(dec, self.group)
+        # final state and total log-decay of the shard travel in ONE collective (5.2 MB + 512 B at Nano dims)
+        nS = S.numel()
+        packed = torch.empty(nS + dec.numel(), dtype=torch.float32, device=S.device)
+        packed[:nS] = S.reshape(-1)
+        packed[nS:] = dec.reshape(-1)
+        both = all_gather_stack(packed, self.group)
+        S_all = both[:, :nS].view((self.world,) + tuple(S.shape))
+        d_all = both[:, nS:].view((self.world,) + tuple(dec.shape))
         if self.rank > 0 and L > 0:
             # the state entering this shard, then the carried-in term y_t += exp(cs_t) C_t . In_r added
             # in place — not a second scan: the term dies out after each head's
@@ -322,7 +341,7 @@ class SequenceParallelTimeViper:
             dtl = {} if "dt_limit" not in kw else {"dt_limit": kw["dt_limit"]}
             if y.dtype == torch.bfloat16 and mixer.ssm_state_size == 128 and mixer.head_dim % 8 == 0 \
                     or not y.is_cuda:
-                y = K.ssd_state_correction(y, dt, A, Cm, inc, dt_bias=mixer.dt_bias, dt_softplus=True,
+                y = K.ssd_state_correction(y, dt, A, Cm, inc, dt_bias=dtb32, dt_softplus=True,
                                            group_map=mixer.group_map, **dtl)
             else:       # shapes outside the correction kernel (fp32 / other d_state): scan again from In_r
                 y, _ = K.mamba_chunk_scan_combined(xh, dt, A, Bm, Cm, initial_states=inc, **kw)
@@ -408,7 +427,7 @@ class SequenceParallelTimeViper:
             order = torch.sort(scores, descending=True, stable=True).indices
             top = (order[:keep] + vis0).sort().values
         elif "uni" in ctype:
-            top = K.uniform_keep_indices(image_tokens, keep, offset=vis0, device=dev)
+            top = None               # located on the host below (one source for boundaries and rows)
         else:
             raise NotImplementedError(ctype)
         # Where the (identical, sorted) kept indices fall in every rank's old range.  "uni" indices are

@@ -388,8 +388,15 @@ def ssd_scan_set_impl(impl: int) -> None:
 def flash_attn_set_variant(variant: int) -> None:
     """0 auto (ViT frames: the streaming kernel), 1 the 4 x 64-row one-wave-per-SIMD kernel, 2 the 8 x 32-row
     two-waves-per-SIMD kernel with 16-row halves, where they apply (non-causal bf16, head_dim 65..80, >= 256 keys;
-    include/timeviper_hip.h).  Process-global (dev tools and tests)."""
+    include/timeviper_hip.h).  The two variants are measured-slower experiments and only exist in a library built
+    with TV_FA_VARIANTS=1 (`flash_attn_variants_built()`); elsewhere the call has no effect.
+    Process-global (dev tools and tests)."""
     _capi.lib().tv_flash_attn_set_variant(int(variant))
+
+
+def flash_attn_variants_built() -> bool:
+    """True in a library built with TV_FA_VARIANTS=1 (csrc/attention_variants.hpp compiled in)."""
+    return bool(_capi.lib().tv_flash_attn_variants_built())
 
 
 _ATTN_FP8 = {"on": False, "min_keys": 4096, "min_queries": 64}

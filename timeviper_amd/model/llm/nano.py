@@ -251,8 +251,21 @@ class NemotronHMamba2Mixer(nn.Module):
         self.use_bias = config.use_bias
         self.group_map = "block"  # "tile" reproduces the reference CPU quirk (tests only)
 
+    def _consts(self):
+        """(-exp(A_log), D, dt_bias) in fp32 — what the scan kernels take (modeling_nano.py:640, :514-522).
+        Derived once per parameter version, not once per call: in a bf16 model the per-call form costs five
+        small launches a layer (float, exp, neg, two casts), 27 layers a forward, every decode step."""
+        ps = (self.A_log, self.D, self.dt_bias)
+        key = tuple((p.data_ptr(), p._version, p.dtype, p.device) for p in ps)
+        if key != getattr(self, "_ckey", None):
+            with torch.no_grad():
+                self._cval = (-torch.exp(self.A_log.detach().float()), self.D.detach().float().contiguous(),
+                              self.dt_bias.detach().float().contiguous())
+            self._ckey = key
+        return self._cval
+
     def _neg_A(self):
-        return -torch.exp(self.A_log.float())
+        return self._consts()[0]
 
     def forward(self, hidden_states, cache_params: Optional[HybridMambaAttentionDynamicCache] = None,
                 cache_position=None, attention_mask=None, seq_idx=None,
@@ -269,6 +282,7 @@ class NemotronHMamba2Mixer(nn.Module):
                   and int(cache_position[0]) > 0)
         gate, xBC, dt = projected_states.split([d_in, self.conv_dim, self.num_heads], dim=-1)
         w = self.conv1d.weight.squeeze(1)
+        negA, D32, dtb32 = self._consts()
         if decode:
             assert seq_len == 1
             xBC = K.causal_conv1d_update(xBC[:, 0], cache_params.conv_states[self.layer_idx], w,
@@ -276,9 +290,9 @@ class NemotronHMamba2Mixer(nn.Module):
             x, Bm, Cm = torch.split(xBC, [d_in, gts, gts], dim=-1)
             y = K.selective_state_update(
                 cache_params.ssm_states[self.layer_idx],
-                x.reshape(batch_size, self.num_heads, self.head_dim), dt[:, 0], self._neg_A(),
+                x.reshape(batch_size, self.num_heads, self.head_dim), dt[:, 0], negA,
                 Bm.reshape(batch_size, self.n_groups, -1), Cm.reshape(batch_size, self.n_groups, -1),
-                self.D, z=None, dt_bias=self.dt_bias, dt_softplus=True)
+                D32, z=None, dt_bias=dtb32, dt_softplus=True)
             y = self.norm(y.reshape(batch_size, 1, d_in), gate)
             return self.out_proj(y)
 
@@ -296,9 +310,9 @@ class NemotronHMamba2Mixer(nn.Module):
         dt_limit = {} if self.time_step_limit == (0.0, float("inf")) \
             else {"dt_limit": self.time_step_limit}
         res = K.mamba_chunk_scan_combined(
-            x.view(batch_size, seq_len, -1, self.head_dim), dt, self._neg_A(), Bm, Cm,
-            chunk_size=self.chunk_size, D=self.D,
-            z=None, seq_idx=None, return_final_states=True, dt_bias=self.dt_bias, dt_softplus=True,
+            x.view(batch_size, seq_len, -1, self.head_dim), dt, negA, Bm, Cm,
+            chunk_size=self.chunk_size, D=D32,
+            z=None, seq_idx=None, return_final_states=True, dt_bias=dtb32, dt_softplus=True,
             initial_states=initial_states, group_map=self.group_map,
             return_total_decay=return_shard_state, cb=cb, **dt_limit)
         scan_output, ssm_state = res[0], res[1]

@@ -185,24 +185,27 @@ class Block(nn.Module):
         h, x = K.layer_norm(x, n2.weight, n2.bias, n2.eps, residual=a, return_sum=True)
         return x, self.ls2(self.mlp(h))
 
-    def forward_stream(self, x, pend):
+    def forward_stream(self, x, pend, pend_mid=None, pend_out=None):
         """Same block (no LayerScale) on a residual stream the projections accumulate INTO: the output
         GEMMs of both sub-layers run as x += h W^T (one pass over x inside the GEMM's epilogue instead
         of a separate read-add-write), their biases are carried beside the stream in `pend` (fp32, one
         row) and enter through the LayerNorm kernel, which then reads x once and writes the normalised
         rows once — 2 passes over the stream per LayerNorm instead of 4.  x (B, N, C), contiguous, is
         updated in place; the block's output is x + pend.  Arithmetic: x + h W^T is rounded to bf16
-        once (the two-step form rounds h W^T + b and the sum separately)."""
+        once (the two-step form rounds h W^T + b and the sum separately).  `pend_mid` / `pend_out`: the
+        bias rows after the attention / after the block where the caller has them pre-summed (they are a pure
+        function of the parameters: VisionTransformer._pending_rows)."""
         n1, n2 = self.norm1, self.norm2
         x2 = x.view(-1, x.shape[-1])
         h = K.layer_norm(x, n1.weight, n1.bias, n1.eps, row_bias=pend)
         o = self.attn.heads(h)
         torch.addmm(x2, o.view(x2.shape), self.attn.proj.weight.t(), out=x2)
-        pend = self.attn.proj.bias.float() if pend is None else pend + self.attn.proj.bias.float()
-        h = K.layer_norm(x, n2.weight, n2.bias, n2.eps, row_bias=pend)
+        if pend_mid is None:          # (callers that do not carry the pre-summed rows)
+            pend_mid = self.attn.proj.bias.float() if pend is None else pend + self.attn.proj.bias.float()
+        h = K.layer_norm(x, n2.weight, n2.bias, n2.eps, row_bias=pend_mid)
         hid, w2 = self.mlp.hidden(h)
         torch.addmm(x2, hid.view(x2.shape[0], -1), w2.t(), out=x2)
-        return x, pend + self.mlp.fc2.bias.float()
+        return x, (pend_mid + self.mlp.fc2.bias.float() if pend_out is None else pend_out)
 
 
 class AttentionPoolLatent(nn.Module):
@@ -237,6 +240,24 @@ class VisionTransformer(nn.Module):
         self.norm = nn.LayerNorm(embed_dim, eps=1e-6)
         self.attn_pool = AttentionPoolLatent(embed_dim, num_heads, mlp_hidden) if pool == "map" else None
 
+    def _pending_rows(self, blocks):
+        """Per block: the fp32 bias row carried beside the stream after the attention projection and after
+        the MLP (running sums of proj.bias and fc2.bias in block order, the same left-to-right fp32 adds
+        `Block.forward_stream` would make) — built once per parameter version instead of two adds and two
+        casts per block and call."""
+        ps = [p for b in blocks for p in (b.attn.proj.bias, b.mlp.fc2.bias)]
+        key = tuple((p.data_ptr(), p._version, p.dtype, p.device) for p in ps)
+        if key != getattr(self, "_pend_key", None):
+            rows, pend = [], None
+            with torch.no_grad():
+                for b in blocks:
+                    pb = b.attn.proj.bias.detach().float()
+                    mid = pb if pend is None else pend + pb
+                    pend = mid + b.mlp.fc2.bias.detach().float()
+                    rows.append((mid, pend))
+            self._pend_key, self._pend_rows = key, rows
+        return self._pend_rows
+
     def get_intermediate_layers(self, x, n=None):
         """timm semantics for n={k}: run blocks 0..k, return block k's output with
         the prefix tokens removed, no final norm."""
@@ -259,9 +280,10 @@ class VisionTransformer(nn.Module):
                 and os.environ.get("TV_VIT_STREAM", "1") != "0":
             # output projections accumulate into the stream, biases ride beside it (Block.forward_stream)
             x = x if x.is_contiguous() else x.contiguous()
+            rows = self._pending_rows(blocks)
             pend = None
-            for blk in blocks:
-                x, pend = blk.forward_stream(x, pend)
+            for blk, (mid, out) in zip(blocks, rows):
+                x, pend = blk.forward_stream(x, pend, mid, out)
             x = x + pend.to(x.dtype)
             return (x[:, self.num_prefix_tokens:],)
         delta = None
