@@ -63,8 +63,9 @@ class OpTimers:
     whose roofline the bench line carries: the SSD scan (HBM), the ViT and the causal LLM attention
     (MFMA), the patch-embedding GEMM (MFMA and HBM)."""
 
-    def __init__(self, K):
+    def __init__(self, K, event=None):
         self.K, self.on, self.rec, self.saved = K, False, {}, {}
+        self.event = event or (lambda: torch.cuda.Event(enable_timing=True))
 
     def _wrap(self, name, classify):
         orig = getattr(self.K, name)
@@ -74,7 +75,7 @@ class OpTimers:
             key = classify(*a, **kw) if self.on else None
             if key is None:
                 return orig(*a, **kw)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0, e1 = self.event(), self.event()
             e0.record()
             out = orig(*a, **kw)
             e1.record()
@@ -366,7 +367,135 @@ def config1_scan(args):
                         "oracle_vs_reference_golden_y (tests/golden/mixer_g1.npz)": err_gold}}), flush=True)
 
 
-def main():
+def config_decode(args):
+    """One generated token against the cache of a 2 048-frame prefill (32 868 tokens, no token drop): the decode step
+    of `generate()` (modeling_nano.py:484-546, 1666-1689) on tv_causal_conv1d_update, tv_selective_state_update and the
+    one-query attention, timed per token; roofline of tv_selective_state_update (HBM: the fp32 state of every head is
+    read and written once per token, 2 x 5.24 MB per Mamba layer)."""
+    from timeviper_amd.build import ensure_built
+    ensure_built()
+    from timeviper_amd import kernels as K
+    from timeviper_amd.model import build_synthetic_timeviper
+    from timeviper_amd.model.llm.nano import HybridMambaAttentionDynamicCache, NemotronHConfig
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    cfg = NemotronHConfig.nemotron_nano_9b_v2()
+    vlm = build_synthetic_timeviper(cfg, "siglip-vit-so400m-384px", pdrop_type=None, merge_module="no_merge",
+                                    device=dev, seed=0)
+    llm = vlm.llm_backbone.llm
+    L = 2048 * TOK_PER_FRAME + 100
+    g = torch.Generator(device=dev).manual_seed(1)
+    emb = (torch.randn(1, L, cfg.hidden_size, device=dev, generator=g) * 0.02).bfloat16()
+    tok = (torch.randn(1, 1, cfg.hidden_size, device=dev, generator=g) * 0.02).bfloat16()
+    steps, warm = max(args.steps, 16), max(args.warmup, 4)
+    rec = []
+    orig = K.selective_state_update
+
+    def timed(state, *a, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig(state, *a, **kw)
+        e1.record()
+        rec.append((e0, e1, 2 * state.numel() * state.element_size()))
+        return out
+    with torch.inference_mode():
+        cache = HybridMambaAttentionDynamicCache(cfg, 1, dtype=torch.bfloat16, device=dev)
+        llm(inputs_embeds=emb, past_key_values=cache, use_cache=True, cache_position=torch.zeros(1, dtype=torch.long))
+        pos = L
+        for _ in range(warm):
+            llm(inputs_embeds=tok, past_key_values=cache, use_cache=True, cache_position=torch.tensor([pos]))
+            pos += 1
+        torch.cuda.synchronize()
+        K.selective_state_update = timed
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = llm(inputs_embeds=tok, past_key_values=cache, use_cache=True, cache_position=torch.tensor([pos])).logits
+            pos += 1
+        torch.cuda.synchronize()
+        dt_s = time.perf_counter() - t0
+        K.selective_state_update = orig
+    assert torch.isfinite(out.float()).all()
+    ms_ssu = sum(e0.elapsed_time(e1) for e0, e1, _ in rec)
+    gbs = sum(b for _, _, b in rec) / (ms_ssu * 1e-3) / 1e9
+    weights = sum(p.numel() * p.element_size() for n, p in llm.named_parameters() if "embed" not in n)
+    print(json.dumps({
+        "metric": "decode tokens/s, TimeViper-9B, batch 1, one token against a 2 048-frame prefill cache",
+        "value": round(steps / dt_s, 2), "unit": "tokens/s", "n_gpus": 1, "steps": steps, "warmup": warm,
+        "ms_per_step": round(dt_s / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"Nemotron-Nano-9B-v2 hybrid decode step (27 Mamba2 / 25 MLP / 4 attention layers), cache of "
+                               f"{L} tokens (2 048 frames, no token drop), host-driven layer loop, GEMVs on hipBLASLt",
+                   "cache_tokens": L, "weights": "random init, seed 0",
+                   "weight_bytes_per_token": weights,
+                   "weight_stream_floor_ms": round(weights / (HBM_PEAK_GBS * 1e9) * 1e3, 3)},
+        "roofline": {"bound": "hbm", "kernel": "selective_state_update_kernel (tv_selective_state_update)",
+                     "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                     "traffic": None, "launches": len(rec), "avg_launch_us": round(ms_ssu * 1e3 / len(rec), 2),
+                     "bytes_per_launch": rec[0][2]}}), flush=True)
+
+
+class CudaEnv:
+    """What `run` needs from the platform: the device of this rank, the collective backend, a device synchronisation,
+    event timers on the launch stream, the model and its input size.  tests/bench_dryrun.py supplies a CPU / gloo
+    stand-in (oracle-backed kernel shims, a toy model) so that the launcher, the sharded step, the max-over-ranks timing
+    and the one-JSON-line contract of `--gpus N` run on a box without GPUs; THIS class is the product."""
+    backend = "nccl"
+    pixels = 384
+
+    def __init__(self, local_rank: int):
+        torch.cuda.set_device(local_rank)
+        self.dev = torch.device("cuda", local_rank)
+
+    def init_process_group(self, world, rank):
+        import torch.distributed as dist
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=self.dev)
+        else:
+            dist.init_process_group("nccl", device_id=self.dev)
+
+    def sync(self):
+        torch.cuda.synchronize()
+
+    def event(self):
+        return torch.cuda.Event(enable_timing=True)
+
+    def kernels(self):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def ensure_built(self):
+        from timeviper_amd.build import ensure_built
+        ensure_built()
+
+    def build_model(self, pd):
+        from timeviper_amd.model import build_synthetic_timeviper
+        from timeviper_amd.model.llm.nano import NemotronHConfig
+        cfg = NemotronHConfig.nemotron_nano_9b_v2()
+        vlm = build_synthetic_timeviper(cfg, "siglip-vit-so400m-384px", pdrop_type=pd,
+                                        merge_module="CrossAttention" if pd else "no_merge",
+                                        device=self.dev, seed=0)
+        return cfg, vlm, ("TimeViper-Nano-9B forward (prefill), {T} frames x 384px, SigLIP-so400m ViT (26 blocks) + ToMe "
+                          "729->16 + 56-layer Nemotron-Nano-9B-v2 hybrid (27 Mamba2 / 25 MLP / 4 attention), {L} tokens, batch 1")
+
+
+def launch_children(script: str, argv, gpus: int) -> int:
+    """`python bench.py --gpus N` typed by hand: start the N ranks as a CHILD job (one process per GPU,
+    torch.distributed.run) and relay its output and exit code.  Nothing has touched the GPU in this process yet
+    (importing torch does not), and nothing is exec'ed over it."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(script).resolve()), *argv]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -374,11 +503,22 @@ def main():
     ap.add_argument("--frames", type=int, default=int(os.environ.get("TV_BENCH_FRAMES", 10240)))
     ap.add_argument("--no-pdrop", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--config", type=int, default=0,
+    ap.add_argument("--config", default="0",
                     help="one of BASELINE.json's other configurations, counted from 1 (1 scan only, 2 256 frames, "
-                         "3 2 048 frames + TransV + pdrop, 5 Qwen2.5 + dual encoder + fp8 attention); default: the "
-                         "headline run (10 240 frames); 4 is the headline run with --gpus 8")
-    args = ap.parse_args()
+                         "3 2 048 frames + TransV + pdrop, 5 Qwen2.5 + dual encoder + fp8 attention), or `decode` (one "
+                         "generated token against a 2 048-frame prefill cache); default: the headline run (10 240 "
+                         "frames); 4 is the headline run with --gpus 8")
+    return ap.parse_args(argv)
+
+
+def main():
+    args = parse_args()
+    if args.config == "decode":
+        return config_decode(args)
+    try:
+        args.config = int(args.config)
+    except ValueError:
+        sys.exit("bench.py: --config takes 1, 2, 3, 4, 5 or decode")
     if args.config == 1:
         return config1_scan(args)
     if args.config == 2:
@@ -391,22 +531,16 @@ def main():
         sys.exit(subprocess.run([sys.executable, str(ROOT / "timeviper_amd" / "devtools" / "run_config5.py"), "4096",
                                  str(max(args.steps, 1)), "1"], cwd=str(ROOT)).returncode)
     elif args.config not in (0, 4):
-        sys.exit("bench.py: --config takes 1, 2, 3, 4 or 5")
+        sys.exit("bench.py: --config takes 1, 2, 3, 4, 5 or decode")
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # `python bench.py --gpus N` typed by hand: start the N ranks as a CHILD job (one process per
-        # GPU, torch.distributed.run) and relay its output and exit code.  Nothing has touched the GPU
-        # in this process yet (importing torch does not), and nothing is exec'ed over it.
-        import socket
-        import subprocess
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-               "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()),
-               *sys.argv[1:]]
-        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        sys.exit(subprocess.run(cmd, env=env).returncode)
+        sys.exit(launch_children(__file__, sys.argv[1:], args.gpus))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    run(args, CudaEnv(int(os.environ.get("LOCAL_RANK", "0"))))
+
+
+def run(args, env):
+    """The timed job on this rank (one process per GPU); rank 0 prints the ONE JSON line."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -414,57 +548,45 @@ def main():
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with\n  python -m "
                  f"torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 "
                  f"--master-port 29500 bench.py --gpus {args.gpus} ...")
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev = env.dev
     # TV_BENCH_FORCE_SP=1 (dev): run the sequence-sharded runner and its RCCL collectives even
     # with one rank, so the N>1 code path can be exercised on a 1-GPU box
     sharded = world > 1 or os.environ.get("TV_BENCH_FORCE_SP") == "1"
     if sharded:
-        import torch.distributed as dist
-        if world == 1:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29533")
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-        else:
-            dist.init_process_group("nccl", device_id=dev)
+        env.init_process_group(world, rank)
 
     if local_rank == 0:         # a tree without build artefacts: compile once, the others wait
-        from timeviper_amd.build import ensure_built
-        ensure_built()
+        env.ensure_built()
     if sharded:
         torch.distributed.barrier()
     from timeviper_amd import kernels as K
-    from timeviper_amd.model import build_synthetic_timeviper
-    from timeviper_amd.model.llm.nano import NemotronHConfig
 
-    cfg = NemotronHConfig.nemotron_nano_9b_v2()
     pd = None if args.no_pdrop else PDROP
-    vlm = build_synthetic_timeviper(cfg, "siglip-vit-so400m-384px", pdrop_type=pd,
-                                    merge_module="CrossAttention" if pd else "no_merge",
-                                    device=dev, seed=0)
+    cfg, vlm, workload = env.build_model(pd)
     T = args.frames
     g = torch.Generator(device=dev).manual_seed(1)
     tok = vlm.default_token_id
-    ids = torch.cat([torch.randint(3, 1000, (20,), device=dev, generator=g),
+    hi_id = min(1000, cfg.vocab_size - 1)
+    ids = torch.cat([torch.randint(3, hi_id, (20,), device=dev, generator=g),
                      torch.full((T,), tok, device=dev),
-                     torch.randint(3, 1000, (80,), device=dev, generator=g)])[None]
+                     torch.randint(3, hi_id, (80,), device=dev, generator=g)])[None]
+    px, pdt = env.pixels, (torch.bfloat16 if dev.type == "cuda" else torch.float32)
     if sharded:
         from timeviper_amd.distributed import SequenceParallelTimeViper
         runner = SequenceParallelTimeViper(vlm, rank, world)
         lo, hi = runner.frame_range(T)
-        pix = torch.randn(hi - lo, 3, 384, 384, device=dev, dtype=torch.bfloat16, generator=g)
+        pix = torch.randn(hi - lo, 3, px, px, device=dev, dtype=pdt, generator=g)
         step = lambda: runner.forward(ids, pix, T)
     else:
-        pix = torch.randn(T, 3, 384, 384, device=dev, dtype=torch.bfloat16, generator=g)
+        pix = torch.randn(T, 3, px, px, device=dev, dtype=pdt, generator=g)
         step = lambda: vlm(input_ids=ids, pixel_values_videos=pix).logits
 
     def barrier():
         if sharded:
             torch.distributed.barrier()
-        torch.cuda.synchronize()
+        env.sync()
 
-    with torch.inference_mode(), OpTimers(K) as st:
+    with torch.inference_mode(), env.kernels(), OpTimers(K, env.event) as st:
         for _ in range(args.warmup):
             step()
         barrier()
@@ -476,6 +598,8 @@ def main():
         dt_s = time.perf_counter() - t0
         st.on = False
     assert torch.isfinite(out.float()).all(), "non-finite logits"
+    if os.environ.get("TV_BENCH_DRYRUN_FAIL_RANK") == str(rank):          # tests: a rank that dies must fail the job
+        raise RuntimeError("TV_BENCH_DRYRUN_FAIL_RANK: this rank fails on purpose")
     t = torch.tensor([dt_s], device=dev, dtype=torch.float64)
     if sharded:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -490,9 +614,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic",
-            "config": {"workload": f"TimeViper-Nano-9B forward (prefill), {T} frames x 384px, SigLIP-so400m "
-                                   f"ViT (26 blocks) + ToMe 729->16 + 56-layer Nemotron-Nano-9B-v2 hybrid "
-                                   f"(27 Mamba2 / 25 MLP / 4 attention), {L} tokens, batch 1",
+            "config": {"workload": workload.format(T=T, L=L),
                        "frames": T, "tokens": L, "pdrop": pd, "merge_module": "CrossAttention" if pd else "no_merge",
                        "parallelism": "single GPU" if world == 1 else f"sequence-sharded x{world} (RCCL)",
                        "weights": "random init, seed 0"},
@@ -501,7 +623,7 @@ def main():
             # ... and every kernel with a stated roof, all event-timed inside the timed steps
             "rooflines": st.all_rooflines(scan_bytes_per_token(cfg), cfg),
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and dev.type == "cuda":
             line["cpu_baseline"] = cpu_baseline(cfg)
     # RCCL writes a version banner through C stdio, which is block-buffered on a pipe and would
     # otherwise surface at process exit, AFTER the result: every rank drains it before the last

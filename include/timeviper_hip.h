@@ -258,6 +258,21 @@ int tv_selective_state_update(void* state, const void* x, const void* dt,
                               void* stream);
 
 /* ------------------------------------------------------------------------
+ * ViT linears with fused epilogues: C = epilogue(A . W^T), A (M,K), W (N,K) =
+ * nn.Linear.weight as stored, C (M,N), all bf16 row-major with element row strides lda / ldw / ldc.
+ *   epilogue 0  C = acc + bias
+ *            1  C = gelu(bf16(acc + bias)), exact (erf) GELU — timm Mlp fc1 + act
+ *               (base_vision.py:274-278 via timm; InternVideo2 Mlp vit_scale_clean.py:296-320): the
+ *               rounding points of a bf16 GEMM followed by tv_gelu_fwd, bit for bit
+ *            2  C = C + acc (bias ignored): output projections accumulating into the residual stream
+ * bias (N) fp32 or bf16 (bias_dtype = TV_F32 / TV_BF16) or NULL.  K % 64 == 0, N % 4 == 0, rows
+ * 16-byte aligned; any M (row tails are masked).  fp32 accumulation on v_mfma_f32_16x16x32_bf16.
+ * --------------------------------------------------------------------- */
+int tv_gemm_bf16_fwd(const void* A, const void* W, const void* bias, void* C, int64_t M, int N,
+                     int K, int64_t lda, int64_t ldw, int64_t ldc, int epilogue, int bias_dtype,
+                     void* stream);
+
+/* ------------------------------------------------------------------------
  * A1 / T3 / ViT  fused softmax attention forward (flash-style, no S x S
  * matrix).  Replaces _flash_attention_forward (modeling_nano.py:1198-1209),
  * F.scaled_dot_product_attention (:1300, cross_attention.py:310) and

@@ -848,3 +848,46 @@ def test_rope_and_silu_mul(K, dtype):
     gate, up = gu[:, :gu.shape[1] // 2], gu[:, gu.shape[1] // 2:]
     y = K.silu_mul(gate.to(DEV), up.to(DEV))
     close(y, torch.nn.functional.silu(gate.float()) * up.float(), *TOL[dtype], "silu_mul")
+
+
+# ---------------------------------------------------------------- ViT linears with fused epilogues (csrc/gemm.hip)
+@pytest.mark.parametrize("M,N,Kd", [(256, 256, 64), (512, 512, 128), (300, 260, 192), (1000, 1152, 1152),
+                                    (729 * 3, 4352, 1152), (700, 1152, 4352), (1, 256, 64), (257, 4, 64)])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_gemm_fused_epilogues(K, M, N, Kd, epi):
+    """tv_gemm_bf16_fwd against an fp64 product of the same bf16 operands: plain bias, bias + exact GELU (applied to
+    the bf16-rounded pre-activation, the rounding points of GEMM-then-tv_gelu_fwd) and accumulation into C; ragged M / N
+    tiles, one K-tile, odd numbers of K-tiles, the ViT's own shapes."""
+    g = torch.Generator().manual_seed(M + N + Kd)
+    a = (torch.randn(M, Kd, generator=g) * 0.5).bfloat16()
+    w = (torch.randn(N, Kd, generator=g) * (1.0 / math.sqrt(Kd))).bfloat16()
+    b = torch.randn(N, generator=g).bfloat16()
+    c0 = torch.randn(M, N, generator=g).bfloat16()
+    acc = a.double() @ w.double().t()
+    if epi == 2:
+        ref = acc + c0.double()
+        out = K.linear_fused(a.to(DEV), w.to(DEV), None, epilogue=2, out=c0.to(DEV).clone())
+    else:
+        pre = acc + b.double()
+        ref = torch.nn.functional.gelu(pre.float().bfloat16().double()) if epi == 1 else pre
+        out = K.linear_fused(a.to(DEV), w.to(DEV), b.to(DEV) if M % 2 else b.float().to(DEV), epilogue=epi)
+    assert out.shape == (M, N) and out.dtype == torch.bfloat16
+    # bf16 output: half an ulp of the result + the fp32 accumulation error (+ one bf16 step of the pre-activation through
+    # GELU's slope <= 1.13)
+    close(out, ref, 2.0 ** -8 * (2.2 if epi == 1 else 1.0), 1e-2 if epi == 1 else 2e-3, f"gemm epi {epi}")
+
+
+def test_gemm_fused_gelu_equals_gemm_then_gelu(K):
+    """The fused fc1 + GELU keeps the two-pass path's rounding points: identical to tv_gemm_bf16_fwd (bias) followed by
+    tv_gelu_fwd, bit for bit; strided input rows (a column slice of a wider tensor) and a strided output."""
+    g = torch.Generator().manual_seed(3)
+    wide = (torch.randn(900, 1152 + 64, generator=g) * 0.5).bfloat16().to(DEV)
+    a = wide[:, 64:]
+    w = (torch.randn(512, 1152, generator=g) * 0.03).bfloat16().to(DEV)
+    b = torch.randn(512, generator=g).to(DEV)
+    two = K.gelu(K.linear_fused(a, w, b, epilogue=0), inplace=True)
+    outw = torch.zeros(900, 600, dtype=torch.bfloat16, device=DEV)
+    one = K.linear_fused(a, w, b, epilogue=1, out=outw[:, :512])
+    assert torch.equal(one, two) and float(outw[:, 512:].abs().max()) == 0.0
+    ref = torch.nn.functional.gelu(torch.nn.functional.linear(a, w, b.bfloat16()))
+    close(one, ref.float().cpu(), 2e-2, 2e-2, "vs torch (hipBLASLt + GELU)")

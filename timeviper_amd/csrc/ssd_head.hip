@@ -109,7 +109,8 @@ struct HeadArgs {
 };
 
 // -DTV_HEAD_ABLATE: timing ablations selected by env TV_HEAD_DBG (results are wrong): 1 no quarters, 2 no x~,
-// 4 no y stores, 8 no C.B^T loads / Ydiag, 16 no prep, 32 no copies after the first chunk, 64 no epilogue arithmetic
+// 4 no y stores, 8 no C.B^T loads / Ydiag, 16 no prep, 32 no x copies after the first chunk, 64 no B / C copies after the
+// first chunk, 128 no dt loads
 #ifdef TV_HEAD_ABLATE
 #define HDBG(a, bit) ((a).dbg & (bit))
 #else
@@ -332,6 +333,7 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
     const int t = min(c * HQ + lane, L - 1);
     const bf16_t* p = dtg + (int64_t)t * a.dsl;
     unsigned r;
+    if (HDBG(a, 128)) return 0u;
     if (!UNTRACKED) r = *(const unsigned short*)p;
     else asm volatile("global_load_ushort %0, %1, off" : "=v"(r) : "v"(p) : "memory");
     return r;

@@ -248,6 +248,43 @@ def rmsnorm_fn(x, weight, bias=None, z=None, eps=1e-6, group_size=None,
     return y.view(x.shape)
 
 
+# ------------------------------------------------------------------- linears with fused epilogues
+GEMM_BIAS, GEMM_BIAS_GELU, GEMM_ACCUM = 0, 1, 2
+
+
+def linear_fused(x, weight, bias=None, epilogue: int = GEMM_BIAS, out=None):
+    """F.linear(x, weight, bias) on the hand-written bf16 GEMM (csrc/gemm.hip) with the epilogue fused:
+    GEMM_BIAS (plain), GEMM_BIAS_GELU (exact GELU of the bf16-rounded result: the timm Mlp's fc1 + act) or
+    GEMM_ACCUM (out += x @ weight.T, `out` required, bias ignored).  x (..., K) bf16 with dense rows,
+    weight (N, K) bf16; K % 64 == 0, N % 4 == 0."""
+    _gpu(x, weight, bias, out)
+    if x.dtype != torch.bfloat16 or weight.dtype != torch.bfloat16:
+        raise TimeViperHipError("linear_fused: bf16 only")
+    x2 = _rows2d(x)
+    N, Kd = weight.shape
+    if weight.stride(1) != 1:
+        weight = weight.contiguous()
+    if epilogue == GEMM_ACCUM:
+        if out is None:
+            raise TimeViperHipError("linear_fused: GEMM_ACCUM needs `out`")
+        bias = None
+    if out is None:
+        out = torch.empty(x.shape[:-1] + (N,), dtype=x.dtype, device=x.device)
+    o2 = out.view(-1, N) if out.dim() != 2 else out
+    if o2.stride(1) != 1 or o2.shape[0] != x2.shape[0]:
+        raise TimeViperHipError("linear_fused: `out` must be (rows, N) with a contiguous last dim")
+    bd = TV_F32
+    if bias is not None:
+        if bias.dtype not in (torch.float32, torch.bfloat16):
+            bias = bias.float()
+        bias = bias.contiguous()
+        bd = _dt(bias)
+    check(_capi.lib().tv_gemm_bf16_fwd(_p(x2), _p(weight), _p(bias), _p(o2), x2.shape[0], N, Kd, x2.stride(0),
+                                       weight.stride(0), o2.stride(0), int(epilogue), bd, _stream()),
+          "tv_gemm_bf16_fwd")
+    return out
+
+
 # ------------------------------------------------------------------- SSD scan
 def _row_view(t: torch.Tensor, inner: int):
     """(B, L, ...) tensor whose trailing dims are contiguous with `inner`
