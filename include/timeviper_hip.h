@@ -265,7 +265,7 @@ int tv_selective_state_update(void* state, const void* x, const void* dt,
  *               (base_vision.py:274-278 via timm; InternVideo2 Mlp vit_scale_clean.py:296-320): the
  *               rounding points of a bf16 GEMM followed by tv_gelu_fwd, bit for bit
  *            2  C = C + acc (bias ignored): output projections accumulating into the residual stream
- * bias (N) fp32 or bf16 (bias_dtype = TV_F32 / TV_BF16) or NULL.  K % 64 == 0, N % 4 == 0, rows
+ * bias (N) fp32 or bf16 (bias_dtype = TV_F32 / TV_BF16) or NULL.  K % 128 == 0, N % 4 == 0, rows
  * 16-byte aligned; any M (row tails are masked).  fp32 accumulation on v_mfma_f32_16x16x32_bf16.
  * --------------------------------------------------------------------- */
 int tv_gemm_bf16_fwd(const void* A, const void* W, const void* bias, void* C, int64_t M, int N,

@@ -149,7 +149,7 @@ def run_scan(K, x, dt, A, Bm, Cm, D, dt_bias, **kw):
                                        return_final_states=True, return_total_decay=True, **kw)
 
 
-@pytest.mark.parametrize("impl", [1, 0, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("impl", [1, 0, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("dtype,B,L,H,P,G,N", [
     (torch.float32, 1, 1024, 32, 64, 1, 16),      # BASELINE config 1
     (torch.float32, 2, 77, 8, 8, 2, 16),
@@ -194,7 +194,7 @@ def test_ssd_scan_initial_state_and_sharding(K, dtype, H, P, G, N):
     close(f1, fin_ref, rt, at)
 
 
-@pytest.mark.parametrize("impl", [2, 3, 4, 5, 6])
+@pytest.mark.parametrize("impl", [2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("B,L,H,P,G", [(1, 1000, 16, 80, 8), (2, 449, 8, 64, 2), (1, 64, 4, 48, 1),
                                        (1, 2049, 8, 80, 4), (1, 130, 4, 128, 2), (1, 65, 6, 24, 3),
                                        (1, 5000, 8, 80, 8), (1, 4100, 4, 72, 2), (2, 2500, 4, 56, 1)])
@@ -221,7 +221,7 @@ def test_ssd_scan_march_kernels(K, impl, B, L, H, P, G):
         K.ssd_scan_set_impl(0)
 
 
-@pytest.mark.parametrize("impl", [6, 4])
+@pytest.mark.parametrize("impl", [6, 4, 7])
 @pytest.mark.parametrize("regime,a_lo,a_hi,dt_mean,dt_std", [
     ("no decay to speak of", 1e-4, 1e-3, -3.0, 0.3),       # 2^-0.01 a chunk: the frame never moves, the state grows with L
     ("slow", 0.05, 0.3, -1.0, 0.5),                       # a few bits a chunk: floating steps, a re-base every few chunks
@@ -764,8 +764,8 @@ def test_conv_xbc_with_cb_fragments(K, Bsz, L, H, P, G):
         A = -(torch.rand(H, generator=g) * 15 + 1).to(DEV)
         D, dtb = torch.ones(H, device=DEV), torch.full((H,), -2.0, device=DEV)
         kw = dict(chunk_size=64, D=D, dt_bias=dtb, dt_softplus=True, return_final_states=True)
-        for impl in (3, 4, 6, 0):      # (6 = the default head-per-wave march, which consumes the fragments unmasked; 0 = auto)
-            if impl == 6 and P not in (32, 64, 80):
+        for impl in (3, 4, 6, 7, 0):   # (6 / 7 = the head-per-wave marches, which consume the fragments unmasked; 0 = auto)
+            if impl in (6, 7) and P not in (32, 64, 80):
                 continue
             K.ssd_scan_set_impl(impl)
             try:
@@ -851,13 +851,13 @@ def test_rope_and_silu_mul(K, dtype):
 
 
 # ---------------------------------------------------------------- ViT linears with fused epilogues (csrc/gemm.hip)
-@pytest.mark.parametrize("M,N,Kd", [(256, 256, 64), (512, 512, 128), (300, 260, 192), (1000, 1152, 1152),
-                                    (729 * 3, 4352, 1152), (700, 1152, 4352), (1, 256, 64), (257, 4, 64)])
+@pytest.mark.parametrize("M,N,Kd", [(256, 256, 128), (512, 512, 256), (300, 260, 384), (1000, 1152, 1152),
+                                    (729 * 3, 4352, 1152), (700, 1152, 4352), (1, 256, 128), (257, 4, 128), (5000, 1152, 640)])
 @pytest.mark.parametrize("epi", [0, 1, 2])
 def test_gemm_fused_epilogues(K, M, N, Kd, epi):
     """tv_gemm_bf16_fwd against an fp64 product of the same bf16 operands: plain bias, bias + exact GELU (applied to
     the bf16-rounded pre-activation, the rounding points of GEMM-then-tv_gelu_fwd) and accumulation into C; ragged M / N
-    tiles, one K-tile, odd numbers of K-tiles, the ViT's own shapes."""
+    tiles, two K-tiles (tail only), the ViT's own shapes."""
     g = torch.Generator().manual_seed(M + N + Kd)
     a = (torch.randn(M, Kd, generator=g) * 0.5).bfloat16()
     w = (torch.randn(N, Kd, generator=g) * (1.0 / math.sqrt(Kd))).bfloat16()

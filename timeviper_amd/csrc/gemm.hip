@@ -21,17 +21,20 @@
 //   * A wave owns rows {64 wr .. +63} of BOTH 128-row halves and columns {32 wc .. +31} of both 128-column halves
 //     (wr = wave / 4, wc = wave % 4): quadrant (mh, nh) of its 128 x 64 outputs touches only half-tiles A[mh] and W[nh],
 //     so the four phases of a K-tile need — and release — the four half-tiles one after the other:
-//         phase 1: read A0, W0 | Q(0,0)     phase 2: read W1 | Q(0,1)     phase 3: read A1 | Q(1,1)     phase 4: Q(1,0)
-//     (W0 stays in registers for phase 4), and the staging of K-tile t + 2 can start while K-tile t is still computed:
-//         phase 1 of t: W1(t+1)   phase 2: A1(t+1)   phase 3: A0(t+2)   phase 4: W0(t+2)
-//     each 4 phases ahead of its first read; a counted s_waitcnt vmcnt(8) per phase keeps four half-tiles in flight
-//     across the barriers (never a drain inside the loop).
+//         phase 1: read A0 | Q(0,0)   phase 2: read W1 | Q(0,1)   phase 3: read A1 | Q(1,1)   phase 4: read W0(t+1) | Q(1,0)
+//     (W0 of a K-tile is read one phase early into a second register set and serves phases 1 and 4: 8 / 4 / 8 / 4
+//     fragment reads a phase instead of 12 / 4 / 8 / 0), and each half-tile buffer is busy for two phases out of eight:
+//     every phase issues ONE half-tile copy, six phases ahead of its read (phase 1 of t: A1(t+1), 2: W0(t+2), 3: A0(t+2),
+//     4: W1(t+2)); a counted s_waitcnt vmcnt(10) per phase keeps five half-tiles (80 KiB) in flight across the
+//     barriers — never a drain inside the loop.
 //   * The two wave groups wr = 0 / 1 (the two waves of each SIMD) run ONE BARRIER APART: while one group issues its 16
 //     MFMAs of a phase, the other issues the fragment reads, copies and waits of its next phase — the matrix pipe of a
 //     SIMD always has one wave feeding it (MI355X guide, "two waves per SIMD": pair matrix with memory).
 //     Rules the schedule obeys (derived in DESIGN.md section 3): data retired by the wait in phase j is read in phase
 //     j + 1 or later; a half-tile is overwritten no earlier than 2 phases after the phase of its last fragment read.
 #include <math.h>
+#include <stdlib.h>
+#include <type_traits>
 #include "ssd_common.hpp"
 
 namespace {
@@ -50,7 +53,7 @@ struct GemmArgs {
   bf16_t* C;
   int M, N, K;
   int64_t lda, ldw, ldc;
-  int tiles_m, tiles_n;
+  int tiles_m, tiles_n, group_m;
   int bias_f32;
 };
 
@@ -86,7 +89,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmArgs a) {
     const int q = ntiles / 8, r = ntiles % 8, x = id % 8;
     id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + id / 8;
   }
-  const int tm = id / a.tiles_n, tn = id % a.tiles_n;
+  // ... in bands of `gm` m-tiles, m fastest: the ~32 work-groups an XCD runs at a time cover gm x (32 / gm) tiles and
+  // share each A / W k-slab through its L2 while they march through K together
+  const int gm = a.group_m;
+  const int band = id / (gm * a.tiles_n), in_band = id % (gm * a.tiles_n);
+  const int rows_in_band = min(gm, a.tiles_m - band * gm);
+  const int tm = band * gm + in_band % rows_in_band, tn = in_band / rows_in_band;
   const int m0 = tm * BM, n0 = tn * BN;
 
   const unsigned lds0 = lds_addr_of(smem_raw);
@@ -123,12 +131,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmArgs a) {
                  : "=&s"(keep) : "v"(v0), "v"(v1), "s"(sp), "s"(dst) : "memory");
   };
 
-  // ---- fragment reads: 16 rows x 64 bytes, lane (lc = row, kq = 16-byte chunk of the k-step)
+  // ---- fragment reads: 16 rows x 64 bytes, lane (lc = row, kq = 16-byte chunk of the k-step); the LDS address of a
+  // fragment = one of four lane bases (operand side x k-step) + a compile-time offset (K-tile buffer, half, 16-row tile)
   const unsigned frag_lo = (unsigned)(lc * 128 + ((kq ^ (lc >> 1)) << 4));
-  auto ldfrag = [&](unsigned base, int ks) {
-    typedef __attribute__((address_space(3))) const bf16x8 lds_bf16x8;
-    return *(lds_bf16x8*)(size_t)(base + (frag_lo ^ (unsigned)(ks * 64)));
-  };
+  const unsigned a_b0 = lds0 + (unsigned)(wr * 64 * 128) + frag_lo, a_b1 = lds0 + (unsigned)(wr * 64 * 128) + (frag_lo ^ 64u);
+  const unsigned w_b0 = lds0 + (unsigned)(wc * 32 * 128) + frag_lo, w_b1 = lds0 + (unsigned)(wc * 32 * 128) + (frag_lo ^ 64u);
+  typedef __attribute__((address_space(3))) const bf16x8 lds_bf16x8;
+#define GEMM_LD(base, off) (*(lds_bf16x8*)(size_t)((base) + (unsigned)(off)))
 
   f32x4 acc[2][2][4][2];
 #pragma unroll
@@ -140,19 +149,50 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmArgs a) {
 #pragma unroll
         for (int n = 0; n < 2; ++n) acc[i][j][m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  bf16x8 af[4][2];          // A rows of the current m-half: [m-tile][k-step]
-  bf16x8 wf0[2][2], wf1[2][2];
+  bf16x8 af[4][2];                          // A rows of the current m-half: [m-tile][k-step]
+  bf16x8 wf0[2][2][2], wf1[2][2];           // W0 of the current and of the next K-tile (by K-tile parity), W1
 
   const int nkt = a.K / BK;
+  const int nitems = 4 * nkt;               // half-tiles in issue order: item 4 t + {0: W0, 1: A0, 2: W1, 3: A1} of K-tile t
 
-  // ---- prologue: K-tile 0 whole, A0 / W0 of K-tile 1
-  stage(0, 0, 0); stage(1, 0, 0); stage(1, 1, 0); stage(0, 1, 0);
-  if (nkt > 1) { stage(0, 0, 1); stage(1, 0, 1); GEMM_WAIT_VM(4); }
-  else GEMM_WAIT_VM(0);
+  // Copy schedule (ONE half-tile per phase, each 6 phases ahead of its read): phase g = 4 t + p (p = 1..4) READS item g —
+  // p 1: A0(t), 2: W1(t), 3: A1(t), 4: W0(t + 1), which then stays in registers for phases 1 and 4 of K-tile t + 1 — and
+  // ISSUES item g + 6 (items 0 .. 6 come from the prologue).  Item g + 6 lands in the buffer of item g - 2, read two
+  // phases ago (rule 2); the wait of phase g retires item g + 1, read one phase later (rule 1), and leaves the 5 younger
+  // half-tiles (80 KiB) in flight.
+  // item = 4 t + k, k a COMPILE-TIME constant at every call (0: W0, 1: A0, 2: W1, 3: A1) — the offset registers are
+  // picked statically (a run-time index would put the arrays into scratch)
+  auto issue_item = [&](int t, auto KT) __attribute__((always_inline)) {
+    constexpr int k = decltype(KT)::value;
+    stage((k & 1) ? 0 : 1, k >> 1, t);
+  };
+  auto wait_items = [&](int allow) __attribute__((always_inline)) {       // at most `allow` half-tiles stay in flight
+    if (allow >= 5) GEMM_WAIT_VM(10);
+    else if (allow == 4) GEMM_WAIT_VM(8);
+    else if (allow == 3) GEMM_WAIT_VM(6);
+    else if (allow == 2) GEMM_WAIT_VM(4);
+    else if (allow == 1) GEMM_WAIT_VM(2);
+    else GEMM_WAIT_VM(0);
+  };
+
+  // ---- prologue: items 0 .. 6; W0(0) and A0(0) have landed behind vmcnt(10)
+  {
+    using std::integral_constant;
+    issue_item(0, integral_constant<int, 0>{}); issue_item(0, integral_constant<int, 1>{});
+    issue_item(0, integral_constant<int, 2>{}); issue_item(0, integral_constant<int, 3>{});
+    issue_item(1, integral_constant<int, 0>{}); issue_item(1, integral_constant<int, 1>{});
+    issue_item(1, integral_constant<int, 2>{});
+  }
+  GEMM_WAIT_VM(10);
   __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    wf0[0][n][0] = GEMM_LD(w_b0, 2 * HALF_BYTES + n * 2048);
+    wf0[0][n][1] = GEMM_LD(w_b1, 2 * HALF_BYTES + n * 2048);
+  }
   if (wr == 1) __builtin_amdgcn_s_barrier();          // the second wave of every SIMD runs one barrier behind
 
-  // One phase = [reads + copies + wait] barrier [16 MFMAs] barrier
+  // One phase = [fragment reads + one copy + counted wait] barrier [16 MFMAs] barrier
   auto mma_quadrant = [&](int mh, int nh, const bf16x8 (&wf)[2][2]) __attribute__((always_inline)) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -166,91 +206,156 @@ __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmArgs a) {
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
   };
-  auto read_a = [&](int t, int mh) __attribute__((always_inline)) {
-    const unsigned base = lds0 + (unsigned)((t & 1) * TILE_BYTES + mh * HALF_BYTES + wr * 64 * 128);
+  // DB: K-tile buffer (t & 1); TAIL: the last two K-tiles, where the copies run out and the waits shrink
+  auto ktile = [&](int t, auto DBT, auto TAILT) __attribute__((always_inline)) {
+    constexpr int DB = decltype(DBT)::value;
+    constexpr bool TAIL = decltype(TAILT)::value;
+    constexpr int TB = DB * TILE_BYTES;
+    const int g0 = 4 * t;
+    // phase p of K-tile t (g = 4 t + p) issues item g + 6 = 4 (t + 1 + (p + 2) / 4) + (p + 2) % 4 (items 0 .. 6 came from
+    // the prologue) and waits until item g + 1 has landed: of the items issued so far, min(nitems, g + 7), the ones
+    // younger than g + 1 may stay in flight
+    auto copy_and_wait = [&](auto PT_) __attribute__((always_inline)) {
+      constexpr int p = decltype(PT_)::value;
+      const int g = g0 + p;
+      const int tt = t + 1 + (p + 2) / 4;
+      if (!TAIL) { issue_item(tt, std::integral_constant<int, (p + 2) % 4>{}); GEMM_WAIT_VM(10); }
+      else {
+        if (g + 6 < nitems) issue_item(tt, std::integral_constant<int, (p + 2) % 4>{});
+        wait_items(min(g + 7, nitems) - g - 2);
+      }
+    };
+    // ---- phase 1: A0(t)
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) af[m][ks] = ldfrag(base + m * 2048, ks);
-  };
-  auto read_w = [&](int t, int nh, bf16x8 (&wf)[2][2]) __attribute__((always_inline)) {
-    const unsigned base = lds0 + (unsigned)((t & 1) * TILE_BYTES + (2 + nh) * HALF_BYTES + wc * 32 * 128);
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) wf[n][ks] = ldfrag(base + n * 2048, ks);
-  };
-
-  for (int t = 0; t < nkt; ++t) {
-    // what the counted waits may leave in flight: 4 half-tiles in the steady state; fewer where the copies run out
-    const bool s1 = t + 1 < nkt, s2 = t + 2 < nkt;
-    // ---- phase 1: A0, W0 | copy W1(t+1)
-    read_w(t, 0, wf0);
-    __builtin_amdgcn_sched_barrier(0);
-    read_a(t, 0);
-    if (s1) stage(1, 1, t + 1);
-    if (s1) GEMM_WAIT_VM(8); else GEMM_WAIT_VM(2);                                      // retires W1(t)
+    for (int m = 0; m < 4; ++m) {
+      af[m][0] = GEMM_LD(a_b0, TB + m * 2048);
+      af[m][1] = GEMM_LD(a_b1, TB + m * 2048);
+    }
+    copy_and_wait(std::integral_constant<int, 1>{});
     __builtin_amdgcn_s_barrier();
-    mma_quadrant(0, 0, wf0);
+    mma_quadrant(0, 0, wf0[DB]);
     __builtin_amdgcn_s_barrier();
-    // ---- phase 2: W1 | copy A1(t+1)
-    read_w(t, 1, wf1);
-    if (s1) stage(0, 1, t + 1);
-    if (s1) GEMM_WAIT_VM(8); else GEMM_WAIT_VM(0);                                      // retires A1(t)
+    // ---- phase 2: W1(t)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      wf1[n][0] = GEMM_LD(w_b0, TB + 3 * HALF_BYTES + n * 2048);
+      wf1[n][1] = GEMM_LD(w_b1, TB + 3 * HALF_BYTES + n * 2048);
+    }
+    copy_and_wait(std::integral_constant<int, 2>{});
     __builtin_amdgcn_s_barrier();
     mma_quadrant(0, 1, wf1);
     __builtin_amdgcn_s_barrier();
-    // ---- phase 3: A1 | copy A0(t+2)
-    read_a(t, 1);
-    if (s2) { stage(0, 0, t + 2); GEMM_WAIT_VM(8); }                                    // retires A0(t+1); (else: phase 4 reads nothing new)
+    // ---- phase 3: A1(t)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      af[m][0] = GEMM_LD(a_b0, TB + HALF_BYTES + m * 2048);
+      af[m][1] = GEMM_LD(a_b1, TB + HALF_BYTES + m * 2048);
+    }
+    copy_and_wait(std::integral_constant<int, 3>{});
     __builtin_amdgcn_s_barrier();
     mma_quadrant(1, 1, wf1);
     __builtin_amdgcn_s_barrier();
-    // ---- phase 4: (W0 still in registers) | copy W0(t+2)
-    if (s2) { stage(1, 0, t + 2); GEMM_WAIT_VM(8); }                                    // retires W0(t+1)
-    else if (s1) GEMM_WAIT_VM(4);                                                       // A0(t+1), W0(t+1) landed; W1, A1 of t+1 in flight
+    // ---- phase 4: W0(t + 1) into the other register set (behind the last K-tile: a read of stale bytes, never used)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      wf0[DB ^ 1][n][0] = GEMM_LD(w_b0, (TILE_BYTES - TB) + 2 * HALF_BYTES + n * 2048);
+      wf0[DB ^ 1][n][1] = GEMM_LD(w_b1, (TILE_BYTES - TB) + 2 * HALF_BYTES + n * 2048);
+    }
+    copy_and_wait(std::integral_constant<int, 4>{});
     __builtin_amdgcn_s_barrier();
-    mma_quadrant(1, 0, wf0);
+    mma_quadrant(1, 0, wf0[DB]);
     __builtin_amdgcn_s_barrier();
+  };
+  {
+    using std::integral_constant;
+    int t = 0;
+    for (; t + 3 < nkt; t += 2) {       // phases g <= 4 (nkt - 3) + 4: item g + 7 exists, 5 half-tiles in flight
+      ktile(t, integral_constant<int, 0>{}, integral_constant<bool, false>{});
+      ktile(t + 1, integral_constant<int, 1>{}, integral_constant<bool, false>{});
+    }
+    // the last two K-tiles (the launcher takes an even number of K-tiles: t is even here)
+    ktile(t, integral_constant<int, 0>{}, integral_constant<bool, true>{});
+    ktile(t + 1, integral_constant<int, 1>{}, integral_constant<bool, true>{});
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();          // barrier counts match again
 
-  // ---- epilogue: lane holds, for (mh, nh, m-tile, n-tile), columns n = .. + 4 kq + 0..3 of row m = .. + lc
+  // ---- epilogue.  A lane holds, for (mh, nh, m-tile, n-tile), columns .. + 4 kq + 0..3 of row .. + lc.  Two m-tiles at a
+  // time: v_permlane16_swap exchanges the odd 16-lane rows of one register with the even rows of the other, after which a
+  // lane holds 8 CONSECUTIVE columns (16 n-tile + 8 (kq >> 1) + 0..7) of row 16 (m-tile + (kq & 1)) + lc: 16-byte loads of
+  // C / stores instead of 8-byte ones (the epilogue is bound by the issue of its stores, MI355X guide T21).
   typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-  typedef unsigned u32x2e __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x4e __attribute__((ext_vector_type(4)));
+  const int row_in_pair = 16 * (kq & 1) + lc, col_in_tile = 8 * (kq >> 1);
 #pragma unroll
   for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
-      const int col = n0 + 128 * nh + 32 * wc + 16 * n + 4 * kq;
-      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      const int col = n0 + 128 * nh + 32 * wc + 16 * n + col_in_tile;
+      float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       if (EPI != EPI_ACCUM && a.bias && col < a.N) {
-        if (a.bias_f32) bv = *(const f32x4*)((const float*)a.bias + col);
-        else {
-          const bf16x4 b4 = *(const bf16x4*)((const bf16_t*)a.bias + col);
-          bv = f32x4{(float)b4[0], (float)b4[1], (float)b4[2], (float)b4[3]};
+        if (a.bias_f32) {
+          const f32x4 b0 = *(const f32x4*)((const float*)a.bias + col);
+          const f32x4 b1 = col + 4 < a.N ? *(const f32x4*)((const float*)a.bias + col + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { bv[r] = b0[r]; bv[4 + r] = b1[r]; }
+        } else {
+          const bf16x4 b0 = *(const bf16x4*)((const bf16_t*)a.bias + col);
+          const bf16x4 b1 = col + 4 < a.N ? *(const bf16x4*)((const bf16_t*)a.bias + col + 4) : bf16x4{};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { bv[r] = (float)b0[r]; bv[4 + r] = (float)b1[r]; }
         }
       }
 #pragma unroll
       for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          const int row = m0 + 128 * mh + 64 * wr + 16 * m + lc;
+        for (int mp = 0; mp < 4; mp += 2) {
+          float v[8];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[mh][nh][mp][n][r]),
+                                                             __float_as_uint(acc[mh][nh][mp + 1][n][r]), false, false);
+            v[r] = __uint_as_float(sw[0]);
+            v[4 + r] = __uint_as_float(sw[1]);
+          }
+          const int row = m0 + 128 * mh + 64 * wr + 16 * mp + row_in_pair;
           if (row >= a.M || col >= a.N) continue;
           bf16_t* cp = a.C + (int64_t)row * a.ldc + col;
-          f32x4 v = acc[mh][nh][m][n];
+          const bool whole = col + 8 <= a.N && (a.ldc % 8 == 0) && (((uintptr_t)a.C & 15) == 0);       // 16-byte piece inside the row
           if (EPI == EPI_ACCUM) {
-            const bf16x4 c4 = *(const bf16x4*)cp;
-            v = f32x4{v[0] + (float)c4[0], v[1] + (float)c4[1], v[2] + (float)c4[2], v[3] + (float)c4[3]};
+            if (whole) {
+              const bf16x8 c8 = *(const bf16x8*)cp;
+#pragma unroll
+              for (int r = 0; r < 8; ++r) v[r] += (float)c8[r];
+            } else {
+              const bf16x4 c4 = *(const bf16x4*)cp;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] += (float)c4[r];
+              if (col + 4 < a.N) {
+                const bf16x4 d4 = *(const bf16x4*)(cp + 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[4 + r] += (float)d4[r];
+              }
+            }
           } else {
-            v = f32x4{v[0] + bv[0], v[1] + bv[1], v[2] + bv[2], v[3] + bv[3]};
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] += bv[r];
           }
           if (EPI == EPI_BIAS_GELU) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = gelu_erf_f((float)(bf16_t)v[r]);       // the GEMM's own bf16 rounding first
+            for (int r = 0; r < 8; ++r) v[r] = gelu_erf_f((float)(bf16_t)v[r]);       // the GEMM's own bf16 rounding first
           }
-          const bf16x2 p01 = {(bf16_t)v[0], (bf16_t)v[1]}, p23 = {(bf16_t)v[2], (bf16_t)v[3]};
-          *(u32x2e*)cp = u32x2e{__builtin_bit_cast(unsigned, p01), __builtin_bit_cast(unsigned, p23)};
+          u32x4e o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bf16x2 pk = {(bf16_t)v[2 * r], (bf16_t)v[2 * r + 1]};
+            o[r] = __builtin_bit_cast(unsigned, pk);
+          }
+          if (whole) *(u32x4e*)cp = o;
+          else {
+            typedef unsigned u32x2e __attribute__((ext_vector_type(2)));
+            *(u32x2e*)cp = u32x2e{o[0], o[1]};
+            if (col + 4 < a.N) *(u32x2e*)(cp + 4) = u32x2e{o[2], o[3]};
+          }
         }
     }
 }
@@ -275,9 +380,9 @@ extern "C" int tv_gemm_bf16_fwd(const void* A, const void* W, const void* bias, 
   TV_CHECK_ARG(A && W && C, "gemm: null pointer");
   TV_CHECK_ARG(epilogue >= 0 && epilogue <= 2, "gemm: epilogue %d", epilogue);
   TV_CHECK_ARG(bias == nullptr || bias_dtype == TV_F32 || bias_dtype == TV_BF16, "gemm: bias dtype %d", bias_dtype);
-  if (K % BK || N % 4 || lda % 8 || ldw % 8 || ldc % 4 || ((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)C & 7) ||
+  if (K % (2 * BK) || N % 4 || lda % 8 || ldw % 8 || ldc % 4 || ((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)C & 7) ||
       ((uintptr_t)bias & 15))
-    TV_UNSUPPORTED("gemm: K must be a multiple of %d, N of 4, rows 16-byte aligned (K %d N %d lda %lld ldw %lld ldc %lld)", BK, K, N,
+    TV_UNSUPPORTED("gemm: K must be a multiple of %d, N of 4, rows 16-byte aligned (K %d N %d lda %lld ldw %lld ldc %lld)", 2 * BK, K, N,
                    (long long)lda, (long long)ldw, (long long)ldc);
   if (M > (1ll << 31) - BM || 256 * lda * 2 >= (1ll << 31) || 256 * ldw * 2 >= (1ll << 31))
     TV_UNSUPPORTED("gemm: sizes beyond the 32-bit offsets of the copies");
@@ -286,6 +391,11 @@ extern "C" int tv_gemm_bf16_fwd(const void* A, const void* W, const void* bias, 
   a.M = (int)M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.ldc = ldc;
   a.tiles_m = (int)((M + BM - 1) / BM); a.tiles_n = (N + BN - 1) / BN;
   a.bias_f32 = bias_dtype == TV_F32;
+  {
+    static const int gm_env = [] { const char* e = getenv("TV_GEMM_GROUP_M"); return e ? atoi(e) : 0; }();     // dev tool
+    a.group_m = gm_env > 0 ? gm_env : 8;
+    if (a.group_m > a.tiles_m) a.group_m = a.tiles_m;
+  }
   if ((int64_t)a.tiles_m * a.tiles_n >= (1ll << 31)) TV_UNSUPPORTED("gemm: too many tiles");
   hipStream_t st = (hipStream_t)stream;
   switch (epilogue) {

@@ -45,7 +45,7 @@ struct CorrArgs {
   // the stand-alone operator has one range = the whole sequence (nsegc 1, first_seg 0, seg_chunks = nchunks)
   int nsegc, first_seg, seg_chunks;
   int64_t tot_stride;              // elements between the (b, h) rows of `tot`
-  int64_t ysb, ysl, dsb, dsl, csb, csl, csg;
+  int64_t ysb, ysl, dsb, dsl, dsh, csb, csl, csg;      // dsh: elements between the heads of dt (1: token-major rows)
   int softplus, group_map;
   float dt_min, dt_max;
 };
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void ssd_chunk_decay_kernel(CorrArgs a) {
   const int h = blockIdx.y * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (h >= a.H) return;
   const int t = c * CQ + lane;
-  const float d = t < a.L ? disc_dt(a, (float)a.dt[(int64_t)b * a.dsb + (int64_t)t * a.dsl + h], h) : 0.f;
+  const float d = t < a.L ? disc_dt(a, (float)a.dt[(int64_t)b * a.dsb + (int64_t)t * a.dsl + (int64_t)h * a.dsh], h) : 0.f;
   const float s = wave_sum(d);
   if (lane == 0) a.tot[((int64_t)b * a.H + h) * a.nchunks + c] = s * a.A[h] * 1.4426950408889634f;
 }
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void ssd_correct_kernel(CorrArgs a) {
     }
   }
   const float Ah = a.A[h] * 1.4426950408889634f;
-  const bf16_t* dp = a.dt + (int64_t)b * a.dsb + (int64_t)tbeg * a.dsl + h;
+  const bf16_t* dp = a.dt + (int64_t)b * a.dsb + (int64_t)tbeg * a.dsl + (int64_t)h * a.dsh;
   const bf16_t* cp = a.Cm + (int64_t)b * a.csb + (int64_t)g * a.csg + (int64_t)tbeg * a.csl;
   bf16_t* yp = a.y + (int64_t)b * a.ysb + (int64_t)tbeg * a.ysl + (int64_t)h * a.P;
   const int nvec = a.P / 8;                          // 16-byte pieces per y row
@@ -276,7 +276,7 @@ int tv_ssd_correct_launch(void* y, const void* dt, const void* A, const void* Cm
   a.nchunks = (seqlen + CQ - 1) / CQ;
   a.tot = (float*)workspace;
   a.pre = a.tot + (size_t)batch * nheads * a.nchunks;
-  a.ysb = ysb; a.ysl = ysl; a.dsb = dsb; a.dsl = dsl; a.csb = csb; a.csl = csl; a.csg = csg;
+  a.ysb = ysb; a.ysl = ysl; a.dsb = dsb; a.dsl = dsl; a.dsh = 1; a.csb = csb; a.csl = csl; a.csg = csg;
   a.softplus = dt_softplus; a.group_map = group_map; a.dt_min = dt_min; a.dt_max = dt_max;
   a.tot_stride = a.nchunks;
   a.state16 = nullptr;
@@ -305,7 +305,7 @@ int tv_ssd_correct_all_launch(void* y, const void* dt, const void* A, const void
                               const float* seg_state, const float* seg_decay, float* final_state,
                               float* total_decay, const float* chunk_tot, int batch, int seqlen, int nheads,
                               int headdim, int ngroups, int nseg, int seg_chunks, int64_t ysb, int64_t ysl,
-                              int64_t dsb, int64_t dsl, int64_t csb, int64_t csl, int64_t csg, int dt_softplus,
+                              int64_t dsb, int64_t dsl, int64_t dsh, int64_t csb, int64_t csl, int64_t csg, int dt_softplus,
                               float dt_min, float dt_max, int group_map, void* workspace, hipStream_t st) {
   CorrArgs a;
   a.y = (bf16_t*)y; a.dt = (const bf16_t*)dt; a.Cm = (const bf16_t*)Cm;
@@ -317,7 +317,7 @@ int tv_ssd_correct_all_launch(void* y, const void* dt, const void* A, const void
   a.state16 = sin16;
   a.tot = const_cast<float*>(chunk_tot);
   a.tot_stride = a.nchunks;
-  a.ysb = ysb; a.ysl = ysl; a.dsb = dsb; a.dsl = dsl; a.csb = csb; a.csl = csl; a.csg = csg;
+  a.ysb = ysb; a.ysl = ysl; a.dsb = dsb; a.dsl = dsl; a.dsh = dsh; a.csb = csb; a.csl = csl; a.csg = csg;
   a.softplus = dt_softplus; a.group_map = group_map; a.dt_min = dt_min; a.dt_max = dt_max;
   int nsegc = 0;                     // segments that exist (a short sequence may leave the last ones empty)
   for (int s = 1; s < nseg; ++s) if ((int64_t)s * seg_chunks < a.nchunks) ++nsegc;

@@ -46,7 +46,7 @@ int tv_ssd_correct_all_launch(void* y, const void* dt, const void* A, const void
                               const float* seg_state, const float* seg_decay, float* final_state,
                               float* total_decay, const float* chunk_tot, int batch, int seqlen, int nheads,
                               int headdim, int ngroups, int nseg, int seg_chunks, int64_t ysb, int64_t ysl,
-                              int64_t dsb, int64_t dsl, int64_t csb, int64_t csl, int64_t csg, int dt_softplus,
+                              int64_t dsb, int64_t dsl, int64_t dsh, int64_t csb, int64_t csl, int64_t csg, int dt_softplus,
                               float dt_min, float dt_max, int group_map, void* workspace, hipStream_t st);
 
 #ifndef TV_HEAD_PIN
@@ -102,7 +102,7 @@ struct HeadArgs {
   float *seg_state, *seg_decay, *chunk_tot;     // nseg > 1: per-segment results for the combine / correction pass
   int nseg, seg_chunks;
   int L, H, P, G, nchunks;
-  int64_t xsb, xsl, dsb, dsl, bsb, bsl, bsg, csb, csl, csg, ysb, ysl;
+  int64_t xsb, xsl, dsb, dsl, dsh, bsb, bsl, bsg, csb, csl, csg, ysb, ysl;      // dsh: elements between the heads of dt
   int softplus, group_map;
   float dt_min, dt_max;
   int dbg;
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
   const float Ah = a.A[h];
   const float bias = a.dt_bias ? a.dt_bias[h] : 0.f;
   const float Dh = a.D ? a.D[h] : 0.f;
-  const bf16_t* dtg = a.dt + (int64_t)b * a.dsb + (int64_t)t_first * a.dsl + h;
+  const bf16_t* dtg = a.dt + (int64_t)b * a.dsb + (int64_t)t_first * a.dsl + (int64_t)h * a.dsh;
   float decay_total = 0.f;
   float E = 0.f;                  // X = 2^E X'
   // raw dt of chunk c, lane = token (rows clamped): a load the compiler does not track (the step's counted waits cover it)
@@ -841,6 +841,31 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
   }
 }
 
+// dt (B, L, H) -> (B, H, Lp) with Lp = 64 nchunks: a wave (= a head) then reads the 64 tokens of a chunk as ONE 128-byte line.
+// Token-major, the same 64 values are 2 bytes each out of 64 lines that all 128 heads share; the lines are evicted between
+// the visits of the work-groups that want them and came from HBM 11 times over (profiles/r04_ssd_scan_read_attribution.json:
+// 0.48 GB of reads for 0.04 GB of dt at 164 k tokens).  grid (nchunks, B), 256 threads; tokens past L are written as zeros.
+__global__ __launch_bounds__(256) void ssd_dt_transpose_kernel(const bf16_t* __restrict__ dt, bf16_t* __restrict__ out, int L, int H,
+                                                               int64_t dsb, int64_t dsl, int64_t lp) {
+  __shared__ unsigned short tile[HQ][130];            // [token][head], row padded against bank conflicts of the column reads
+  const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const unsigned short* src = (const unsigned short*)dt + (int64_t)b * dsb;
+  for (int h0 = 0; h0 < H; h0 += 128) {
+    const int nh = min(128, H - h0);
+    for (int i = tid; i < HQ * 128; i += 256) {
+      const int t = i >> 7, h = i & 127, tok = c * HQ + t;
+      tile[t][h] = (tok < L && h < nh) ? src[(int64_t)tok * dsl + h0 + h] : (unsigned short)0;
+    }
+    __syncthreads();
+    unsigned short* dst = (unsigned short*)out + ((int64_t)b * H + h0) * lp + (int64_t)c * HQ;
+    for (int i = tid; i < 128 * HQ; i += 256) {
+      const int h = i >> 6, t = i & 63;
+      if (h < nh) dst[(int64_t)h * lp + t] = tile[t][h];
+    }
+    __syncthreads();
+  }
+}
+
 // heads of one group per work-group: 4, 2 or 1
 int pick_nw(int hpg) { return hpg % 4 == 0 ? 4 : hpg % 2 == 0 ? 2 : 1; }
 
@@ -855,7 +880,7 @@ int pick_segments(int batch, int nheads, int nchunks) {
 }
 
 struct HeadLayout {
-  size_t cb, seg_state, seg_decay, ctot, corr, total;
+  size_t cb, seg_state, seg_decay, ctot, corr, dtt, total;
   int nseg, seg_chunks;
 };
 HeadLayout head_layout(int batch, int seqlen, int nheads, int headdim, int ngroups) {
@@ -870,7 +895,8 @@ HeadLayout head_layout(int batch, int seqlen, int nheads, int headdim, int ngrou
   l.seg_decay = l.seg_state + (l.nseg > 1 ? up(l.nseg * st) : 0);
   l.ctot = l.seg_decay + (l.nseg > 1 ? up((size_t)l.nseg * batch * nheads * sizeof(float)) : 0);
   l.corr = l.ctot + (l.nseg > 1 ? up((size_t)batch * nheads * nchunks * sizeof(float)) : 0);
-  l.total = l.corr + (l.nseg > 1 ? up(tv_ssd_correct_all_workspace_bytes(batch, nheads, (int)nchunks, l.nseg, headdim)) : 0);
+  l.dtt = l.corr + (l.nseg > 1 ? up(tv_ssd_correct_all_workspace_bytes(batch, nheads, (int)nchunks, l.nseg, headdim)) : 0);
+  l.total = l.dtt + up((size_t)batch * nheads * nchunks * HQ * sizeof(bf16_t));       // dt, head-major
   return l;
 }
 
@@ -887,6 +913,14 @@ hipError_t launch_head(const HeadArgs& a, dim3 grid, hipStream_t st) {
 }
 
 }  // namespace
+
+// dt (B, L, H) -> head-major (B, H, 64 nchunks) for the march kernels of this file and of ssd_pair.hip
+void tv_ssd_dt_transpose_launch(const void* dt, void* out, int batch, int seqlen, int nheads, int64_t dsb, int64_t dsl,
+                                hipStream_t st) {
+  const int nchunks = (seqlen + HQ - 1) / HQ;
+  ssd_dt_transpose_kernel<<<dim3(nchunks, batch), 256, 0, st>>>((const bf16_t*)dt, (bf16_t*)out, seqlen, nheads, dsb, dsl,
+                                                               (int64_t)nchunks * HQ);
+}
 
 #ifdef TV_HEAD_STAMP
 extern "C" int tv_ssd_head_debug_stamps(unsigned long long* out) {
@@ -935,6 +969,14 @@ int tv_ssd_head_launch(const void* x, const void* dt, const void* A, const void*
   a.seg_state = lay.nseg > 1 ? (float*)(wsb + lay.seg_state) : nullptr;
   a.seg_decay = lay.nseg > 1 ? (float*)(wsb + lay.seg_decay) : nullptr;
   a.chunk_tot = lay.nseg > 1 ? (float*)(wsb + lay.ctot) : nullptr;
+  // dt head-major into the workspace (one small launch: 2 x 42 MB at 164 k tokens); both the march and the correction read it
+  {
+    const int64_t lp = (int64_t)a.nchunks * HQ;
+    bf16_t* dtt = (bf16_t*)(wsb + lay.dtt);
+    ssd_dt_transpose_kernel<<<dim3(a.nchunks, batch), 256, 0, st>>>((const bf16_t*)dt, dtt, seqlen, nheads, dsb, dsl, lp);
+    a.dt = dtt; dt = dtt;
+    dsb = (int64_t)nheads * lp; dsl = 1; a.dsh = lp;
+  }
   a.xsb = xsb; a.xsl = xsl; a.dsb = dsb; a.dsl = dsl; a.bsb = bsb; a.bsl = bsl; a.bsg = bsg;
   a.csb = csb; a.csl = csl; a.csg = csg; a.ysb = ysb; a.ysl = ysl;
   a.softplus = dt_softplus; a.group_map = group_map; a.dt_min = dt_min; a.dt_max = dt_max;
@@ -967,7 +1009,7 @@ int tv_ssd_head_launch(const void* x, const void* dt, const void* A, const void*
   if (a.nseg > 1) {
     const int rc = tv_ssd_correct_all_launch(y, dt, A, Cm, dt_bias, a.seg_state, a.seg_decay, (float*)final_state,
                                              (float*)total_decay, a.chunk_tot, batch, seqlen, nheads, headdim,
-                                             ngroups, a.nseg, a.seg_chunks, ysb, ysl, dsb, dsl, csb, csl, csg,
+                                             ngroups, a.nseg, a.seg_chunks, ysb, ysl, dsb, dsl, a.dsh, csb, csl, csg,
                                              dt_softplus, dt_min, dt_max, group_map, wsb + lay.corr, st);
     if (rc != TV_OK) return rc;
   }

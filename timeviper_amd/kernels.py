@@ -256,7 +256,7 @@ def linear_fused(x, weight, bias=None, epilogue: int = GEMM_BIAS, out=None):
     """F.linear(x, weight, bias) on the hand-written bf16 GEMM (csrc/gemm.hip) with the epilogue fused:
     GEMM_BIAS (plain), GEMM_BIAS_GELU (exact GELU of the bf16-rounded result: the timm Mlp's fc1 + act) or
     GEMM_ACCUM (out += x @ weight.T, `out` required, bias ignored).  x (..., K) bf16 with dense rows,
-    weight (N, K) bf16; K % 64 == 0, N % 4 == 0."""
+    weight (N, K) bf16; K % 128 == 0, N % 4 == 0."""
     _gpu(x, weight, bias, out)
     if x.dtype != torch.bfloat16 or weight.dtype != torch.bfloat16:
         raise TimeViperHipError("linear_fused: bf16 only")
@@ -417,7 +417,8 @@ def selective_state_update(state, x, dt, A, B, C, D=None, z=None, dt_bias=None,
 def ssd_scan_set_impl(impl: int) -> None:
     """0 auto (= 6 where it applies, else 4, 3, 2, 1), 1 generic fp32-recurrence kernel, 2 MFMA chunk-march kernel,
     3 MFMA slice march with two work-groups per head, 4 / 5 whole-head slice march (8 / 12 waves) x sequence
-    segments, 6 head-per-wave march (ssd_head.hip).  Process-global (dev tools and tests)."""
+    segments, 6 head-per-wave march (ssd_head.hip), 7 the same with a head's columns split over two waves, two waves per SIMD
+    (ssd_pair.hip, head_dim 80; elsewhere 6).  Process-global (dev tools and tests)."""
     _capi.lib().tv_ssd_scan_set_impl(int(impl))
 
 
