@@ -460,6 +460,37 @@ def test_qwen2_prefill_plus_decode_matches_full_prefill():
     assert relerr(o1[:, -1], full[:, 68]) < 3e-2 and relerr(o2[:, -1], full[:, 69]) < 3e-2
 
 
+def test_vit_mlp_fused_fc1_gelu_matches_the_two_pass_path(monkeypatch):
+    """From 4 096 rows on the SigLIP / InternVideo2 MLPs run fc1 + bias + exact GELU as ONE kernel (tv_gemm_bf16_fwd,
+    epilogue 1): same result as hipBLASLt + tv_gelu_fwd up to the accumulation order of the GEMM, and as the plain
+    nn.Linear / nn.GELU modules (grad mode)."""
+    from timeviper_amd.model.vit.siglip import Mlp
+    from timeviper_amd.model.vit.internvideo2 import Mlp as IvMlp
+    from timeviper_amd import kernels as K
+    torch.manual_seed(3)
+    for mlp, dim in ((Mlp(1152, 4304), 1152), (IvMlp(1408, 6144), 1408)):
+        mlp = mlp.to(DEV).bfloat16().eval()
+        with torch.no_grad():
+            for p_ in mlp.parameters():
+                p_.normal_(0, 0.03 if p_.dim() > 1 else 0.05)
+        x = torch.randn(8, 729, dim, device=DEV).bfloat16()
+        calls = []
+        orig = K.linear_fused
+        monkeypatch.setattr(K, "linear_fused", lambda *a, **kw: (calls.append(kw.get("epilogue")), orig(*a, **kw))[1])
+        with torch.no_grad():
+            fused = mlp(x)
+        assert calls == [K.GEMM_BIAS_GELU], calls
+        monkeypatch.setenv("TV_VIT_FUSED_FC1", "0")
+        with torch.no_grad():
+            two_pass = mlp(x)
+        assert calls == [K.GEMM_BIAS_GELU]
+        monkeypatch.delenv("TV_VIT_FUSED_FC1")
+        monkeypatch.setattr(K, "linear_fused", orig)
+        with torch.enable_grad():
+            plain = mlp.fc2(torch.nn.functional.gelu(mlp.fc1(x))).detach()
+        assert relerr(fused, two_pass) < 4e-3 and relerr(fused, plain) < 4e-3
+
+
 def test_vit_zero_padded_gemms_match_plain_linears():
     """so400m widths (qkv N = 3456, MLP hidden 4304 — not multiples of the 256-wide GEMM tile): the
     inference path runs zero-padded weight copies; it must equal the plain nn.Linear path, follow

@@ -393,7 +393,9 @@ extern "C" int tv_gemm_bf16_fwd(const void* A, const void* W, const void* bias, 
   a.bias_f32 = bias_dtype == TV_F32;
   {
     static const int gm_env = [] { const char* e = getenv("TV_GEMM_GROUP_M"); return e ? atoi(e) : 0; }();     // dev tool
-    a.group_m = gm_env > 0 ? gm_env : 8;
+    // measured at 1 492 992 rows (bench_gemm_fused.py, gm 1 / 4 / 8 / 16 / 32): N 4 352: 15.8 / 15.3 / 15.7 / 15.4 / 15.7 ms,
+    // N 3 584: 10.9 / 10.4 / 10.5 / 10.8 / 11.5, N 1 152 (K 4 352): 12.8 / 12.6 / 12.5 / 13.3 / 16.0
+    a.group_m = gm_env > 0 ? gm_env : (a.tiles_n >= 8 ? 4 : 8);
     if (a.group_m > a.tiles_m) a.group_m = a.tiles_m;
   }
   if ((int64_t)a.tiles_m * a.tiles_n >= (1ll << 31)) TV_UNSUPPORTED("gemm: too many tiles");

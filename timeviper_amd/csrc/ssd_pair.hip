@@ -126,46 +126,81 @@ __device__ __forceinline__ void pair_march(const PairArgs& a, PairSmem& sm, unsi
   const bf16_t* Cg = a.Cm + (int64_t)b * a.csb + (int64_t)g * a.csg + (int64_t)t_first * a.csl;
   // piece k of this wave (k = 0, 1) = token rows 8 wave + 4 k + (lane >> 4), 16-byte chunk lane & 15 of the row, stored
   // swizzled: B chunk ^ 4 (row & 3) (the same for both k), C chunk ^ (row & 15) (k flips bit 2 of it)
-  const int bc_row0 = 8 * wave + (lane >> 4);
-  const unsigned off_b0 = (unsigned)((bc_row0 * a.bsl + ((lane & 15) ^ (4 * ((lane >> 4) & 3))) * 8) * 2);
-  const unsigned off_c0 = (unsigned)((bc_row0 * a.csl + ((lane & 15) ^ (bc_row0 & 15)) * 8) * 2);
+  // (the lane offsets of the copies are re-derived from the lane index at every use: kept across the step they are the
+  // first registers the allocator spills, and a reload in front of a copy waits for every copy before it)
   auto issue_bc = [&](int c, int which) __attribute__((always_inline)) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int bc_row0 = 8 * wave + (ln >> 4);
+    const unsigned off_b0 = (unsigned)((bc_row0 * (int)a.bsl + ((ln & 15) ^ (4 * ((ln >> 4) & 3))) * 8) * 2);
+    const unsigned off_c0 = (unsigned)((bc_row0 * (int)a.csl + ((ln & 15) ^ (bc_row0 & 15)) * 8) * 2);
     const int t0 = c * HQ;
     const bf16_t* Tc = which ? Cg + (int64_t)t0 * a.csl : Bg + (int64_t)t0 * a.bsl;
     const int64_t rl = which ? a.csl : a.bsl;
     const unsigned dst = (which ? lds_ct : lds_bt) + (c & 1) * (HQ * HN * 2) + 2 * wave * 1024;
-    if (t0 + HQ <= L) {       // whole chunk: the scalar base moves by 4 rows for the second piece
-      glds16(uniform_ptr(Tc), which ? off_c0 : off_b0, dst);
-      glds16(uniform_ptr(Tc + 4 * rl), which ? (off_c0 ^ 64u) : off_b0, dst + 1024);
+    if (t0 + HQ <= L) {       // whole chunk: ONE M0 set-up and scalar base for the two pieces; the instruction offset of the
+                              // second moves the source and the LDS address alike, its lane offset makes up the difference
+      const unsigned r4 = (unsigned)(4 * rl * 2) - 1024u;      // bytes of 4 rows in memory - bytes of a piece (rows >= 256 B)
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
+                   "global_load_lds_dwordx4 %1, %3\n\t"
+                   "global_load_lds_dwordx4 %2, %3 offset:1024\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(which ? off_c0 : off_b0), "v"((which ? (off_c0 ^ 64u) : off_b0) + r4),
+                     "s"(uniform_ptr(Tc)), "s"(dst) : "memory");
       return;
     }
     const void* sp = uniform_ptr(Tc);
 #pragma unroll
     for (int k = 0; k < 2; ++k) {      // last, partial chunk: rows past the end repeat the last row (finite)
-      const int row = 8 * wave + 4 * k + (lane >> 4);
+      const int row = 8 * wave + 4 * k + (ln >> 4);
       const int rr = min(row, L - 1 - t0);
-      const int cg = which ? (lane & 15) ^ (row & 15) : (lane & 15) ^ (4 * (row & 3));
+      const int cg = which ? (ln & 15) ^ (row & 15) : (ln & 15) ^ (4 * (row & 3));
       glds16(sp, (unsigned)((rr * rl + cg * 8) * 2), dst + k * 1024);
     }
   };
 
   // ------------------------------------------------------------------ x: the head's tile, copied by its two waves
   const bf16_t* xg = a.x + (int64_t)b * a.xsb + (int64_t)t_first * a.xsl + (int64_t)h * HP;
-  const int x_lrow = lane / NPC;
   constexpr int XI0 = CT0 == 0 ? 0 : 6, XI1 = CT0 == 0 ? 6 : NXI;       // this wave's copy instructions
-  const unsigned x_off = (unsigned)((x_lrow * a.xsl + (lane % NPC) * 8) * 2);
+  // whole chunks: instruction k = XI0 + j copies rows RPI k .. of the tile; groups of up to four share ONE M0 set-up and scalar
+  // base, the instruction offset (j RPI XROW <= 2 880) moves both addresses, lane offset j dj makes up the difference
   auto issue_x = [&](int c) __attribute__((always_inline)) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int x_lrow = ln / NPC;
+    const unsigned x_off = (unsigned)((x_lrow * (int)a.xsl + (ln - NPC * x_lrow) * 8) * 2);
     const int t0 = c * HQ;
     const bf16_t* xc = xg + (int64_t)t0 * a.xsl;
     const unsigned dst = lds_xr + (c & 1) * XSLOT;
-    const bool whole = t0 + HQ <= L;
+    if (t0 + HQ <= L) {
+      const unsigned dj = (unsigned)(RPI * a.xsl * 2) - (unsigned)(RPI * XROW);
+      const void* s0 = uniform_ptr(xc + (int64_t)RPI * XI0 * a.xsl);
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\t"
+                   "global_load_lds_dwordx4 %1, %5\n\t"
+                   "global_load_lds_dwordx4 %2, %5 offset:%7\n\t"
+                   "global_load_lds_dwordx4 %3, %5 offset:%8\n\t"
+                   "global_load_lds_dwordx4 %4, %5 offset:%9\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(x_off), "v"(x_off + dj), "v"(x_off + 2 * dj), "v"(x_off + 3 * dj), "s"(s0),
+                     "s"(dst + RPI * XI0 * XROW), "n"(RPI * XROW), "n"(2 * RPI * XROW), "n"(3 * RPI * XROW) : "memory");
+      const void* s1 = uniform_ptr(xc + (int64_t)RPI * (XI0 + 4) * a.xsl);
+      if (CT0 == 0)       // instructions 4, 5
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %3\n\t"
+                     "global_load_lds_dwordx4 %2, %3 offset:%5\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(x_off), "v"(x_off + dj), "s"(s1), "s"(dst + RPI * (XI0 + 4) * XROW), "n"(RPI * XROW) : "memory");
+      else                // instruction 10: rows 60 .. 63 only (lanes 0 .. 39): nothing lands behind the tile
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_mov_b32 exec_hi, 0xff\n\ts_nop 1\n\t"
+                     "global_load_lds_dwordx4 %1, %2\n\ts_mov_b64 exec, -1\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(x_off), "s"(s1), "s"(dst + RPI * (XI0 + 4) * XROW) : "memory");
+      return;
+    }
+    const void* sp = uniform_ptr(xc);
 #pragma unroll
-    for (int k = XI0; k < XI1; ++k) {
-      // whole chunk: the scalar base moves by RPI rows per instruction; else the rows are clamped per lane
-      const void* sp = uniform_ptr(whole ? xc + (int64_t)RPI * k * a.xsl : xc);
-      const unsigned vo = whole ? x_off : (unsigned)((min(RPI * k + x_lrow, L - 1 - t0) * a.xsl + (lane % NPC) * 8) * 2);
+    for (int k = XI0; k < XI1; ++k) {      // last, partial chunk: the rows are clamped per lane
+      const unsigned vo = (unsigned)((min(RPI * k + x_lrow, L - 1 - t0) * (int)a.xsl + (ln - NPC * x_lrow) * 8) * 2);
       if (k < NXI - 1) glds16(sp, vo, dst + RPI * k * XROW);
-      else {      // the last instruction: rows 60 .. 63 only (lanes 0 .. 39), nothing lands behind the tile
+      else {
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_mov_b32 exec_hi, 0xff\n\ts_nop 1\n\t"
                      "global_load_lds_dwordx4 %1, %2\n\ts_mov_b64 exec, -1\n\ts_mov_b32 m0, %0"
@@ -277,6 +312,19 @@ __device__ __forceinline__ void pair_march(const PairArgs& a, PairSmem& sm, unsi
       }
     asm volatile("s_nop 7" ::: "memory");
   };
+  auto zero_state = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int ct = 0; ct < PT; ++ct)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        // (read-write operands: the tile stays in its registers — a fresh output would meet the untouched tile in a PHI)
+        float e0 = xacc[ct][i][0], e1 = xacc[ct][i][1], e2 = xacc[ct][i][2], e3 = xacc[ct][i][3];
+        asm volatile("v_accvgpr_write_b32 %0, 0\n\tv_accvgpr_write_b32 %1, 0\n\tv_accvgpr_write_b32 %2, 0\n\tv_accvgpr_write_b32 %3, 0"
+                     : "+a"(e0), "+a"(e1), "+a"(e2), "+a"(e3));
+        xacc[ct][i] = f32x4{e0, e1, e2, e3};
+      }
+    asm volatile("s_nop 7" ::: "memory");
+  };
   const int c_lo = lc * 256;
   const int c_z = (kq ^ lc) << 4;
   const int bsw = q4 << 6;
@@ -305,6 +353,46 @@ __device__ __forceinline__ void pair_march(const PairArgs& a, PairSmem& sm, unsi
     const unsigned char* Bt = reinterpret_cast<const unsigned char*>(sm.bt[c & 1]);
     const unsigned char* Ct = reinterpret_cast<const unsigned char*>(sm.ct[c & 1]);
     const unsigned xt = lds_xr + (c & 1) * XSLOT;
+    bf16x8 cbv[NFR];                // causal C.B^T of this chunk (global, L2: requested first, used after pass 1)
+#pragma unroll
+    for (int f = 0; f < NFR; ++f) cbv[f] = *(const bf16x8*)(cbg + (int64_t)c * CBE + f * 512 + lane * 8);
+    // The step runs as THREE passes so that few fragments are live at a time (112 vector registers a wave):
+    //   1. Yoff^T = X'^T C^T for the four quarters of 32 state rows (C fragments + ONE bf16 copy of 32 state rows of one
+    //      column tile live), 2. x~ = w_s x, then X' += B^T x~ quarter by quarter, 3. Ydiag with the causal C.B^T.
+    f32x4 yo[PT][4];              // (first written by quarter 0's MFMAs: C = 0)
+    unsigned dt_raw = dt_next;
+    {
+      bf16x8 cf[2][4];
+      {
+        const unsigned char* cp = Ct + xad(c_z, 0, c_lo);
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) cf[0][ti] = ld8(cp + ti * 4096);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (q < 3) {        // the next quarter's C fragments are in flight under this quarter's MFMAs
+          const unsigned char* cp = Ct + xad(c_z, 64 * (q + 1), c_lo);
+#pragma unroll
+          for (int ti = 0; ti < 4; ++ti) cf[(q + 1) & 1][ti] = ld8(cp + ti * 4096);
+        }
+#pragma unroll
+        for (int ct = 0; ct < PT; ++ct) {
+          const bf16x8 sb = snap_tile(q, ct);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) yo[ct][j] = mfma16(sb, cf[q & 1][j], q == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : yo[ct][j]);
+        }
+        // copies of the next chunk between the quarters: B, C behind quarter 0 / 1, x behind quarter 2
+        if (more && q == 0) issue_bc(c + 1, 0);
+        if (more && q == 1) issue_bc(c + 1, 1);
+        if (more && q == 2) issue_x(c + 1);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- order of the rest of the step: Ydiag and the y stores FIRST (they need x~ and C.B^T, not the new state; the stores
+    // then have the whole state update to drain, and the y accumulators are free during it), the state update last
+    float ev[4];                    // 2^(cs_t + E) of this lane's token 16 ti + lc
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) ev[ti] = vec.ecs[16 * ti + lc];
     // ---- x~ = w_s x on the fragments (element j of fragment ks is token 32 ks + 8 kq + j)
     bf16x8 xw[PT][2];
     auto make_xw = [&](const float* wsrc) __attribute__((always_inline)) {
@@ -330,78 +418,52 @@ __device__ __forceinline__ void pair_march(const PairArgs& a, PairSmem& sm, unsi
           xw[ct][ks] = __builtin_bit_cast(bf16x8, o);
         }
     };
-    make_xw(vec.wts);
-    // ---- Yoff^T = X'^T C^T and X' += B^T x~, in quarters of 32 state rows
-    f32x4 yo[PT][4];
-#pragma unroll
-    for (int ct = 0; ct < PT; ++ct)
-#pragma unroll
-      for (int ti = 0; ti < 4; ++ti) yo[ct][ti] = f32x4{0.f, 0.f, 0.f, 0.f};
-    unsigned dt_raw = dt_next;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      // fragments are read just ahead of their MFMA groups (two groups' worth in flight), not a quarter at a time: the
-      // whole wave lives in 112 vector registers
-      const unsigned char* cp = Ct + xad(c_z, 64 * q, c_lo);
-      const unsigned char* bp = Bt + xad(bsw, 64 * q, b_lo);
-      bf16x8 sb[PT];
-      bf16x8 cfa[2], cfb[2];
-      cfa[0] = ld8(cp);
-      cfa[1] = ld8(cp + 4096);
-#pragma unroll
-      for (int ct = 0; ct < PT; ++ct) sb[ct] = snap_tile(q, ct);
-      cfb[0] = ld8(cp + 2 * 4096);
-      cfb[1] = ld8(cp + 3 * 4096);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-#pragma unroll
-        for (int ct = 0; ct < PT; ++ct) yo[ct][j] = mfma16(sb[ct], cfa[j], yo[ct][j]);
-        // copies of the next chunk between the MFMA groups: B, C in quarter 0, x in quarter 1
-        if (more && q == 0 && j == 1) issue_bc(c + 1, 0);
-        if (more && q == 1 && j == 1) issue_x(c + 1);
-      }
-      bf16x4 bta[4];              // B^T for state tile 2 q (k-steps 0, 1)
-      bta[0] = tr4(bp);
-      bta[1] = tr4(bp + 1024);
-      bta[2] = tr4(bp + 8192);
-      bta[3] = tr4(bp + 8192 + 1024);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-#pragma unroll
-        for (int ct = 0; ct < PT; ++ct) yo[ct][2 + j] = mfma16(sb[ct], cfb[j], yo[ct][2 + j]);
-        if (more && q == 0 && j == 1) issue_bc(c + 1, 1);
-      }
-      bf16x4 btb[4];              // ... and for state tile 2 q + 1
-      btb[0] = tr4(bp + 8);
-      btb[1] = tr4(bp + 8 + 1024);
-      btb[2] = tr4(bp + 8 + 8192);
-      btb[3] = tr4(bp + 8 + 8192 + 1024);
-#pragma unroll
-      for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const bf16x8 bfrag = ii == 0 ? cat4(bta[2 * ks], bta[2 * ks + 1]) : cat4(btb[2 * ks], btb[2 * ks + 1]);
-          if (ks == 0 && reset_step) {
-#pragma unroll
-            for (int ct = 0; ct < PT; ++ct) xacc[ct][2 * q + ii] = mfma16(bfrag, xw[ct][0], f32x4{0.f, 0.f, 0.f, 0.f});
-          } else {
-#pragma unroll
-            for (int ct = 0; ct < PT; ++ct) xacc[ct][2 * q + ii] = mfma16(bfrag, xw[ct][ks], xacc[ct][2 * q + ii]);
-          }
+    // x~ for Ydiag: the frame the accumulators are in (a reset step's state update runs in the NEW frame: x~ is formed again
+    // below; a standard step takes raw x here)
+    // Ydiag + the y stores are written out once per kind of step (as a lambda inlined into both branches): joined behind
+    // the branch, the scaled accumulators, the masked fragments and the raw x fragments of a standard step would meet the
+    // floating step's registers in PHIs — copies of 48 accumulation registers and spills of state tiles
+    const bool full = (c + 1) * HQ <= L;
+    auto ydiag_and_store = [&](const float (&ev)[4]) __attribute__((always_inline)) {
+      // ---- Ydiag on top of Yoff, same frame: the A operand is x~, the B operand the causal C.B^T fragment
+  #pragma unroll
+      for (int ti = 0; ti < 4; ++ti)
+  #pragma unroll
+        for (int ct = 0; ct < PT; ++ct) yo[ct][ti] = mfma16(xw[ct][0], cbv[ti == 0 ? 0 : ti == 1 ? 1 : ti == 2 ? 2 : 4], yo[ct][ti]);
+  #pragma unroll
+      for (int ti = 2; ti < 4; ++ti)
+  #pragma unroll
+        for (int ct = 0; ct < PT; ++ct) yo[ct][ti] = mfma16(xw[ct][1], cbv[ti == 2 ? 3 : 5], yo[ct][ti]);
+      // ---- y = row factor * accumulators + D x, rounded to bf16 and stored (16 bytes a lane: two t-tiles joined)
+      const f32x2 dh2 = {Dh, Dh};
+      auto finish = [&](int ct, int ti) __attribute__((always_inline)) {
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        typedef __attribute__((address_space(3))) const u32x2 lds_u32x2;
+        const u32x2 xr = *(lds_u32x2*)(size_t)(xt + xv_lo + 32 * (CT0 + ct) + ti * (16 * XROW));
+        const f32x2 e2 = {ev[ti], ev[ti]};
+        const f32x2 y0 = __builtin_elementwise_fma(f32x2{yo[ct][ti][0], yo[ct][ti][1]}, e2, dh2 * f32x2{bf16_lo(xr[0]), bf16_hi(xr[0])});
+        const f32x2 y1 = __builtin_elementwise_fma(f32x2{yo[ct][ti][2], yo[ct][ti][3]}, e2, dh2 * f32x2{bf16_lo(xr[1]), bf16_hi(xr[1])});
+        const bf16x2 p01 = {(bf16_t)y0[0], (bf16_t)y0[1]}, p23 = {(bf16_t)y1[0], (bf16_t)y1[1]};
+        return u32x2{__builtin_bit_cast(unsigned, p01), __builtin_bit_cast(unsigned, p23)};
+      };
+  #pragma unroll
+      for (int tp = 0; tp < 4; tp += 2) {
+        const void* yrow = uniform_ptr(ygs + (int64_t)(c * HQ + 16 * tp) * a.ysl);
+        const bool ok = full || c * HQ + 16 * tp + 16 * (kq & 1) + lc < L;
+  #pragma unroll
+        for (int ct = 0; ct < PT; ++ct) {
+          const u32x2 ya = finish(ct, tp), yb = finish(ct, tp + 1);
+          const auto s0 = __builtin_amdgcn_permlane16_swap(ya[0], yb[0], false, false);
+          const auto s1 = __builtin_amdgcn_permlane16_swap(ya[1], yb[1], false, false);
+          const u32x4v w = {s0[0], s1[0], s0[1], s1[1]};
+          if (ok) asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3" :: "v"(yoff16), "v"(w), "s"(yrow), "n"(32 * (CT0 + ct)) : "memory");
         }
-      if (PREP && q == 2) dt_next = load_dt(min(c + 2, nchunks - 1));
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    float ev[4];                    // 2^(cs_t + E) of this lane's token 16 ti + lc
-#pragma unroll
-    for (int ti = 0; ti < 4; ++ti) ev[ti] = vec.ecs[16 * ti + lc];
-    // ---- the vectors of the NEXT chunk, into the other parity's slot (nobody reads that slot during this step)
-    if (PREP && more) prep(c + 1, dt_raw);
-    bf16x8 cbv[NFR];                // causal C.B^T of this chunk
-#pragma unroll
-    for (int f = 0; f < NFR; ++f) cbv[f] = *(const bf16x8*)(cbg + (int64_t)c * CBE + f * 512 + lane * 8);
-    if (reset_step && !ustd_step) make_xw(vec.wtd);       // Ydiag shares the accumulators with Yoff: the OLD frame's weights
-    if (ustd_step) {
+      }
+    };
+    if (!ustd_step) {
+      make_xw(reset_step ? vec.wtd : vec.wts);
+      ydiag_and_store(ev);
+    } else {
       // ---- standard step: (1) the accumulators get their row factor now, (2) the per-head mask replaces C.B^T in its
       // registers, (3) the A operand becomes the raw x fragments (ssd_head.hip)
 #pragma unroll
@@ -448,28 +510,49 @@ __device__ __forceinline__ void pair_march(const PairArgs& a, PairSmem& sm, unsi
           }
           cbv[f] = __builtin_bit_cast(bf16x8, o);
         };
-        float eD[8], eS[8], fac[8];
+        // one fragment at a time, every factor formed where it is used (few live registers: the diagonal factors of a lane
+        // half are formed twice rather than kept)
         const int sA = 8 * kq;
-        diag(16 * hi + lc, sA, eD);
+        {
+          float fac[8];
+          diag(16 * hi + lc, sA, fac);                          // fragment (0,0): diagonal block for hi = 0, nothing for hi = 1
 #pragma unroll
-        for (int j = 0; j < 8; ++j) fac[j] = hi ? 0.f : eD[j];
-        apply(0, fac);
-        sepf(16 + lc, sA & 15, eS);
+          for (int j = 0; j < 8; ++j) fac[j] = hi ? 0.f : fac[j];
+          apply(0, fac);
+        }
+        {
+          float fac[8], eS[8];
+          diag(16 * hi + lc, sA, fac);                          // fragment (1,0): diagonal block for hi = 1, separable for hi = 0
+          sepf(16 + lc, sA & 15, eS);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) fac[j] = hi ? eD[j] : eS[j];
-        apply(1, fac);
-        sepf(32 + lc, 16 + sA, eS);
-        apply(2, eS);
-        diag(32 + 16 * hi + lc, 32 + sA, eD);
+          for (int j = 0; j < 8; ++j) fac[j] = hi ? fac[j] : eS[j];
+          apply(1, fac);
+        }
+        {
+          float eS[8];
+          sepf(32 + lc, 16 + sA, eS);                            // blocks (2,0), (2,1)
+          apply(2, eS);
+        }
+        {
+          float fac[8];
+          diag(32 + 16 * hi + lc, 32 + sA, fac);                // fragment (2,1) diagonal for hi = 0
 #pragma unroll
-        for (int j = 0; j < 8; ++j) fac[j] = hi ? 0.f : eD[j];
-        apply(3, fac);
-        sepf(48 + lc, 48 + sA, eS);
-        apply(4, eS);
-        sepf(48 + lc, 48 + 32 + (sA & 15), eS);
+          for (int j = 0; j < 8; ++j) fac[j] = hi ? 0.f : fac[j];
+          apply(3, fac);
+        }
+        {
+          float eS[8];
+          sepf(48 + lc, 48 + sA, eS);                            // blocks (3,0), (3,1)
+          apply(4, eS);
+        }
+        {
+          float fac[8], eS[8];
+          diag(32 + 16 * hi + lc, 32 + sA, fac);                // fragment (3,1): diagonal for hi = 1, separable (3,2) for hi = 0
+          sepf(48 + lc, 48 + 32 + (sA & 15), eS);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) fac[j] = hi ? eD[j] : eS[j];
-        apply(5, fac);
+          for (int j = 0; j < 8; ++j) fac[j] = hi ? fac[j] : eS[j];
+          apply(5, fac);
+        }
       }
 #pragma unroll
       for (int ct = 0; ct < PT; ++ct)
@@ -477,44 +560,43 @@ __device__ __forceinline__ void pair_march(const PairArgs& a, PairSmem& sm, unsi
         for (int ks = 0; ks < 2; ++ks) xw[ct][ks] = read_xf(xt, ct, ks);
 #pragma unroll
       for (int ti = 0; ti < 4; ++ti) ev[ti] = 1.f;
-    }
-    // ---- Ydiag on top of Yoff, same frame: the A operand is x~, the B operand the causal C.B^T fragment
-#pragma unroll
-    for (int ti = 0; ti < 4; ++ti)
-#pragma unroll
-      for (int ct = 0; ct < PT; ++ct) yo[ct][ti] = mfma16(xw[ct][0], cbv[ti == 0 ? 0 : ti == 1 ? 1 : ti == 2 ? 2 : 4], yo[ct][ti]);
-#pragma unroll
-    for (int ti = 2; ti < 4; ++ti)
-#pragma unroll
-      for (int ct = 0; ct < PT; ++ct) yo[ct][ti] = mfma16(xw[ct][1], cbv[ti == 2 ? 3 : 5], yo[ct][ti]);
-    // ---- y = row factor * accumulators + D x, rounded to bf16 and stored (16 bytes a lane: two t-tiles joined)
-    const f32x2 dh2 = {Dh, Dh};
-    const bool full = (c + 1) * HQ <= L;
-    auto finish = [&](int ct, int ti) __attribute__((always_inline)) {
-      typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-      typedef __attribute__((address_space(3))) const u32x2 lds_u32x2;
-      const u32x2 xr = *(lds_u32x2*)(size_t)(xt + xv_lo + 32 * (CT0 + ct) + ti * (16 * XROW));
-      const f32x2 e2 = {ev[ti], ev[ti]};
-      const f32x2 y0 = __builtin_elementwise_fma(f32x2{yo[ct][ti][0], yo[ct][ti][1]}, e2, dh2 * f32x2{bf16_lo(xr[0]), bf16_hi(xr[0])});
-      const f32x2 y1 = __builtin_elementwise_fma(f32x2{yo[ct][ti][2], yo[ct][ti][3]}, e2, dh2 * f32x2{bf16_lo(xr[1]), bf16_hi(xr[1])});
-      const bf16x2 p01 = {(bf16_t)y0[0], (bf16_t)y0[1]}, p23 = {(bf16_t)y1[0], (bf16_t)y1[1]};
-      return u32x2{__builtin_bit_cast(unsigned, p01), __builtin_bit_cast(unsigned, p23)};
-    };
-#pragma unroll
-    for (int tp = 0; tp < 4; tp += 2) {
-      const void* yrow = uniform_ptr(ygs + (int64_t)(c * HQ + 16 * tp) * a.ysl);
-      const bool ok = full || c * HQ + 16 * tp + 16 * (kq & 1) + lc < L;
-#pragma unroll
-      for (int ct = 0; ct < PT; ++ct) {
-        const u32x2 ya = finish(ct, tp), yb = finish(ct, tp + 1);
-        const auto s0 = __builtin_amdgcn_permlane16_swap(ya[0], yb[0], false, false);
-        const auto s1 = __builtin_amdgcn_permlane16_swap(ya[1], yb[1], false, false);
-        const u32x4v w = {s0[0], s1[0], s0[1], s1[1]};
-        if (ok) asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3" :: "v"(yoff16), "v"(w), "s"(yrow), "n"(32 * (CT0 + ct)) : "memory");
-      }
+      ydiag_and_store(ev);
     }
     // (the copies of the next chunk were issued long ago; this step's y stores stay in flight where the chunk is whole)
-    if (full) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PT) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (reset_step) make_xw(vec.wts);        // (standard steps are reset steps: their weights onto zero)
+    // ---- X' += B^T x~; a reset step drops the old state first (every bf16 copy of it has been taken in pass 1)
+    if (reset_step) zero_state();
+    {
+      bf16x4 bt[2][8];            // B^T of a quarter: state tiles 2 q (0..3) and 2 q + 1 (4..7), k-steps 0, 1
+      auto read_bt = [&](int q, bf16x4 (&d)[8]) __attribute__((always_inline)) {
+        const unsigned char* bp = Bt + xad(bsw, 64 * q, b_lo);
+        d[0] = tr4(bp);
+        d[1] = tr4(bp + 1024);
+        d[2] = tr4(bp + 8192);
+        d[3] = tr4(bp + 8192 + 1024);
+        d[4] = tr4(bp + 8);
+        d[5] = tr4(bp + 8 + 1024);
+        d[6] = tr4(bp + 8 + 8192);
+        d[7] = tr4(bp + 8 + 8192 + 1024);
+      };
+      read_bt(0, bt[0]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (q < 3) read_bt(q + 1, bt[(q + 1) & 1]);
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 bfrag = cat4(bt[q & 1][4 * ii + 2 * ks], bt[q & 1][4 * ii + 2 * ks + 1]);
+#pragma unroll
+            for (int ct = 0; ct < PT; ++ct) xacc[ct][2 * q + ii] = mfma16(bfrag, xw[ct][ks], xacc[ct][2 * q + ii]);
+          }
+        if (PREP && q == 2) dt_next = load_dt(min(c + 2, nchunks - 1));
+      }
+    }
+    if (PREP && more) prep(c + 1, dt_raw);
+    if (full) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PT + (PREP ? 1 : 0)) : "memory");      // (+ the dt load behind the stores)
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }

@@ -19,6 +19,8 @@ backbone.py:63-91 loads it.
 """
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
@@ -127,6 +129,13 @@ class Mlp(nn.Module):
         self.fc2 = nn.Linear(hidden, dim)
 
     def forward(self, x):
+        w1 = self.fc1.weight
+        # fc1 + bias + exact GELU in one kernel where the hand-written GEMM applies (csrc/gemm.hip, see
+        # model/vit/siglip.py::Mlp._fused_fc1); vit_scale_clean.py:296-320
+        if (x.is_cuda and x.dtype == torch.bfloat16 and w1.dtype == torch.bfloat16 and not torch.is_grad_enabled()
+                and w1.shape[1] % 128 == 0 and w1.shape[0] % 4 == 0 and x.numel() // x.shape[-1] >= 4096
+                and os.environ.get("TV_VIT_FUSED_FC1", "1") != "0"):
+            return self.fc2(K.linear_fused(x, w1, self.fc1.bias, epilogue=K.GEMM_BIAS_GELU))
         return self.fc2(K.gelu(self.fc1(x), inplace=True))
 
 
