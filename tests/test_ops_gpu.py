@@ -891,3 +891,43 @@ def test_gemm_fused_gelu_equals_gemm_then_gelu(K):
     assert torch.equal(one, two) and float(outw[:, 512:].abs().max()) == 0.0
     ref = torch.nn.functional.gelu(torch.nn.functional.linear(a, w, b.bfloat16()))
     close(one, ref.float().cpu(), 2e-2, 2e-2, "vs torch (hipBLASLt + GELU)")
+
+
+# ---------------------------------------------------------------- ragged / padded batches (flash_attention_class.py:59-91)
+def test_flash_attn_varlen_ragged_and_key_padding_mask(K):
+    """flash_attn_varlen_qkvpacked_func on a ragged batch (runs of equal and unequal lengths, an empty sequence) against the
+    oracle sequence by sequence, and the FlashAttention module's key_padding_mask path (unpad -> kernel -> pad with
+    zeros) against the same."""
+    from timeviper_amd.model.vit.internvideo2 import FlashAttention
+    g = torch.Generator().manual_seed(4)
+    H, D = 4, 88
+    lens = [257, 257, 100, 0, 33, 33, 33, 300]
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32)
+    qkv = torch.randn(int(cu[-1]), 3, H, D, generator=g).bfloat16()
+    out = K.flash_attn_varlen_qkvpacked_func(qkv.to(DEV), cu.to(DEV), max(lens))
+    assert out.shape == (int(cu[-1]), H, D)
+    for i, n in enumerate(lens):
+        if n == 0:
+            continue
+        x = qkv[int(cu[i]):int(cu[i + 1])].float()[None]
+        ref, _ = R.attention_ref(x[:, :, 0], x[:, :, 1], x[:, :, 2], False)
+        close(out[int(cu[i]):int(cu[i + 1])], ref[0], 2e-2, 1e-2, f"sequence {i}")
+    # padded batch: (B, S) mask with holes in the middle and at the ends
+    B, S = 3, 120
+    mask = torch.rand(B, S, generator=g) > 0.3
+    mask[1, :10] = False
+    mask[2, 100:] = False
+    x = torch.randn(B, S, 3, H, D, generator=g).bfloat16()
+    o, _ = FlashAttention()(x.to(DEV), key_padding_mask=mask.to(DEV))
+    assert o.shape == (B, S, H, D)
+    for b in range(B):
+        keep = mask[b].nonzero().flatten()
+        xb = x[b, keep].float()[None]
+        ref, _ = R.attention_ref(xb[:, :, 0], xb[:, :, 1], xb[:, :, 2], False)
+        close(o[b, keep], ref[0], 2e-2, 1e-2, f"batch {b}")
+        assert float(o[b, ~mask[b]].abs().max()) == 0.0
+    # already unpadded input through the module, causal
+    o2, _ = FlashAttention()(qkv.to(DEV), cu_seqlens=cu.to(DEV), max_s=max(lens), causal=True)
+    x0 = qkv[:257].float()[None]
+    ref, _ = R.attention_ref(x0[:, :, 0], x0[:, :, 1], x0[:, :, 2], True)
+    close(o2[:257], ref[0], 2e-2, 1e-2, "causal, first sequence")

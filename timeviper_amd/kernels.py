@@ -547,16 +547,34 @@ def scaled_dot_product_attention(query, key, value, attn_mask=None, dropout_p=0.
 
 def flash_attn_varlen_qkvpacked_func(qkv, cu_seqlens, max_seqlen, dropout_p=0.0,
                                      softmax_scale=None, causal=False, **kwargs):
-    """qkv (nnz, 3, H, D) with equal-length sequences (what the InternVideo2 ViT
-    produces: every clip has the same token count, flash_attention_class.py:59)."""
+    """qkv (nnz, 3, H, D), sequences [cu_seqlens[i], cu_seqlens[i+1]) (flash_attention_class.py:59-66, :68-91).
+    Equal lengths — what the InternVideo2 ViT produces: every clip has the same token count — are ONE launch over
+    a (nseq, len) view; a ragged batch (the `key_padding_mask` / `unpad_input` path of the reference) runs one launch per
+    run of consecutive equal-length sequences.  The boundaries are read on the host: one device-to-host copy of
+    `cu_seqlens` when it lives on the GPU (the reference's unpad_input synchronises for max_seqlen as well)."""
     nnz, three, H, D = qkv.shape
     assert three == 3
     nseq = cu_seqlens.numel() - 1
-    if nnz != nseq * max_seqlen:
-        raise TimeViperHipError("flash_attn_varlen_qkvpacked_func: ragged batches unsupported")
-    x = qkv.view(nseq, max_seqlen, 3, H, D)
-    o = flash_attn_func(x[:, :, 0], x[:, :, 1], x[:, :, 2], dropout_p, softmax_scale, causal)
-    return o.reshape(nnz, H, D)
+    if nseq > 0 and nnz == nseq * max_seqlen:                # equal lengths: no host read
+        x = qkv.view(nseq, max_seqlen, 3, H, D)
+        o = flash_attn_func(x[:, :, 0], x[:, :, 1], x[:, :, 2], dropout_p, softmax_scale, causal)
+        return o.reshape(nnz, H, D)
+    cu = [int(v) for v in cu_seqlens.tolist()]
+    if cu[0] != 0 or cu[-1] != nnz or any(b < a for a, b in zip(cu, cu[1:])):
+        raise TimeViperHipError("flash_attn_varlen_qkvpacked_func: cu_seqlens must rise from 0 to nnz")
+    out = torch.empty((nnz, H, D), dtype=qkv.dtype, device=qkv.device)
+    i = 0
+    while i < nseq:
+        n = cu[i + 1] - cu[i]
+        j = i + 1
+        while j < nseq and cu[j + 1] - cu[j] == n:
+            j += 1
+        if n > 0:
+            x = qkv[cu[i]:cu[j]].view(j - i, n, 3, H, D)
+            out[cu[i]:cu[j]] = flash_attn_func(x[:, :, 0], x[:, :, 1], x[:, :, 2], dropout_p, softmax_scale,
+                                               causal).reshape((j - i) * n, H, D)
+        i = j
+    return out
 
 
 # --------------------------------------------------------------- token ops

@@ -121,6 +121,41 @@ class Attention(nn.Module):
         return self.proj(o.reshape(B, N, C))
 
 
+class FlashAttention(nn.Module):
+    """flash_attention_class.py:16-110: softmax attention on packed qkv.  qkv (B, S, 3, H, D) with an optional
+    `key_padding_mask` (B, S) bool (True = token present: the padded positions are removed before the kernel and come
+    back as zeros, `unpad_input` / `pad_input`), or already unpadded (nnz, 3, H, D) with `cu_seqlens` / `max_s`.
+    The tower itself calls the kernel on equal-length clips; this module keeps the reference's entry point whole."""
+
+    def __init__(self, softmax_scale=None, attention_dropout=0.0, device=None, dtype=None):
+        super().__init__()
+        self.softmax_scale, self.dropout_p = softmax_scale, attention_dropout
+
+    def forward(self, qkv, key_padding_mask=None, causal=False, cu_seqlens=None, max_s=None, need_weights=False):
+        assert not need_weights
+        assert qkv.dtype in (torch.float16, torch.bfloat16)
+        if self.training and self.dropout_p:
+            raise NotImplementedError("attention dropout is a training feature")
+        if cu_seqlens is not None:
+            assert max_s is not None
+            return K.flash_attn_varlen_qkvpacked_func(qkv, cu_seqlens, max_s, 0.0, softmax_scale=self.softmax_scale,
+                                                      causal=causal), None
+        B, S = qkv.shape[:2]
+        if key_padding_mask is None:
+            o = K.flash_attn_func(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], 0.0, self.softmax_scale, causal)
+            return o, None
+        nheads, hd = qkv.shape[-2], qkv.shape[-1]
+        lens = key_padding_mask.sum(dim=-1, dtype=torch.int32)
+        idx = torch.nonzero(key_padding_mask.flatten(), as_tuple=False).flatten()       # unpad_input
+        cu = torch.nn.functional.pad(torch.cumsum(lens, 0, dtype=torch.int32), (1, 0))
+        x = qkv.reshape(B * S, 3, nheads, hd)[idx]
+        o_un = K.flash_attn_varlen_qkvpacked_func(x, cu, int(lens.max()), 0.0, softmax_scale=self.softmax_scale,
+                                                  causal=causal)
+        out = torch.zeros((B * S, nheads, hd), dtype=qkv.dtype, device=qkv.device)     # pad_input
+        out[idx] = o_un
+        return out.view(B, S, nheads, hd), None
+
+
 class Mlp(nn.Module):
     def __init__(self, dim, hidden):
         super().__init__()
