@@ -302,8 +302,9 @@ def test_ssd_scan_strided_views(K):
     close(fin, fin_ref, 2e-2, 2e-2)
 
 
-def test_selective_state_update(K):
-    B, H, P, G, N = 2, 8, 16, 2, 32
+@pytest.mark.parametrize("B,H,P,G,N", [(2, 8, 16, 2, 32), (1, 128, 80, 8, 128), (3, 4, 24, 1, 16), (1, 6, 7, 3, 256),
+                                       (1, 4, 8, 2, 40)])      # (N = 40: the thread-per-row kernel)
+def test_selective_state_update(K, B, H, P, G, N):
     ins = scan_inputs(B, 1, H, P, G, N, 9, torch.bfloat16)
     x, dt, A, Bm, Cm, D, dt_bias = ins
     g = torch.Generator().manual_seed(2)

@@ -167,6 +167,54 @@ __global__ void state_update_kernel(float* __restrict__ state, const T* __restri
   y[((int64_t)b * H + h) * P + p] = from_f32<T>(fmaf(D ? D[h] : 0.f, xr, acc));
 }
 
+// Decode step for d_state = 4 LPR (16 .. 256): LPR lanes share a state row (16 bytes = 4 fp32 each), a wave covers
+// 64 / LPR rows per load — coalesced 512-byte rows instead of one thread walking its row with 4-byte loads at a 512-byte
+// lane stride (36.7 us for the 2 x 5.2 MB of a Nano layer = 3.6 % of the HBM roofline, bench.py --config decode, round 4).
+template <typename T, int LPR>
+__global__ __launch_bounds__(256) void state_update_rows_kernel(float* __restrict__ state, const T* __restrict__ x,
+                                                                const T* __restrict__ dt, const float* __restrict__ A,
+                                                                const T* __restrict__ Bm, const T* __restrict__ Cm,
+                                                                const float* __restrict__ D, const float* __restrict__ dt_bias,
+                                                                T* __restrict__ y, int H, int P, int G, int softplus,
+                                                                int64_t rows_total) {
+  constexpr int N = 4 * LPR, RPW = 64 / LPR, ITERS = 4;
+  const int lane = threadIdx.x & 63;
+  const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int sub = lane / LPR, ln = lane % LPR;
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const int64_t row = (w * ITERS + it) * RPW + sub;          // (b, h, p) flattened
+    const bool ok = row < rows_total;
+    float part = 0.f, xr = 0.f, dh = 0.f;
+    if (ok) {
+      const int64_t bh = row / P;
+      const int h = (int)(bh % H);
+      const int64_t b = bh / H;
+      const int g = h / (H / G);
+      float d = to_f32(dt[bh]) + (dt_bias ? dt_bias[h] : 0.f);
+      if (softplus) d = softplus_f(d);
+      const float dec = expf(d * A[h]);
+      xr = to_f32(x[row]);
+      dh = D ? D[h] : 0.f;
+      const float xv = d * xr;
+      f32x4* sp = (f32x4*)(state + row * N) + ln;
+      const f32x4 sv = *sp;
+      const T* Br = Bm + (b * G + g) * N + 4 * ln;
+      const T* Cr = Cm + (b * G + g) * N + 4 * ln;
+      f32x4 v;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[i] = fmaf(dec, sv[i], xv * to_f32(Br[i]));
+        part = fmaf(v[i], to_f32(Cr[i]), part);
+      }
+      *sp = v;
+    }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+    if (ok && ln == 0) y[row] = from_f32<T>(fmaf(dh, xr, part));
+  }
+}
+
 }  // namespace
 
 // called from ssd_scan.hip (dispatcher)
@@ -204,8 +252,31 @@ extern "C" int tv_selective_state_update(void* state, const void* x, const void*
   TV_CHECK_ARG(batch > 0 && nheads > 0 && headdim > 0 && ngroups > 0 && dstate > 0 &&
                    nheads % ngroups == 0,
                "selective_state_update: bad sizes");
-  dim3 grid((headdim + 63) / 64, nheads, batch);
   hipStream_t s = (hipStream_t)stream;
+  // d_state 16 / 32 / 64 / 128 / 256 with 16-byte aligned rows: lanes share a row (coalesced); anything else: a thread per row
+  const int lpr = dstate / 4;
+  if (dstate % 4 == 0 && (lpr == 4 || lpr == 8 || lpr == 16 || lpr == 32 || lpr == 64) && (((uintptr_t)state) & 15) == 0) {
+    const int64_t rows = (int64_t)batch * nheads * headdim;
+    const int64_t rows_per_block = 4 * 4 * (64 / lpr);          // 4 waves x 4 iterations x rows per wave-instruction
+    const dim3 rgrid((unsigned)((rows + rows_per_block - 1) / rows_per_block));
+#define TV_SUR(T, LPR)                                                                                        \
+    state_update_rows_kernel<T, LPR><<<rgrid, 256, 0, s>>>((float*)state, (const T*)x, (const T*)dt,          \
+        (const float*)A, (const T*)Bm, (const T*)Cm, (const float*)D, (const float*)dt_bias, (T*)y, nheads,   \
+        headdim, ngroups, dt_softplus, rows)
+#define TV_SUR_T(T)                                                                                           \
+    switch (lpr) { case 4: TV_SUR(T, 4); break; case 8: TV_SUR(T, 8); break; case 16: TV_SUR(T, 16); break;     \
+                   case 32: TV_SUR(T, 32); break; default: TV_SUR(T, 64); break; }
+    switch (dtype) {
+      case TV_F32: TV_SUR_T(float); break;
+      case TV_BF16: TV_SUR_T(bf16_t); break;
+      case TV_F16: TV_SUR_T(f16_t); break;
+      default: TV_UNSUPPORTED("selective_state_update: dtype %d", dtype);
+    }
+#undef TV_SUR_T
+#undef TV_SUR
+    TV_LAUNCH_CHECK();
+  }
+  dim3 grid((headdim + 63) / 64, nheads, batch);
 #define TV_SU(T)                                                                              \
   state_update_kernel<T><<<grid, 64, 0, s>>>((float*)state, (const T*)x, (const T*)dt,        \
       (const float*)A, (const T*)Bm, (const T*)Cm, (const float*)D, (const float*)dt_bias,    \

@@ -84,6 +84,17 @@ int tv_ssd_correct_all_launch(void* y, const void* dt, const void* A, const void
 #ifndef TV_HEAD_FENCE
 #define TV_HEAD_FENCE 1
 #endif
+// TV_HEAD_NT: 1 = the x copies and the y stores carry the non-temporal bit — they stream through the XCD's L2 once, and
+// marking them first-to-evict keeps the B / C tiles, which the four work-groups of a (group, segment) share, resident
+// until the last of the four has fetched them
+#ifndef TV_HEAD_NT
+#define TV_HEAD_NT 1
+#endif
+#if TV_HEAD_NT
+#define TV_X_NT " nt"
+#else
+#define TV_X_NT ""
+#endif
 namespace {
 using namespace ssdk;
 
@@ -282,23 +293,23 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
     unsigned keep;
     if (n == 4)
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\t"
-                   "global_load_lds_dwordx4 %1, %5\n\t"
-                   "global_load_lds_dwordx4 %2, %5 offset:%7\n\t"
-                   "global_load_lds_dwordx4 %3, %5 offset:%8\n\t"
-                   "global_load_lds_dwordx4 %4, %5 offset:%9\n\ts_mov_b32 m0, %0"
+                   "global_load_lds_dwordx4 %1, %5" TV_X_NT "\n\t"
+                   "global_load_lds_dwordx4 %2, %5 offset:%7" TV_X_NT "\n\t"
+                   "global_load_lds_dwordx4 %3, %5 offset:%8" TV_X_NT "\n\t"
+                   "global_load_lds_dwordx4 %4, %5 offset:%9" TV_X_NT "\n\ts_mov_b32 m0, %0"
                    : "=&s"(keep) : "v"(x_off), "v"(x_off + dj), "v"(x_off + 2 * dj), "v"(vl + 3 * dj), "s"(sx), "s"(dst),
                      "n"(RPI * XROW), "n"(2 * RPI * XROW), "n"(3 * RPI * XROW) : "memory");
     else if (n == 3)
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\t"
-                   "global_load_lds_dwordx4 %1, %4\n\t"
-                   "global_load_lds_dwordx4 %2, %4 offset:%6\n\t"
-                   "global_load_lds_dwordx4 %3, %4 offset:%7\n\ts_mov_b32 m0, %0"
+                   "global_load_lds_dwordx4 %1, %4" TV_X_NT "\n\t"
+                   "global_load_lds_dwordx4 %2, %4 offset:%6" TV_X_NT "\n\t"
+                   "global_load_lds_dwordx4 %3, %4 offset:%7" TV_X_NT "\n\ts_mov_b32 m0, %0"
                    : "=&s"(keep) : "v"(x_off), "v"(x_off + dj), "v"(vl + 2 * dj), "s"(sx), "s"(dst),
                      "n"(RPI * XROW), "n"(2 * RPI * XROW) : "memory");
     else if (n == 2)
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
-                   "global_load_lds_dwordx4 %1, %3\n\t"
-                   "global_load_lds_dwordx4 %2, %3 offset:%5\n\ts_mov_b32 m0, %0"
+                   "global_load_lds_dwordx4 %1, %3" TV_X_NT "\n\t"
+                   "global_load_lds_dwordx4 %2, %3 offset:%5" TV_X_NT "\n\ts_mov_b32 m0, %0"
                    : "=&s"(keep) : "v"(x_off), "v"(vl + dj), "s"(sx), "s"(dst), "n"(RPI * XROW) : "memory");
     else
       glds16(sx, vl, dst);
@@ -318,7 +329,7 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
   const unsigned yoff0 = (unsigned)((lc * a.ysl + 4 * kq) * 2);
   unsigned yoff16 = (unsigned)(((16 * (kq & 1) + lc) * a.ysl + 8 * (kq >> 1)) * 2);     // 16-byte form (TV_HEAD_Y16)
   auto store_y_tile = [&](const void* yrow, bool ok, int ct, u32x2 v) {      // yrow: row 16 ti of the chunk, columns of this head
-    if (ok) asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3" :: "v"(yoff0), "v"(v), "s"(yrow), "n"(32 * ct) : "memory");
+    if (ok) asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3" TV_X_NT :: "v"(yoff0), "v"(v), "s"(yrow), "n"(32 * ct) : "memory");
   };
 
   // ------------------------------------------------------------------ per-chunk vectors (lane = token)
@@ -791,7 +802,7 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
         const auto s0 = __builtin_amdgcn_permlane16_swap(ya[0], yb[0], false, false);
         const auto s1 = __builtin_amdgcn_permlane16_swap(ya[1], yb[1], false, false);
         const u32x4v w = {s0[0], s1[0], s0[1], s1[1]};
-        if (ok) asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3" :: "v"(yo16), "v"(w), "s"(yrow), "n"(32 * ct) : "memory");
+        if (ok) asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3" TV_X_NT :: "v"(yo16), "v"(w), "s"(yrow), "n"(32 * ct) : "memory");
       }
     }
 #else
@@ -846,21 +857,36 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
 // the visits of the work-groups that want them and came from HBM 11 times over (profiles/r04_ssd_scan_read_attribution.json:
 // 0.48 GB of reads for 0.04 GB of dt at 164 k tokens).  grid (nchunks, B), 256 threads; tokens past L are written as zeros.
 __global__ __launch_bounds__(256) void ssd_dt_transpose_kernel(const bf16_t* __restrict__ dt, bf16_t* __restrict__ out, int L, int H,
-                                                               int64_t dsb, int64_t dsl, int64_t lp) {
-  __shared__ unsigned short tile[HQ][130];            // [token][head], row padded against bank conflicts of the column reads
+                                                               int64_t dsb, int64_t dsl, int64_t lp, int vec) {
+  __shared__ __attribute__((aligned(16))) unsigned short tile[HQ][136];       // [token][head], rows of 272 bytes (16-byte multiple)
   const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const unsigned short* src = (const unsigned short*)dt + (int64_t)b * dsb;
+  typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
   for (int h0 = 0; h0 < H; h0 += 128) {
     const int nh = min(128, H - h0);
-    for (int i = tid; i < HQ * 128; i += 256) {
-      const int t = i >> 7, h = i & 127, tok = c * HQ + t;
-      tile[t][h] = (tok < L && h < nh) ? src[(int64_t)tok * dsl + h0 + h] : (unsigned short)0;
+    if (vec) {          // 16-byte loads: 8 heads of a token (rows and base 16-byte aligned, H a multiple of 8)
+      for (int i = tid; i < HQ * 16; i += 256) {
+        const int t = i >> 4, hc = i & 15, tok = c * HQ + t;
+        u16x8 v = {};
+        if (tok < L && 8 * hc < nh) v = *(const u16x8*)(src + (int64_t)tok * dsl + h0 + 8 * hc);
+        *(u16x8*)(&tile[t][8 * hc]) = v;
+      }
+    } else {
+      for (int i = tid; i < HQ * 128; i += 256) {
+        const int t = i >> 7, h = i & 127, tok = c * HQ + t;
+        tile[t][h] = (tok < L && h < nh) ? src[(int64_t)tok * dsl + h0 + h] : (unsigned short)0;
+      }
     }
     __syncthreads();
     unsigned short* dst = (unsigned short*)out + ((int64_t)b * H + h0) * lp + (int64_t)c * HQ;
-    for (int i = tid; i < 128 * HQ; i += 256) {
-      const int h = i >> 6, t = i & 63;
-      if (h < nh) dst[(int64_t)h * lp + t] = tile[t][h];
+    for (int i = tid; i < 128 * 8; i += 256) {       // 16-byte stores: 8 tokens of a head
+      const int h = i >> 3, tc = i & 7;
+      if (h < nh) {
+        u16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = tile[8 * tc + j][h];
+        *(u16x8*)(dst + (int64_t)h * lp + 8 * tc) = v;
+      }
     }
     __syncthreads();
   }
@@ -918,8 +944,9 @@ hipError_t launch_head(const HeadArgs& a, dim3 grid, hipStream_t st) {
 void tv_ssd_dt_transpose_launch(const void* dt, void* out, int batch, int seqlen, int nheads, int64_t dsb, int64_t dsl,
                                 hipStream_t st) {
   const int nchunks = (seqlen + HQ - 1) / HQ;
+  const int vec = (((uintptr_t)dt) & 15) == 0 && dsl % 8 == 0 && dsb % 8 == 0 && nheads % 8 == 0;
   ssd_dt_transpose_kernel<<<dim3(nchunks, batch), 256, 0, st>>>((const bf16_t*)dt, (bf16_t*)out, seqlen, nheads, dsb, dsl,
-                                                               (int64_t)nchunks * HQ);
+                                                               (int64_t)nchunks * HQ, vec);
 }
 
 #ifdef TV_HEAD_STAMP
@@ -973,7 +1000,7 @@ int tv_ssd_head_launch(const void* x, const void* dt, const void* A, const void*
   {
     const int64_t lp = (int64_t)a.nchunks * HQ;
     bf16_t* dtt = (bf16_t*)(wsb + lay.dtt);
-    ssd_dt_transpose_kernel<<<dim3(a.nchunks, batch), 256, 0, st>>>((const bf16_t*)dt, dtt, seqlen, nheads, dsb, dsl, lp);
+    tv_ssd_dt_transpose_launch(dt, dtt, batch, seqlen, nheads, dsb, dsl, st);
     a.dt = dtt; dt = dtt;
     dsb = (int64_t)nheads * lp; dsl = 1; a.dsh = lp;
   }
