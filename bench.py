@@ -369,13 +369,17 @@ def config1_scan(args):
 
 def config_decode(args):
     """One generated token against the cache of a 2 048-frame prefill (32 868 tokens, no token drop): the decode step
-    of `generate()` (modeling_nano.py:484-546, 1666-1689) on tv_causal_conv1d_update, tv_selective_state_update and the
-    one-query attention, timed per token; roofline of tv_selective_state_update (HBM: the fp32 state of every head is
-    read and written once per token, 2 x 5.24 MB per Mamba layer)."""
+    of `generate()` (modeling_nano.py:484-546, 1666-1689) on tv_causal_conv1d_update, tv_selective_state_update and
+    tv_attn_decode_fwd.  `value`: tokens/s of the step replayed as ONE hipGraph (llm/decode_graph.py: static K / V
+    buffers, key count on the device), greedy, the token fed back; the host-driven loop is timed beside it
+    (`config.eager_tokens_per_s`) and gives the per-kernel rooflines (events around the operator calls): the state
+    update (HBM: the fp32 state of every head read and written once per token, 2 x 5.24 MB per Mamba layer) and the
+    split-KV attention (HBM: K and V of the cache read once per token and attention layer)."""
     from timeviper_amd.build import ensure_built
     ensure_built()
     from timeviper_amd import kernels as K
     from timeviper_amd.model import build_synthetic_timeviper
+    from timeviper_amd.model.llm.decode_graph import GraphedDecodeStep
     from timeviper_amd.model.llm.nano import HybridMambaAttentionDynamicCache, NemotronHConfig
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
@@ -386,52 +390,77 @@ def config_decode(args):
     L = 2048 * TOK_PER_FRAME + 100
     g = torch.Generator(device=dev).manual_seed(1)
     emb = (torch.randn(1, L, cfg.hidden_size, device=dev, generator=g) * 0.02).bfloat16()
-    tok = (torch.randn(1, 1, cfg.hidden_size, device=dev, generator=g) * 0.02).bfloat16()
     steps, warm = max(args.steps, 16), max(args.warmup, 4)
-    rec = []
-    orig = K.selective_state_update
+    host_pos = torch.ones(1, dtype=torch.long)
+    recs = {"ssu": [], "attn": []}
 
-    def timed(state, *a, **kw):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        out = orig(state, *a, **kw)
-        e1.record()
-        rec.append((e0, e1, 2 * state.numel() * state.element_size()))
-        return out
+    def timed(name, orig, nbytes):
+        def f(*a, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = orig(*a, **kw)
+            e1.record()
+            recs[name].append((e0, e1, nbytes(*a, **kw)))
+            return out
+        return f
+
+    def roofline(name, kernel):
+        rec = recs[name]
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in rec)
+        gbs = sum(b for _, _, b in rec) / (ms * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": kernel, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "launches": len(rec),
+                "avg_launch_us": round(ms * 1e3 / len(rec), 2), "bytes_per_launch": rec[0][2]}
     with torch.inference_mode():
         cache = HybridMambaAttentionDynamicCache(cfg, 1, dtype=torch.bfloat16, device=dev)
-        llm(inputs_embeds=emb, past_key_values=cache, use_cache=True, cache_position=torch.zeros(1, dtype=torch.long))
-        pos = L
+        out = llm(inputs_embeds=emb, past_key_values=cache, use_cache=True, cache_position=torch.zeros(1, dtype=torch.long))
+        tok = out.logits[:, -1].argmax(-1).view(1, 1)
+        # ---- host-driven loop
         for _ in range(warm):
-            llm(inputs_embeds=tok, past_key_values=cache, use_cache=True, cache_position=torch.tensor([pos]))
-            pos += 1
+            tok = llm(input_ids=tok, past_key_values=cache, use_cache=True, cache_position=host_pos).logits[:, -1].argmax(-1).view(1, 1)
         torch.cuda.synchronize()
-        K.selective_state_update = timed
+        orig_ssu, orig_attn = K.selective_state_update, K.flash_attn_decode
+        K.selective_state_update = timed("ssu", orig_ssu, lambda state, *a, **kw: 2 * state.numel() * state.element_size())
+        K.flash_attn_decode = timed("attn", orig_attn, lambda q, k, v, *a, **kw: 2 * k.shape[0] * k.shape[1] * k.shape[2] * k.shape[3] * k.element_size())
         t0 = time.perf_counter()
         for _ in range(steps):
-            out = llm(inputs_embeds=tok, past_key_values=cache, use_cache=True, cache_position=torch.tensor([pos])).logits
-            pos += 1
+            tok = llm(input_ids=tok, past_key_values=cache, use_cache=True, cache_position=host_pos).logits[:, -1].argmax(-1).view(1, 1)
+        torch.cuda.synchronize()
+        eager_s = time.perf_counter() - t0
+        K.selective_state_update, K.flash_attn_decode = orig_ssu, orig_attn
+        # ---- the same step as one graph launch per token
+        gsteps = max(steps, 64)
+        cache.begin_static_decode(warm + gsteps + 8)
+        stepper = GraphedDecodeStep(
+            lambda ids: llm(input_ids=ids, past_key_values=cache, use_cache=True, cache_position=host_pos).logits,
+            cache, 1, dev)
+        for _ in range(warm):                 # two eager steps in static mode, the capture, replays
+            tok = stepper.step(tok).view(1, 1)
+        torch.cuda.synchronize()
+        assert stepper.graph is not None
+        t0 = time.perf_counter()
+        for _ in range(gsteps):
+            tok = stepper.step(tok).view(1, 1)
         torch.cuda.synchronize()
         dt_s = time.perf_counter() - t0
-        K.selective_state_update = orig
+        out = stepper.logits
     assert torch.isfinite(out.float()).all()
-    ms_ssu = sum(e0.elapsed_time(e1) for e0, e1, _ in rec)
-    gbs = sum(b for _, _, b in rec) / (ms_ssu * 1e-3) / 1e9
     weights = sum(p.numel() * p.element_size() for n, p in llm.named_parameters() if "embed" not in n)
+    rl_ssu = roofline("ssu", "state_update_rows_kernel (tv_selective_state_update)")
+    rl_attn = roofline("attn", "attn_decode_kernel + attn_decode_merge_kernel (tv_attn_decode_fwd)")
     print(json.dumps({
         "metric": "decode tokens/s, TimeViper-9B, batch 1, one token against a 2 048-frame prefill cache",
-        "value": round(steps / dt_s, 2), "unit": "tokens/s", "n_gpus": 1, "steps": steps, "warmup": warm,
-        "ms_per_step": round(dt_s / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value": round(gsteps / dt_s, 2), "unit": "tokens/s", "n_gpus": 1, "steps": gsteps, "warmup": warm,
+        "ms_per_step": round(dt_s / gsteps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"Nemotron-Nano-9B-v2 hybrid decode step (27 Mamba2 / 25 MLP / 4 attention layers), cache of "
-                               f"{L} tokens (2 048 frames, no token drop), host-driven layer loop, GEMVs on hipBLASLt",
+                               f"{L} tokens (2 048 frames, no token drop), greedy, one hipGraph launch per token, GEMVs on "
+                               f"hipBLASLt",
                    "cache_tokens": L, "weights": "random init, seed 0",
+                   "eager_tokens_per_s": round(steps / eager_s, 2), "eager_ms_per_step": round(eager_s / steps * 1e3, 3),
                    "weight_bytes_per_token": weights,
                    "weight_stream_floor_ms": round(weights / (HBM_PEAK_GBS * 1e9) * 1e3, 3)},
-        "roofline": {"bound": "hbm", "kernel": "selective_state_update_kernel (tv_selective_state_update)",
-                     "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                     "traffic": None, "launches": len(rec), "avg_launch_us": round(ms_ssu * 1e3 / len(rec), 2),
-                     "bytes_per_launch": rec[0][2]}}), flush=True)
+        "roofline": rl_ssu, "rooflines": [rl_ssu, rl_attn]}), flush=True)
 
 
 class CudaEnv:

@@ -330,6 +330,23 @@ int tv_flash_attn_fp8_fwd(const void* q, const void* k, const void* v, void* o,
                           float softmax_scale, int causal, int dtype,
                           void* workspace, size_t workspace_bytes, void* stream);
 
+/* The decode step of the same operator: ONE query token per sequence against a K / V cache (q_len == 1 in
+ * modeling_nano.py:1198-1209; cache layout of HybridMambaAttentionDynamicCache, :205-360).  q (B, Hq, D) and
+ * o (B, Hq, D) by batch / head strides, k / v (B, Lk, Hkv, D) as in tv_flash_attn_fwd; lse (B, Hq) fp32 or NULL.
+ * The q-heads of a kv-head share one pass over its K / V, the keys are split over the chip (split-KV) and merged by a
+ * second launch.  seqlens_k: NULL, or DEVICE memory holding `batch` ints — the keys of each sequence actually in
+ * use, clamped to [0, seqlen_k]; seqlen_k is then the capacity the launch is sized for, so a step captured in a
+ * hipGraph replays against a growing cache.  headdim 128, bf16 (other shapes: tv_flash_attn_fwd with seqlen_q 1,
+ * same results up to the summation order).  workspace: tv_attn_decode_workspace_bytes(), 16-byte aligned. */
+size_t tv_attn_decode_workspace_bytes(int batch, int nheads_q, int nheads_kv, int seqlen_k);
+int tv_attn_decode_fwd(const void* q, const void* k, const void* v, void* o, void* lse, int batch,
+                       int seqlen_k, const int* seqlens_k, int nheads_q, int nheads_kv, int headdim,
+                       int64_t q_stride_b, int64_t q_stride_h, int64_t k_stride_b,
+                       int64_t k_stride_l, int64_t k_stride_h, int64_t v_stride_b,
+                       int64_t v_stride_l, int64_t v_stride_h, int64_t o_stride_b,
+                       int64_t o_stride_h, float softmax_scale, int dtype,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------
  * T2  pdrop "attn" ranking.  Replaces modeling_nano.py:1822-1857,:1914-1939
  * without the (L,L) mask: one query row (the last prompt token) against all

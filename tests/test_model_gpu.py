@@ -561,3 +561,76 @@ def test_internvideo2_fused_clips_equal_separate_clips():
             first = {k: v[: (64 if "internvideo2" in k else 256)] for k, v in fused.items()} \
                 if isinstance(fused, dict) else fused[:64]
             assert relerr(pf[:256], vlm.projector_forward(first, is_video=True)) < 5e-3, bid
+
+
+def _toy_hybrid_d128(pattern="M-*M*-"):
+    from timeviper_amd.model.llm.nano import NemotronHConfig, NemotronHForCausalLM
+    torch.manual_seed(11)
+    cfg = NemotronHConfig(vocab_size=256, hidden_size=256, intermediate_size=384, num_hidden_layers=len(pattern),
+                          hybrid_override_pattern=pattern, num_attention_heads=8, head_dim=128,
+                          num_key_value_heads=2, ssm_state_size=16, mamba_num_heads=8,
+                          mamba_n_groups=2, mamba_head_dim=16, mamba_chunk_size=16)
+    model = NemotronHForCausalLM(cfg).to(DEV).bfloat16().eval()
+    with torch.no_grad():       # spread the logits: N(0, 0.02) weights give near-uniform attention and near-tied tokens
+        for blk in model.backbone.layers:
+            if blk.block_type == "attention":
+                blk.mixer.q_proj.weight.mul_(8.0)
+                blk.mixer.k_proj.weight.mul_(8.0)
+    return cfg, model
+
+
+def test_kv_cache_grows_in_place_and_matches_concatenation():
+    """`update` writes a token into spare capacity instead of re-concatenating the cache (modeling_nano.py:246-251):
+    the views it hands out hold exactly what torch.cat would."""
+    from timeviper_amd.model.llm.nano import HybridMambaAttentionDynamicCache
+    cfg, _ = _toy_hybrid_d128("*")
+    cache = HybridMambaAttentionDynamicCache(cfg, 2, dtype=torch.bfloat16, device=DEV, kv_reserve=4)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    ks = [torch.randn(2, n, 2, 128, device=DEV, generator=g).bfloat16() for n in (300, 1, 1, 1, 1, 1, 7, 1)]
+    vs = [torch.randn_like(k) for k in ks]
+    for i, (k, v) in enumerate(zip(ks, vs)):
+        kc, vc = cache.update(k, v, 0)
+        assert torch.equal(kc, torch.cat(ks[:i + 1], 1)) and torch.equal(vc, torch.cat(vs[:i + 1], 1))
+        assert cache.get_seq_length() == kc.shape[1] and cache.key_cache[0].data_ptr() == kc.data_ptr()
+    ptrs = set()
+    for _ in range(40):          # geometric growth: few re-allocations for many tokens
+        cache.update(ks[1], vs[1], 0)
+        ptrs.add(cache.kv_buffers(0)[0].data_ptr())
+    assert len(ptrs) <= 3
+
+
+@pytest.mark.parametrize("pattern", ["M-*M*-", "*M-"])
+def test_graphed_decode_step_matches_the_eager_loop(pattern):
+    """GraphedDecodeStep (static K / V buffers, device-side key count, one hipGraph launch per token) against the eager
+    decode loop, teacher-forced with the same tokens: the logits of every step agree to bf16 round-off (the graph path
+    runs tv_attn_decode_fwd, the eager one the prefill kernel with one query row)."""
+    from timeviper_amd.model.llm.decode_graph import GraphedDecodeStep
+    from timeviper_amd.model.llm.nano import HybridMambaAttentionDynamicCache
+    cfg, model = _toy_hybrid_d128(pattern)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    prompt = torch.randint(0, 256, (1, 300), device=DEV, generator=g)
+    forced = torch.randint(0, 256, (10,), device=DEV, generator=g)
+    host_pos = torch.ones(1, dtype=torch.long)
+    with torch.inference_mode():
+        eager_cache = HybridMambaAttentionDynamicCache(cfg, 1, dtype=torch.bfloat16, device=DEV)
+        model(input_ids=prompt, past_key_values=eager_cache, use_cache=True, cache_position=torch.zeros(1, dtype=torch.long))
+        eager = [model(input_ids=t.view(1, 1), past_key_values=eager_cache, use_cache=True,
+                       cache_position=host_pos).logits[:, -1].clone() for t in forced]
+        cache = HybridMambaAttentionDynamicCache(cfg, 1, dtype=torch.bfloat16, device=DEV)
+        model(input_ids=prompt, past_key_values=cache, use_cache=True, cache_position=torch.zeros(1, dtype=torch.long))
+        cache.begin_static_decode(len(forced))
+        stepper = GraphedDecodeStep(
+            lambda ids: model(input_ids=ids, past_key_values=cache, use_cache=True, cache_position=host_pos).logits,
+            cache, 1, DEV)
+        for i, t in enumerate(forced):
+            nxt = stepper.step(t.view(1, 1))
+            assert relerr(stepper.logits, eager[i]) < 3e-2, (i, relerr(stepper.logits, eager[i]))
+            assert int(nxt) == int(stepper.logits.argmax(-1))
+            assert cache.get_seq_length() == 300 + i + 1
+        assert stepper.graph is not None          # steps 3.. were replays
+        with pytest.raises(RuntimeError):         # the reservation is spent: the buffers must not move under the graph
+            for _ in range(400):
+                stepper.step(forced[0].view(1, 1))
+        # ... and the cache it leaves is an ordinary one
+        assert torch.equal(cache.key_cache[cache.attention_layers[0]][:, :310],
+                           cache.kv_buffers(cache.attention_layers[0])[0][:, :310])

@@ -1,6 +1,7 @@
 """Parity of every HIP operator against the CPU oracle (same seeded inputs) and the
 reference-generated golden fixtures.  Calls go through the C ABI (ctypes)."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -490,6 +491,84 @@ def test_flash_attention_spiked_max(K):
     o_ref, _ = R.attention_ref(q.float(), k.float(), v.float(), True)
     o = K.flash_attn_func(q.to(DEV), k.to(DEV), v.to(DEV), causal=True)
     close(o, o_ref, 2e-2, 1e-2)
+
+
+@pytest.mark.parametrize("B,Lk,Hq,Hkv", [
+    (1, 256, 32, 8),         # the smallest cache the split-KV kernel takes: 2 splits x 4 waves x one step
+    (1, 257, 32, 8),         # one key in the last step
+    (1, 1000, 32, 8),
+    (2, 4099, 8, 8),         # no GQA: one real column of the MFMA tile
+    (1, 3000, 16, 1),        # 16 q-heads on one kv-head: the whole tile
+    (1, 2500, 40, 2),        # 20 q-heads per kv-head: two head blocks
+    (3, 777, 12, 4),
+    (1, 32868, 32, 8),       # the bench's cache: 2 048 frames
+])
+def test_flash_attn_decode_split_kv(K, B, Lk, Hq, Hkv):
+    """One query token against a cache (modeling_nano.py:1198-1209, q_len 1): fp32 oracle, and the one-row launch of the
+    prefill kernel — same operator, other summation order."""
+    g = torch.Generator().manual_seed(Lk + Hq)
+    q = torch.randn(B, 1, Hq, 128, generator=g).bfloat16()
+    k = torch.randn(B, Lk, Hkv, 128, generator=g).bfloat16()
+    v = torch.randn(B, Lk, Hkv, 128, generator=g).bfloat16()
+    o_ref, lse_ref = R.attention_ref(q.float(), k.float(), v.float(), True)
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    o, lse = K.flash_attn_decode(qd, kd, vd, return_lse=True)
+    close(o, o_ref, 2e-2, 1e-2, "o")
+    close(lse, lse_ref, 1e-3, 2e-3, "lse")
+    # flash_attn_func routes one-query calls here; TV_ATTN_DECODE=0 keeps them on the prefill kernel
+    o2 = K.flash_attn_func(qd, kd, vd, causal=True)
+    assert torch.equal(o2, o)
+    os.environ["TV_ATTN_DECODE"] = "0"
+    try:
+        o3 = K.flash_attn_func(qd, kd, vd, causal=True)
+    finally:
+        del os.environ["TV_ATTN_DECODE"]
+    close(o, o3.float().cpu(), 2e-2, 1e-2, "against the prefill kernel")
+
+
+def test_flash_attn_decode_device_lengths_and_strided_cache(K):
+    """seqlens_k on the device (what a captured decode step replays with): keys past the length are never read into the
+    result — they hold NaNs here; the cache buffers are views with a capacity larger than the length."""
+    g = torch.Generator().manual_seed(5)
+    B, cap, Hq, Hkv = 3, 1500, 32, 8
+    lens = [1500, 1, 700]
+    q = torch.randn(B, 1, Hq, 128, generator=g).bfloat16().to(DEV)
+    kbuf = torch.randn(B, cap + 64, Hkv, 128, generator=g).bfloat16().to(DEV)
+    vbuf = torch.randn(B, cap + 64, Hkv, 128, generator=g).bfloat16().to(DEV)
+    for b, n in enumerate(lens):
+        kbuf[b, n:] = float("nan")
+        vbuf[b, n:] = float("nan")
+    k, v = kbuf[:, :cap], vbuf[:, :cap]                    # strided views of the capacity buffers
+    sl = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    o, lse = K.flash_attn_decode(q, k, v, seqlens_k=sl, return_lse=True)
+    assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
+    for b, n in enumerate(lens):
+        o_ref, lse_ref = R.attention_ref(q[b:b + 1].float().cpu(), k[b:b + 1, :n].float().cpu(), v[b:b + 1, :n].float().cpu(), True)
+        close(o[b:b + 1], o_ref, 2e-2, 1e-2, f"o[{b}]")
+        close(lse[b:b + 1], lse_ref, 1e-3, 2e-3, f"lse[{b}]")
+    # a growing cache under ONE set of launch parameters: the length is read on the device
+    sl.fill_(10)
+    o10 = K.flash_attn_decode(q, k, v, seqlens_k=sl)
+    o_ref, _ = R.attention_ref(q[0:1].float().cpu(), k[0:1, :10].float().cpu(), v[0:1, :10].float().cpu(), True)
+    close(o10[0:1], o_ref, 2e-2, 1e-2, "length 10")
+    with pytest.raises(K.TimeViperHipError):
+        K.flash_attn_decode(q, k, v, seqlens_k=sl.to(torch.int64))
+
+
+def test_flash_attn_decode_spiked_max(K):
+    """The running maximum jumps late in a wave's walk and differs by orders of magnitude between splits."""
+    g = torch.Generator().manual_seed(1)
+    B, Lk, Hq, Hkv = 1, 5000, 32, 8
+    q = torch.randn(B, 1, Hq, 128, generator=g)
+    k = torch.randn(B, Lk, Hkv, 128, generator=g)
+    v = torch.randn(B, Lk, Hkv, 128, generator=g)
+    for pos, hq in ((70, 0), (2500, 5), (4999, 31), (33, 17)):
+        k[0, pos, hq // 4] = q[0, 0, hq] * 3.0
+    q, k, v = (t.bfloat16() for t in (q, k, v))
+    o_ref, lse_ref = R.attention_ref(q.float(), k.float(), v.float(), True)
+    o, lse = K.flash_attn_decode(q.to(DEV), k.to(DEV), v.to(DEV), return_lse=True)
+    close(o, o_ref, 2e-2, 1e-2, "o")
+    close(lse, lse_ref, 1e-3, 2e-3, "lse")
 
 
 def test_attention_golden_module_level(K):

@@ -84,17 +84,6 @@ int tv_ssd_correct_all_launch(void* y, const void* dt, const void* A, const void
 #ifndef TV_HEAD_FENCE
 #define TV_HEAD_FENCE 1
 #endif
-// TV_HEAD_NT: 1 = the x copies and the y stores carry the non-temporal bit — they stream through the XCD's L2 once, and
-// marking them first-to-evict keeps the B / C tiles, which the four work-groups of a (group, segment) share, resident
-// until the last of the four has fetched them
-#ifndef TV_HEAD_NT
-#define TV_HEAD_NT 1
-#endif
-#if TV_HEAD_NT
-#define TV_X_NT " nt"
-#else
-#define TV_X_NT ""
-#endif
 namespace {
 using namespace ssdk;
 
@@ -293,23 +282,23 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
     unsigned keep;
     if (n == 4)
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\t"
-                   "global_load_lds_dwordx4 %1, %5" TV_X_NT "\n\t"
-                   "global_load_lds_dwordx4 %2, %5 offset:%7" TV_X_NT "\n\t"
-                   "global_load_lds_dwordx4 %3, %5 offset:%8" TV_X_NT "\n\t"
-                   "global_load_lds_dwordx4 %4, %5 offset:%9" TV_X_NT "\n\ts_mov_b32 m0, %0"
+                   "global_load_lds_dwordx4 %1, %5\n\t"
+                   "global_load_lds_dwordx4 %2, %5 offset:%7\n\t"
+                   "global_load_lds_dwordx4 %3, %5 offset:%8\n\t"
+                   "global_load_lds_dwordx4 %4, %5 offset:%9\n\ts_mov_b32 m0, %0"
                    : "=&s"(keep) : "v"(x_off), "v"(x_off + dj), "v"(x_off + 2 * dj), "v"(vl + 3 * dj), "s"(sx), "s"(dst),
                      "n"(RPI * XROW), "n"(2 * RPI * XROW), "n"(3 * RPI * XROW) : "memory");
     else if (n == 3)
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\t"
-                   "global_load_lds_dwordx4 %1, %4" TV_X_NT "\n\t"
-                   "global_load_lds_dwordx4 %2, %4 offset:%6" TV_X_NT "\n\t"
-                   "global_load_lds_dwordx4 %3, %4 offset:%7" TV_X_NT "\n\ts_mov_b32 m0, %0"
+                   "global_load_lds_dwordx4 %1, %4\n\t"
+                   "global_load_lds_dwordx4 %2, %4 offset:%6\n\t"
+                   "global_load_lds_dwordx4 %3, %4 offset:%7\n\ts_mov_b32 m0, %0"
                    : "=&s"(keep) : "v"(x_off), "v"(x_off + dj), "v"(vl + 2 * dj), "s"(sx), "s"(dst),
                      "n"(RPI * XROW), "n"(2 * RPI * XROW) : "memory");
     else if (n == 2)
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
-                   "global_load_lds_dwordx4 %1, %3" TV_X_NT "\n\t"
-                   "global_load_lds_dwordx4 %2, %3 offset:%5" TV_X_NT "\n\ts_mov_b32 m0, %0"
+                   "global_load_lds_dwordx4 %1, %3\n\t"
+                   "global_load_lds_dwordx4 %2, %3 offset:%5\n\ts_mov_b32 m0, %0"
                    : "=&s"(keep) : "v"(x_off), "v"(vl + dj), "s"(sx), "s"(dst), "n"(RPI * XROW) : "memory");
     else
       glds16(sx, vl, dst);
@@ -329,7 +318,7 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
   const unsigned yoff0 = (unsigned)((lc * a.ysl + 4 * kq) * 2);
   unsigned yoff16 = (unsigned)(((16 * (kq & 1) + lc) * a.ysl + 8 * (kq >> 1)) * 2);     // 16-byte form (TV_HEAD_Y16)
   auto store_y_tile = [&](const void* yrow, bool ok, int ct, u32x2 v) {      // yrow: row 16 ti of the chunk, columns of this head
-    if (ok) asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3" TV_X_NT :: "v"(yoff0), "v"(v), "s"(yrow), "n"(32 * ct) : "memory");
+    if (ok) asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3" :: "v"(yoff0), "v"(v), "s"(yrow), "n"(32 * ct) : "memory");
   };
 
   // ------------------------------------------------------------------ per-chunk vectors (lane = token)
@@ -802,7 +791,7 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
         const auto s0 = __builtin_amdgcn_permlane16_swap(ya[0], yb[0], false, false);
         const auto s1 = __builtin_amdgcn_permlane16_swap(ya[1], yb[1], false, false);
         const u32x4v w = {s0[0], s1[0], s0[1], s1[1]};
-        if (ok) asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3" TV_X_NT :: "v"(yo16), "v"(w), "s"(yrow), "n"(32 * ct) : "memory");
+        if (ok) asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3" :: "v"(yo16), "v"(w), "s"(yrow), "n"(32 * ct) : "memory");
       }
     }
 #else

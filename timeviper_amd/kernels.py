@@ -18,6 +18,7 @@ eager fallback: tensors must live on the GPU and the HIP library must be built.
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import torch
@@ -507,6 +508,8 @@ def flash_attn_func(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False,
         return flash_attn_fp8_func(q, k, v, softmax_scale, causal, return_lse)
     fix = lambda t: t if t.stride(-1) == 1 else t.contiguous()
     q, k, v = fix(q), fix(k), fix(v)
+    if Lq == 1 and _decode_attn_takes(q, k, v):         # a decode step: split-KV kernel (causal or not: one query, last row)
+        return flash_attn_decode(q, k, v, softmax_scale=softmax_scale, return_lse=return_lse)
     if D % 8:
         raise TimeViperHipError(f"flash_attn_func: head_dim {D} must be a multiple of 8")
     for t in (q, k, v):
@@ -520,6 +523,44 @@ def flash_attn_func(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False,
         q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
         v.stride(0), v.stride(1), v.stride(2), o.stride(0), o.stride(1), o.stride(2),
         scale, int(bool(causal)), _dt(q), _stream()), "tv_flash_attn_fwd")
+    return (o, lse) if return_lse else o
+
+
+def _decode_attn_takes(q, k, v) -> bool:
+    """Shapes tv_attn_decode_fwd is written for (the rest stays on tv_flash_attn_fwd with one query row)."""
+    return (q.dtype == torch.bfloat16 and q.shape[-1] == 128 and k.shape[1] >= 256
+            and os.environ.get("TV_ATTN_DECODE", "1") != "0"
+            and all(s % 8 == 0 for t in (q, k, v) for s in t.stride()[:3])
+            and all(t.data_ptr() % 16 == 0 for t in (q, k, v)))
+
+
+def flash_attn_decode(q, k, v, seqlens_k=None, softmax_scale=None, return_lse=False, out=None):
+    """One query token per sequence against a K / V cache: q (B, 1, Hq, 128) bf16, k / v (B, Lk, Hkv, 128) ->
+    (B, 1, Hq, 128) (the q_len == 1 call of modeling_nano.py:1198-1209).  `seqlens_k`: int32 tensor (B,) ON THE GPU with
+    the keys in use per sequence (<= Lk, the capacity of the cache buffers) — the form a captured decode step replays
+    with; None: all Lk keys."""
+    _gpu(q, k, v, seqlens_k)
+    B, Lq, Hq, D = q.shape
+    Lk, Hkv = k.shape[1], k.shape[2]
+    if Lq != 1:
+        raise TimeViperHipError("flash_attn_decode: one query token per sequence")
+    if seqlens_k is not None and (seqlens_k.dtype != torch.int32 or seqlens_k.numel() != B or not seqlens_k.is_contiguous()):
+        raise TimeViperHipError("flash_attn_decode: seqlens_k must be a contiguous int32 tensor of `batch` entries")
+    fix = lambda t: t if t.stride(-1) == 1 else t.contiguous()
+    q, k, v = fix(q), fix(k), fix(v)
+    scale = 1.0 / math.sqrt(D) if softmax_scale is None else float(softmax_scale)
+    o = torch.empty((B, 1, Hq, D), dtype=q.dtype, device=q.device) if out is None else out
+    if o.shape != (B, 1, Hq, D) or o.dtype != q.dtype or o.stride(-1) != 1:
+        raise TimeViperHipError("flash_attn_decode: out must be (B, 1, Hq, D) of q's dtype with unit last stride")
+    lse = torch.empty((B, Hq, 1), dtype=torch.float32, device=q.device) if return_lse else None
+    lib = _capi.lib()
+    ws = torch.empty((max(int(lib.tv_attn_decode_workspace_bytes(B, Hq, Hkv, Lk)), 16),), dtype=torch.uint8,
+                     device=q.device)
+    check(lib.tv_attn_decode_fwd(
+        _p(q), _p(k), _p(v), _p(o), _p(lse), B, Lk, _p(seqlens_k), Hq, Hkv, D,
+        q.stride(0), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
+        v.stride(0), v.stride(1), v.stride(2), o.stride(0), o.stride(2),
+        scale, _dt(q), _p(ws), ws.numel() * ws.element_size(), _stream()), "tv_attn_decode_fwd")
     return (o, lse) if return_lse else o
 
 

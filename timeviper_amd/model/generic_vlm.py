@@ -9,6 +9,8 @@ forward (prefill) = ViT over 256-frame clips -> ToMe+MLP projector -> splice one
 """
 from __future__ import annotations
 
+import os
+
 from typing import List, Optional, Union
 
 import torch
@@ -303,11 +305,15 @@ class GenericTimeViperVLM(nn.Module):
         new_tokens: List[int] = []
         tok = out.logits[:, -1].argmax(-1)
         pdargs = self.pdrop_args if self.use_pdrop else None
+        stepper = self._graphed_decode_step(cache, max_new_tokens, pdargs)
         for _ in range(max_new_tokens):
             t = int(tok)
             new_tokens.append(t)
             if t in eos:
                 break
+            if stepper is not None:            # the same step as below, replayed as one hipGraph launch
+                tok = stepper.step(tok.view(1, 1))
+                continue
             mi = self.prepare_inputs_for_generation(tok.view(1, 1), past_key_values=cache,
                                                     cache_position=torch.zeros(1, dtype=torch.long))
             out = self.llm_backbone(input_ids=mi["input_ids"], past_key_values=cache, use_cache=True,
@@ -319,6 +325,27 @@ class GenericTimeViperVLM(nn.Module):
         if return_ids or not hasattr(tokenizer, "decode"):
             return ids
         return tokenizer.decode(ids[0], skip_special_tokens=False).strip()
+
+    def _graphed_decode_step(self, cache, max_new_tokens, pdargs):
+        """The decode step behind `generate` as a captured graph (llm/decode_graph.py) where the stack allows it: the
+        Nemotron-H hybrid (no positional encoding), bf16, attention head_dim 128 (tv_attn_decode_fwd), on the GPU, and
+        enough tokens to pay for two eager warm-up steps and the capture.  TV_DECODE_GRAPH=0 keeps the eager loop."""
+        from .llm.decode_graph import GraphedDecodeStep
+        from .llm.nano import HybridMambaAttentionDynamicCache, NemotronHForCausalLM
+        llm = self.llm_backbone.llm
+        if (os.environ.get("TV_DECODE_GRAPH", "1") == "0" or self.device.type != "cuda" or max_new_tokens < 8
+                or not isinstance(llm, NemotronHForCausalLM) or not isinstance(cache, HybridMambaAttentionDynamicCache)
+                or self.dtype != torch.bfloat16 or not cache.attention_layers
+                or cache.key_cache[cache.attention_layers[0]].shape[-1] != 128):
+            return None
+        cache.begin_static_decode(max_new_tokens)
+        host_pos = torch.ones(1, dtype=torch.long)              # "not the prefill" for the mixers' host-side branch
+        dev_pos = torch.ones((1, 1), dtype=torch.long, device=self.device)
+
+        def step_fn(ids):
+            return self.llm_backbone(input_ids=ids, past_key_values=cache, use_cache=True, cache_position=host_pos,
+                                     position_ids=dev_pos, train_pdrop_args=pdargs).logits
+        return GraphedDecodeStep(step_fn, cache, 1, self.device)
 
     @classmethod
     def from_pretrained(cls, pretrained_checkpoint, model_id: str, vision_backbone: VisionBackbone,

@@ -149,9 +149,18 @@ class CausalLMOutputWithPast:
 # ------------------------------------------------------------------- cache
 class HybridMambaAttentionDynamicCache:
     """Per-layer conv / ssm / key / value lists (reference :205-360).  SSM states
-    are kept in fp32 (what the scan kernel returns and the decode kernel updates)."""
+    are kept in fp32 (what the scan kernel returns and the decode kernel updates).
 
-    def __init__(self, config, batch_size, dtype=torch.bfloat16, device=None):
+    Keys / values: `key_cache[i]` is what the reference holds — (B, L_i, Hkv, D) with every token seen so far — but it is a
+    VIEW of a buffer with spare capacity: the reference's `torch.cat` per generated token (:246-251) re-copies the whole
+    cache (2 x 135 MB per attention layer and token behind a 2 048-frame prefill); here a token is written in place and the
+    buffer grows geometrically when it runs out.
+
+    `begin_static_decode(n)` fixes the buffers for the next n tokens and moves the write position and the key count to
+    DEVICE memory: every launch of a decode step then has the same parameters, which is what
+    lets `GraphedDecodeStep` replay it as one hipGraph."""
+
+    def __init__(self, config, batch_size, dtype=torch.bfloat16, device=None, kv_reserve=256):
         self.dtype = dtype
         self.hybrid_override_pattern = config.hybrid_override_pattern
         self.has_previous_state = False
@@ -166,16 +175,93 @@ class HybridMambaAttentionDynamicCache:
                                    if c != "M"]
         self.attention_layers = [i for i, c in enumerate(config.hybrid_override_pattern)
                                  if c == "*"]
+        self.kv_reserve = int(kv_reserve)
+        self._kv_buf = [None] * n              # (k, v) capacity buffers, (B, cap, Hkv, D)
+        self._kv_len = [0] * n
+        # static decode: per distinct cache length an int64 (1,) write slot and an int32 (B,) key count, on the device
+        self._static, self._static_of, self.static_decode = {}, {}, False
+
+    def _reserve(self, layer_idx, need):
+        have = self._kv_len[layer_idx]
+        buf = self._kv_buf[layer_idx]
+        if buf is not None and buf[0].shape[1] >= need:
+            return
+        if self.static_decode:
+            raise RuntimeError("static decode: the key / value buffers are fixed (begin_static_decode reserved too little)")
+        k_old, v_old = self.key_cache[layer_idx], self.value_cache[layer_idx]
+        shape = (k_old.shape[0], need + max(self.kv_reserve, have // 8)) + tuple(k_old.shape[2:])
+        kb, vb = k_old.new_empty(shape), v_old.new_empty(shape)
+        kb[:, :have], vb[:, :have] = k_old, v_old
+        self._kv_buf[layer_idx] = (kb, vb)
+        self.key_cache[layer_idx], self.value_cache[layer_idx] = kb[:, :have], vb[:, :have]
 
     def update(self, key_states, value_states, layer_idx, cache_kwargs=None):
         """key/value (B, L, Hkv, D) — sequence-major, the layout the attention kernel reads."""
-        if self.key_cache[layer_idx].shape[-1] == 0:
-            self.key_cache[layer_idx] = key_states
-            self.value_cache[layer_idx] = value_states
+        new = key_states.shape[1]
+        if self.key_cache[layer_idx].shape[-1] == 0:        # prefill: adopt the projections' output, no copy
+            self.key_cache[layer_idx], self.value_cache[layer_idx] = key_states, value_states
+            self._kv_buf[layer_idx], self._kv_len[layer_idx] = None, new
+            return key_states, value_states
+        have = self._kv_len[layer_idx]
+        self._reserve(layer_idx, have + new)
+        kb, vb = self._kv_buf[layer_idx]
+        if self.static_decode:
+            if new != 1:
+                raise RuntimeError("static decode takes one token per step")
+            pos = self._static_of[layer_idx][0]
+            kb.index_copy_(1, pos, key_states)
+            vb.index_copy_(1, pos, value_states)
         else:
-            self.key_cache[layer_idx] = torch.cat([self.key_cache[layer_idx], key_states], dim=1)
-            self.value_cache[layer_idx] = torch.cat([self.value_cache[layer_idx], value_states], dim=1)
+            kb[:, have:have + new], vb[:, have:have + new] = key_states, value_states
+        self._kv_len[layer_idx] = have + new
+        self.key_cache[layer_idx], self.value_cache[layer_idx] = kb[:, :have + new], vb[:, :have + new]
         return self.key_cache[layer_idx], self.value_cache[layer_idx]
+
+    def kv_buffers(self, layer_idx):
+        """The capacity buffers of a layer (static decode: what the attention kernel is handed, with `decode_lens`)."""
+        return self._kv_buf[layer_idx]
+
+    # ---- static decode (fixed launch parameters; see GraphedDecodeStep)
+    def begin_static_decode(self, max_new_tokens: int):
+        """Token drop (pdrop) leaves the attention layers behind a stage with fewer tokens than the ones in front of it:
+        one (write position, key count) pair per distinct length, shared by the layers that hold it."""
+        if not self.attention_layers or any(self._kv_len[i] == 0 for i in self.attention_layers):
+            raise RuntimeError("static decode starts behind a prefill (every attention layer holding its tokens)")
+        self.end_static_decode()
+        for i in self.attention_layers:
+            self._reserve(i, self._kv_len[i] + int(max_new_tokens))
+        k0 = self.key_cache[self.attention_layers[0]]
+        self._static = {}
+        for n in sorted({self._kv_len[i] for i in self.attention_layers}):
+            self._static[n] = (torch.full((1,), n, dtype=torch.int64, device=k0.device),
+                               torch.full((k0.shape[0],), n + 1, dtype=torch.int32, device=k0.device))
+        self._static_of = {i: self._static[self._kv_len[i]] for i in self.attention_layers}
+        self.static_decode = True
+
+    def end_static_decode(self):
+        self._static, self._static_of, self.static_decode = {}, {}, False
+
+    def static_room(self) -> int:
+        """Tokens the fixed buffers still take (a replayed graph writes where its device-side position says: the caller
+        must stop before the buffers end — GraphedDecodeStep checks this before every launch)."""
+        return min(self._kv_buf[i][0].shape[1] - self._kv_len[i] for i in self.attention_layers)
+
+    def advance_static_device(self):
+        """Device side of one finished step (part of the captured graph)."""
+        for pos, lens in self._static.values():
+            pos += 1
+            lens += 1
+
+    def decode_lens(self, layer_idx):
+        return self._static_of[layer_idx][1]
+
+    def advance_static_host(self):
+        """Host side of one REPLAYED step: the bookkeeping `update` does when it runs."""
+        for i in self.attention_layers:
+            n = self._kv_len[i] + 1
+            kb, vb = self._kv_buf[i]
+            self._kv_len[i] = n
+            self.key_cache[i], self.value_cache[i] = kb[:, :n], vb[:, :n]
 
     def get_seq_length(self, layer_idx: Optional[int] = 0) -> int:
         if not self.attention_layers:
@@ -376,8 +462,13 @@ class NemotronHAttention(nn.Module):
         v = self.v_proj(hidden_states).view(bsz, q_len, self.num_key_value_heads, self.head_dim)
         if past_key_value is not None:
             k, v = past_key_value.update(k, v, self.layer_idx)
-        o = K._flash_attention_forward(q, k, v, attention_mask=None, query_length=q_len,
-                                       is_causal=self.is_causal)
+        if past_key_value is not None and q_len == 1 and past_key_value.static_decode:
+            # static decode: the whole buffers + the key count on the device (same launch parameters every token)
+            kb, vb = past_key_value.kv_buffers(self.layer_idx)
+            o = K.flash_attn_decode(q, kb, vb, seqlens_k=past_key_value.decode_lens(self.layer_idx))
+        else:
+            o = K._flash_attention_forward(q, k, v, attention_mask=None, query_length=q_len,
+                                           is_causal=self.is_causal)
         o = self.o_proj(o.reshape(bsz, q_len, self.num_heads * self.head_dim))
         return o, None, past_key_value
 
