@@ -330,6 +330,27 @@ int tv_flash_attn_fp8_fwd(const void* q, const void* k, const void* v, void* o,
                           float softmax_scale, int causal, int dtype,
                           void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Decode-step linear layers (torch.nn.Linear with 1..4 rows, modeling_nano.py:484-546 / :993-1000 at q_len 1):
+ *   y[m][n] = sum_k f(x)[m][k] W[n][k] (+ bias[n]),   W (N, K) row-major with row stride ldw, bf16, fp32 accumulation.
+ * f is the single-row operator the reference runs in front of the product, computed in the kernel's prologue with the
+ * rounding points of the stand-alone kernels:
+ *   prologue 0  f(x) = x
+ *            1  RMSNorm with the residual add: s = bf16(x + delta) (delta NULL: s = x), written to sum_out if not NULL;
+ *               f = bf16(norm_weight * (s * rsqrt(mean(s^2) + eps)))          (tv_rmsnorm_fwd; :897-903, :966)
+ *            2  f = bf16(relu(x)^2)                                           (tv_relu2_fwd; :993-994)
+ *            3  gated group RMSNorm: v = x * silu(gate) (gate NULL: v = x),
+ *               f = bf16(norm_weight * (v * rsqrt(mean_group(v^2) + eps))), groups of group_size channels
+ *                                                                             (tv_rmsnorm_gated_fwd; :371-380)
+ * norm_weight_dtype TV_F32 or TV_BF16.  M <= 4, M * K * 2 <= 128 KiB, K % 8 == 0; x / W / delta / gate / sum_out rows
+ * 16-byte aligned.  The arguments of the prologues not selected are ignored.
+ * --------------------------------------------------------------------- */
+int tv_gemv_bf16_fwd(const void* x, const void* W, const void* bias, void* y, int M, int N, int K,
+                     int64_t x_stride, int64_t ldw, int64_t y_stride, int prologue, const void* delta,
+                     int64_t delta_stride, void* sum_out, int64_t sum_stride, const void* norm_weight,
+                     int norm_weight_dtype, float eps, const void* gate, int64_t gate_stride,
+                     int group_size, void* stream);
+
 /* The decode step of the same operator: ONE query token per sequence against a K / V cache (q_len == 1 in
  * modeling_nano.py:1198-1209; cache layout of HybridMambaAttentionDynamicCache, :205-360).  q (B, Hq, D) and
  * o (B, Hq, D) by batch / head strides, k / v (B, Lk, Hkv, D) as in tv_flash_attn_fwd; lse (B, Hq) fp32 or NULL.

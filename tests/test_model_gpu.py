@@ -634,3 +634,41 @@ def test_graphed_decode_step_matches_the_eager_loop(pattern):
         # ... and the cache it leaves is an ordinary one
         assert torch.equal(cache.key_cache[cache.attention_layers[0]][:, :310],
                            cache.kv_buffers(cache.attention_layers[0])[0][:, :310])
+
+
+def test_fused_decode_step_matches_the_unfused_one(monkeypatch):
+    """TV_DECODE_FUSED (default): the decode token's norms / activations run in the prologues of tv_gemv_bf16_fwd; =0:
+    stand-alone kernels + torch.nn.Linear.  Same rounding points, so the logits agree to the products' accumulation
+    order, token after token, and the caches end up equal to round-off."""
+    from timeviper_amd import kernels as K
+    from timeviper_amd.model.llm.nano import HybridMambaAttentionDynamicCache
+    cfg, model = _toy_hybrid_d128("M-*M-*")
+    g = torch.Generator(device=DEV).manual_seed(9)
+    prompt = torch.randint(0, 256, (2, 270), device=DEV, generator=g)
+    forced = torch.randint(0, 256, (6, 2), device=DEV, generator=g)
+    host_pos = torch.ones(1, dtype=torch.long)
+    runs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("TV_DECODE_FUSED", mode)
+        calls = []
+        orig = K.gemv_fused
+        monkeypatch.setattr(K, "gemv_fused", lambda *a, **kw: (calls.append(kw.get("prologue", a[3] if len(a) > 3 else 0)), orig(*a, **kw))[1])
+        with torch.inference_mode():
+            cache = HybridMambaAttentionDynamicCache(cfg, 2, dtype=torch.bfloat16, device=DEV)
+            model(input_ids=prompt, past_key_values=cache, use_cache=True, cache_position=torch.zeros(1, dtype=torch.long))
+            outs = [model(input_ids=t.view(2, 1), past_key_values=cache, use_cache=True, cache_position=host_pos).logits[:, -1].clone()
+                    for t in forced]
+        monkeypatch.setattr(K, "gemv_fused", orig)
+        runs[mode] = (outs, cache, calls)
+    assert runs["0"][2] == []
+    assert runs["1"][2][0] == K.GEMV_NONE                  # the prefill's lm_head on its last position is one row too
+    per_token = runs["1"][2][1:][:(len(runs["1"][2]) - 1) // 6]
+    # M, M: rmsnorm-in_proj + gated-out_proj; -: rmsnorm-up + relu2-down; *: q, k, v, o; the head
+    assert per_token == [K.GEMV_RMSNORM, K.GEMV_GATED, K.GEMV_RMSNORM, K.GEMV_RELU2, 0, 0, 0, 0,
+                         K.GEMV_RMSNORM, K.GEMV_GATED, K.GEMV_RMSNORM, K.GEMV_RELU2, 0, 0, 0, 0, 0], per_token
+    for a, b in zip(runs["0"][0], runs["1"][0]):
+        assert relerr(a, b) < 2e-2, relerr(a, b)
+    c0, c1 = runs["0"][1], runs["1"][1]
+    for i in range(cfg.num_hidden_layers):
+        if c0.ssm_states[i].numel():
+            assert relerr(c0.ssm_states[i], c1.ssm_states[i]) < 2e-2 and relerr(c0.conv_states[i], c1.conv_states[i]) < 2e-2

@@ -493,6 +493,72 @@ def test_flash_attention_spiked_max(K):
     close(o, o_ref, 2e-2, 1e-2)
 
 
+# ---------------------------------------------------------------- decode-step linears
+@pytest.mark.parametrize("M,N,Kd", [(1, 1000, 4096), (1, 18560, 4096), (3, 777, 4480), (4, 4096, 15680), (1, 131, 64),
+                                    (2, 96, 8), (1, 4096, 10240)])
+@pytest.mark.parametrize("prologue", ["none", "rmsnorm", "rmsnorm+delta", "relu2", "gated", "gated-nogate"])
+def test_gemv_fused_prologues(K, M, N, Kd, prologue):
+    """tv_gemv_bf16_fwd against the stand-alone operators + an fp64 product of THEIR bf16 output: the prologue rounds
+    where tv_rmsnorm_fwd / tv_relu2_fwd / tv_rmsnorm_gated_fwd round, so f(x) is compared bit for bit (through sum_out
+    and a product with the identity) and y to the accumulation order."""
+    if prologue.startswith("rmsnorm") and Kd > 8192:
+        pytest.skip("the rmsnorm prologue holds rows of <= 8192 channels")
+    group = {10240: 1280, 15680: 1960, 4096: 512, 4480: 560, 64: 32, 8: 8}[Kd]
+    g = torch.Generator(device=DEV).manual_seed(M * 7 + N + Kd)
+    x = torch.randn(M, 1, Kd, device=DEV, generator=g).bfloat16()
+    d = (torch.randn(M, 1, Kd, device=DEV, generator=g) * 0.5).bfloat16()
+    z = torch.randn(M, 1, Kd, device=DEV, generator=g).bfloat16()
+    W = (torch.randn(N, Kd, device=DEV, generator=g) / math.sqrt(Kd)).bfloat16()
+    b = torch.randn(N, device=DEV, generator=g).bfloat16() if N % 2 else None
+    nw = (1 + 0.1 * torch.randn(Kd, device=DEV, generator=g))
+    nw = nw.bfloat16() if M % 2 else nw.float()
+    sum_out = None
+    if prologue == "none":
+        f, kw = x, dict(prologue=K.GEMV_NONE)
+    elif prologue == "rmsnorm":
+        f, kw = K.rms_norm(x, nw, 1e-5), dict(prologue=K.GEMV_RMSNORM, norm_weight=nw, eps=1e-5)
+    elif prologue == "rmsnorm+delta":
+        f, s_ref = K.rms_norm(x, nw, 1e-5, residual=d, return_sum=True)
+        sum_out = torch.full_like(x, float("nan"))
+        kw = dict(prologue=K.GEMV_RMSNORM, norm_weight=nw, eps=1e-5, delta=d, sum_out=sum_out)
+    elif prologue == "relu2":
+        f, kw = K.relu2(x), dict(prologue=K.GEMV_RELU2)
+    else:
+        gate = z if prologue == "gated" else None
+        f = K.rmsnorm_fn(x, nw, None, z=gate, eps=1e-5, group_size=group, norm_before_gate=False)
+        kw = dict(prologue=K.GEMV_GATED, norm_weight=nw, eps=1e-5, gate=gate, group_size=group)
+    assert K.gemv_takes(x, W)
+    y = K.gemv_fused(x, W, b, **kw)
+    assert y.shape == (M, 1, N) and y.dtype == torch.bfloat16
+    ref = f.double().view(M, Kd) @ W.double().t() + (0 if b is None else b.double())
+    err = (y.double().view(M, N) - ref).abs()
+    tol = 2.0 ** -8 * ref.abs() + 2e-3            # one bf16 rounding of y + fp32 accumulation over K
+    assert (err <= tol).all(), f"max excess {(err / tol).max().item():.2f}"
+    if sum_out is not None:
+        assert torch.equal(sum_out, s_ref)
+    if Kd <= 4480 and N != 131:                    # f(x) itself, bit for bit: rows of the identity pick its elements
+        eye = torch.eye(Kd, device=DEV).bfloat16()
+        kw.pop("sum_out", None)
+        assert torch.equal(K.gemv_fused(x, eye, None, **kw).view(M, Kd), f.view(M, Kd))
+
+
+def test_gemv_fused_strided_rows_and_errors(K):
+    g = torch.Generator(device=DEV).manual_seed(0)
+    buf = torch.randn(2, 1, 3 * 512, device=DEV, generator=g).bfloat16()
+    x, gate = buf[..., 512:1024], buf[..., :512]           # views into wider rows (the mixer's in_proj output)
+    W = (torch.randn(300, 512, device=DEV, generator=g) / 20).bfloat16()
+    nw = torch.ones(512, device=DEV)
+    y = K.gemv_fused(x, W, None, K.GEMV_GATED, norm_weight=nw, eps=1e-5, gate=gate, group_size=128)
+    f = K.rmsnorm_fn(x.contiguous(), nw, None, z=gate.contiguous(), eps=1e-5, group_size=128, norm_before_gate=False)
+    close(y, (f.float() @ W.float().t()).cpu(), 1e-2, 2e-3)
+    assert not K.gemv_takes(torch.zeros(5, 1, 512, device=DEV).bfloat16(), W)          # 5 rows
+    assert not K.gemv_takes(x.float(), W)
+    with pytest.raises(K.TimeViperHipError):
+        K.gemv_fused(torch.zeros(5, 1, 512, device=DEV).bfloat16(), W)
+    with pytest.raises(K.TimeViperHipError):
+        K.gemv_fused(x, W, None, K.GEMV_RMSNORM)                                        # no norm weight
+
+
 @pytest.mark.parametrize("B,Lk,Hq,Hkv", [
     (1, 256, 32, 8),         # the smallest cache the split-KV kernel takes: 2 splits x 4 waves x one step
     (1, 257, 32, 8),         # one key in the last step

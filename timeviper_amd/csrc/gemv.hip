@@ -1,0 +1,429 @@
+// Decode-step linear layers: y[m][n] = sum_k f(x)[m][k] W[n][k] (+ bias[n]) for M <= 4 rows (one token per sequence).
+//
+// A generated token moves every weight of the stack once (16.6 GB for Nemotron-Nano-9B-v2) through matrix-VECTOR
+// products: HBM-bound, 2 flops a byte.  The library's skinny-GEMM kernels reach 2.3 - 3.4 TB/s on these shapes
+// (bench.py --config decode, rocprofv3), and every product is surrounded by single-row kernels — RMSNorm + residual add
+// in front of in_proj / up_proj, relu^2 in front of down_proj, the gated group norm in front of out_proj — that take
+// 7 - 10 us each for a few KiB.  This kernel streams W with 16-byte loads (1 KiB per load instruction, 12 - 16 of them in
+// flight per wave) against f(x) held in LDS as bf16.  A work-group owns whole rows of W (b, b + grid, ...) and its four
+// waves split K — with N = 4 480 rows (out_proj, down_proj) a wave per row leaves the 2 048 waves of the chip 2 or 3
+// rows each (73 % balance), a work-group per row 8 or 9 (97 %); the four partial sums meet in LDS.  f — the single-row
+// operator in front of the product — is computed in the prologue, redundantly in every work-group (x is a few KiB in L2):
+//   PRO_NONE      f(x) = x
+//   PRO_RMSNORM   s = bf16(x + delta) (written to `sum_out` by work-group 0: the new residual stream),
+//                 f = bf16(w * (s * rsqrt(mean(s^2) + eps)))             NemotronHRMSNorm + block add, modeling_nano.py:897-903, :966
+//   PRO_RELU2     f = bf16(relu(x)^2)                                    NemotronHMLP, :993-994
+//   PRO_GATED     v = x * silu(z), f = bf16(w * (v * rsqrt(mean_group(v^2) + eps)))     MambaRMSNormGated, :371-380
+// with the rounding points of the stand-alone kernels (norms.hip), so the fused step and the unfused one agree to the
+// accumulation order of the dot products.  fp32 accumulation (v_dot2c_f32_bf16), one rounding of y.
+#include "common.hpp"
+
+namespace {
+
+enum { PRO_NONE = 0, PRO_RMSNORM = 1, PRO_RELU2 = 2, PRO_GATED = 3 };
+constexpr int GV_THREADS = 256;
+constexpr int GV_WAVES = GV_THREADS / 64;
+constexpr int GV_MAXM = 4;
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+struct GemvArgs {
+  const bf16_t *x, *W, *bias, *delta, *gate;
+  const void* norm_w;
+  bf16_t *y, *sum_out;
+  int M, N, K, group, norm_w_f32;
+  int64_t xs, ldw, ys, ds, ss, gs;
+  float eps;
+};
+
+__device__ __forceinline__ float normw(const void* w, int f32, int i) {
+  return f32 ? ((const float*)w)[i] : (float)((const bf16_t*)w)[i];
+}
+
+__device__ __forceinline__ float dot8(bf16x8 a, bf16x8 b, float acc) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    acc = __builtin_amdgcn_fdot2_f32_bf16(bf16x2{a[2 * j], a[2 * j + 1]}, bf16x2{b[2 * j], b[2 * j + 1]}, acc, false);
+  return acc;
+}
+
+// f(x) -> LDS (bf16, [M][K]); ends with a barrier
+template <int PRO>
+__device__ __forceinline__ void gemv_prologue(const GemvArgs& a, bf16_t* fx, float* red) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = a.K, nv = K / 8;
+  for (int m = 0; m < a.M; ++m) {
+    const bf16_t* xr = a.x + (int64_t)m * a.xs;
+    bf16_t* fr = fx + (int64_t)m * K;
+    if (PRO == PRO_NONE || PRO == PRO_RELU2) {
+      for (int iv = tid; iv < nv; iv += GV_THREADS) {
+        bf16x8 v = *(const bf16x8*)(xr + 8 * iv);
+        if (PRO == PRO_RELU2) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float r = fmaxf((float)v[j], 0.f);
+            v[j] = (bf16_t)(r * r);
+          }
+        }
+        *(bf16x8*)(fr + 8 * iv) = v;
+      }
+    } else if (PRO == PRO_RMSNORM) {
+      constexpr int MAXV = 4;                        // K <= 8 * 256 * 4 (launcher)
+      float vals[MAXV][8];
+      float ssq = 0.f;
+#pragma unroll
+      for (int k = 0; k < MAXV; ++k) {
+        const int iv = tid + k * GV_THREADS;
+        if (iv < nv) {
+          bf16x8 v = *(const bf16x8*)(xr + 8 * iv);
+          if (a.delta) {
+            const bf16x8 d = *(const bf16x8*)(a.delta + (int64_t)m * a.ds + 8 * iv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (bf16_t)((float)v[j] + (float)d[j]);     // the add rounds to bf16 (:966)
+          }
+          if (a.sum_out && blockIdx.x == 0) *(bf16x8*)(a.sum_out + (int64_t)m * a.ss + 8 * iv) = v;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            vals[k][j] = (float)v[j];
+            ssq = fmaf(vals[k][j], vals[k][j], ssq);
+          }
+        }
+      }
+      ssq = wave_sum(ssq);
+      __syncthreads();                               // (red is reused by the next row)
+      if (lane == 0) red[wave] = ssq;
+      __syncthreads();
+      float tot = 0.f;
+#pragma unroll
+      for (int i = 0; i < GV_WAVES; ++i) tot += red[i];
+      const float rstd = rsqrtf(tot / (float)K + a.eps);
+#pragma unroll
+      for (int k = 0; k < MAXV; ++k) {
+        const int iv = tid + k * GV_THREADS;
+        if (iv < nv) {
+          bf16x8 o;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = (bf16_t)(normw(a.norm_w, a.norm_w_f32, 8 * iv + j) * (vals[k][j] * rstd));
+          *(bf16x8*)(fr + 8 * iv) = o;
+        }
+      }
+    } else {                                         // PRO_GATED: a wave per group of `group` channels, two groups at a time
+      constexpr int MAXV = 4;                        // group <= 8 * 64 * 4 (launcher)
+      const int ngroups = K / a.group, gv = a.group / 8;
+      for (int g0 = wave; g0 < ngroups; g0 += 2 * GV_WAVES) {
+        bf16x8 xv[2][MAXV], zv[2][MAXV];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {                // (the loads of both groups before the first use)
+          const int g = min(g0 + q * GV_WAVES, ngroups - 1);
+#pragma unroll
+          for (int k = 0; k < MAXV; ++k) {
+            const int iv = lane + k * 64;
+            if (iv < gv) {
+              xv[q][k] = *(const bf16x8*)(xr + (int64_t)g * a.group + 8 * iv);
+              if (a.gate) zv[q][k] = *(const bf16x8*)(a.gate + (int64_t)m * a.gs + (int64_t)g * a.group + 8 * iv);
+            }
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int g = g0 + q * GV_WAVES;
+          if (g >= ngroups) break;
+          float vals[MAXV][8];
+          float ssq = 0.f;
+#pragma unroll
+          for (int k = 0; k < MAXV; ++k) {
+            const int iv = lane + k * 64;
+            if (iv < gv) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                float f = (float)xv[q][k][j];
+                if (a.gate) {
+                  const float gt = (float)zv[q][k][j];
+                  f *= gt * __builtin_amdgcn_rcpf(1.f + __expf(-gt));
+                }
+                vals[k][j] = f;
+                ssq = fmaf(f, f, ssq);
+              }
+            }
+          }
+          ssq = wave_sum(ssq);
+          const float rstd = rsqrtf(ssq / (float)a.group + a.eps);
+#pragma unroll
+          for (int k = 0; k < MAXV; ++k) {
+            const int iv = lane + k * 64;
+            if (iv < gv) {
+              bf16x8 o;
+#pragma unroll
+              for (int j = 0; j < 8; ++j)
+                o[j] = (bf16_t)(normw(a.norm_w, a.norm_w_f32, g * a.group + 8 * iv + j) * (vals[k][j] * rstd));
+              *(bf16x8*)(fr + (int64_t)g * a.group + 8 * iv) = o;
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+}
+
+// MT: 1 = one row of x (the batch-1 decode step), GV_MAXM = up to four (a.M);  R rows of W at a time, NB load
+// instructions per row and batch (R * NB loads in flight per wave).  Used for K >= 8 192.
+template <int PRO, int MT, int R, int NB>
+__global__ __launch_bounds__(GV_THREADS) void gemv_bf16_kernel(GemvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gv_smem[];
+  bf16_t* fx = (bf16_t*)gv_smem;                     // [M][K]
+  __shared__ float red[GV_WAVES];
+  __shared__ float part[2][GV_WAVES][R][MT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = a.K, nv = K / 8;
+
+  // This wave's share of K: 16-byte pieces [p0, p0 + np) of every row, 64 per load instruction.  The first batch of a
+  // row group is issued one group AHEAD — for the first group before the prologue (the loads do not depend on f(x)), for
+  // the others before the math of the group in front of them.
+  const int G = gridDim.x;
+  const int pw = (nv + GV_WAVES - 1) / GV_WAVES, p0 = wave * pw;
+  const int np = min(nv - p0, pw);                   // (<= 0: nothing for this wave)
+  const int nins = np > 0 ? (np + 63) / 64 : 0;
+  auto load_batch = [&](bf16x8 (&dst)[NB][R], int n0, int i0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (n0 + r * G < a.N) {                        // (work-group uniform)
+        const bf16_t* wp = a.W + (int64_t)(n0 + r * G) * a.ldw + 8 * (p0 + lane);
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+          const bf16x8 z = {};
+          dst[u][r] = 64 * (i0 + u) + lane < np ? *(const bf16x8*)(wp + 512 * (i0 + u)) : z;
+        }
+      }
+    }
+  };
+  bf16x8 cur[NB][R];
+  if ((int)blockIdx.x < a.N) load_batch(cur, blockIdx.x, 0);
+
+  gemv_prologue<PRO>(a, fx, red);
+
+  // ---------------------------------------------------------------- the products
+  const bf16_t* fl = fx + 8 * (p0 + lane);
+  int par = 0;
+  for (int n0 = blockIdx.x; n0 < a.N; n0 += R * G, par ^= 1) {
+    float acc[R][MT];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[r][m] = 0.f;
+    auto fma_batch = [&](const bf16x8 (&w)[NB][R], int i0) __attribute__((always_inline)) {
+#pragma unroll
+      for (int u = 0; u < NB; ++u)
+        if (64 * (i0 + u) + lane < np) {
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+            if (MT == 1 || m < a.M) {
+              const bf16x8 xv = *(const bf16x8*)(fl + (int64_t)m * K + 512 * (i0 + u));
+#pragma unroll
+              for (int r = 0; r < R; ++r)
+                if (n0 + r * G < a.N) acc[r][m] = dot8(w[u][r], xv, acc[r][m]);
+            }
+        }
+    };
+    const bool more = n0 + R * G < a.N;
+    bf16x8 nxt[NB][R];
+    if (more) load_batch(nxt, n0 + R * G, 0);
+    fma_batch(cur, 0);
+    for (int i0 = NB; i0 < nins; i0 += NB) {
+      bf16x8 wv[NB][R];
+      load_batch(wv, n0, i0);
+      fma_batch(wv, i0);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const float sm = wave_sum(acc[r][m]);
+        if (lane == 0) part[par][wave][r][m] = sm;
+      }
+    __syncthreads();                                 // (the other parity is written by the next group: one barrier a group)
+    if (tid < R * MT) {
+      const int r = tid / MT, m = tid % MT, n = n0 + r * G;
+      if (n < a.N && (MT == 1 || m < a.M)) {
+        float sm = 0.f;
+#pragma unroll
+        for (int w = 0; w < GV_WAVES; ++w) sm += part[par][w][r][m];
+        a.y[(int64_t)m * a.ys + n] = (bf16_t)(sm + (a.bias ? (float)a.bias[n] : 0.f));
+      }
+    }
+    if (more) {
+#pragma unroll
+      for (int u = 0; u < NB; ++u)
+#pragma unroll
+        for (int r = 0; r < R; ++r) cur[u][r] = nxt[u][r];
+    }
+  }
+}
+
+// The same product with a ROW of W per wave (two at a time, 16 loads in flight), for K < 8 192: a row is 3 - 16 load
+// instructions, too few to split four ways (the waves of a work-group would meet at a barrier every 12 loads), and N is
+// large where K is small in this model (in_proj 22 656 x 4 480, up_proj 15 680 x 4 480: 8 - 11 rows a wave).
+template <int PRO, int MT>
+__global__ __launch_bounds__(GV_THREADS) void gemv_rows_kernel(GemvArgs a) {
+  constexpr int R = 2, NB = 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char gv_smem[];
+  bf16_t* fx = (bf16_t*)gv_smem;                     // [M][K]
+  __shared__ float red[GV_WAVES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = a.K, nv = K / 8;
+  const int TW = gridDim.x * GV_WAVES, gw = blockIdx.x * GV_WAVES + wave;
+  const int nins = (nv + 63) / 64;
+  auto load_batch = [&](bf16x8 (&dst)[NB][R], int n0, int i0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (n0 + r * TW < a.N) {                       // (wave uniform)
+        const bf16_t* wp = a.W + (int64_t)(n0 + r * TW) * a.ldw + 8 * lane;
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+          const bf16x8 z = {};
+          dst[u][r] = 64 * (i0 + u) + lane < nv ? *(const bf16x8*)(wp + 512 * (i0 + u)) : z;
+        }
+      }
+    }
+  };
+  bf16x8 cur[NB][R];
+  if (gw < a.N) load_batch(cur, gw, 0);              // in flight while the prologue runs
+
+  gemv_prologue<PRO>(a, fx, red);
+
+  const bf16_t* fl = fx + 8 * lane;
+  for (int n0 = gw; n0 < a.N; n0 += R * TW) {
+    float acc[R][MT];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[r][m] = 0.f;
+    auto fma_batch = [&](const bf16x8 (&w)[NB][R], int i0) __attribute__((always_inline)) {
+#pragma unroll
+      for (int u = 0; u < NB; ++u)
+        if (64 * (i0 + u) + lane < nv) {
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+            if (MT == 1 || m < a.M) {
+              const bf16x8 xv = *(const bf16x8*)(fl + (int64_t)m * K + 512 * (i0 + u));
+#pragma unroll
+              for (int r = 0; r < R; ++r)
+                if (n0 + r * TW < a.N) acc[r][m] = dot8(w[u][r], xv, acc[r][m]);
+            }
+        }
+    };
+    if (n0 != gw) load_batch(cur, n0, 0);
+    fma_batch(cur, 0);
+    for (int i0 = NB; i0 < nins; i0 += NB) {
+      load_batch(cur, n0, i0);
+      fma_batch(cur, i0);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int n = n0 + r * TW;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+        if (MT == 1 || m < a.M) {
+          const float sm = wave_sum(acc[r][m]);
+          if (lane == 0 && n < a.N) a.y[(int64_t)m * a.ys + n] = (bf16_t)(sm + (a.bias ? (float)a.bias[n] : 0.f));
+        }
+    }
+  }
+}
+
+int cu_count() {
+  static const int n = [] {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8)
+      cus = 256;                               // MI355X
+    return cus;
+  }();
+  return n;
+}
+
+template <int PRO, int MT, int R, int NB>
+int launch_gemv_r(const GemvArgs& a, hipStream_t st) {
+  const size_t lds = (size_t)a.M * a.K * sizeof(bf16_t);
+  static const hipError_t attr = hipFuncSetAttribute((const void*)gemv_bf16_kernel<PRO, MT, R, NB>,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+  if (attr != hipSuccess) {
+    tv_set_error("gemv: cannot reserve 128 KiB of LDS: %s", hipGetErrorString(attr));
+    return TV_ERR_LAUNCH;
+  }
+  // two work-groups per CU; fewer when there are not R rows for each
+  int wgs = (a.N + R - 1) / R;
+  const int most = 2 * cu_count();
+  if (wgs > most) wgs = most;
+  gemv_bf16_kernel<PRO, MT, R, NB><<<dim3((unsigned)wgs), GV_THREADS, lds, st>>>(a);
+  TV_LAUNCH_CHECK();
+}
+template <int PRO, int MT>
+int launch_gemv_rows(const GemvArgs& a, hipStream_t st) {
+  const size_t lds = (size_t)a.M * a.K * sizeof(bf16_t);
+  static const hipError_t attr = hipFuncSetAttribute((const void*)gemv_rows_kernel<PRO, MT>,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+  if (attr != hipSuccess) {
+    tv_set_error("gemv: cannot reserve 128 KiB of LDS: %s", hipGetErrorString(attr));
+    return TV_ERR_LAUNCH;
+  }
+  int wgs = (a.N + 2 * GV_WAVES - 1) / (2 * GV_WAVES);            // >= one row pair per wave, two work-groups per CU
+  const int most = 2 * cu_count();
+  if (wgs > most) wgs = most;
+  gemv_rows_kernel<PRO, MT><<<dim3((unsigned)wgs), GV_THREADS, lds, st>>>(a);
+  TV_LAUNCH_CHECK();
+}
+template <int PRO, int MT>
+int launch_gemv_m(const GemvArgs& a, hipStream_t st) {
+  static const int force = [] { const char* e = getenv("TV_GEMV_SPLITK"); return e ? atoi(e) : -1; }();    // (dev: 0 / 1)
+  const bool splitk = force >= 0 ? force != 0 : a.K >= 8192;
+  return splitk ? launch_gemv_r<PRO, MT, 2, 8>(a, st) : launch_gemv_rows<PRO, MT>(a, st);
+}
+template <int PRO>
+int launch_gemv(const GemvArgs& a, hipStream_t st) {
+  return a.M == 1 ? launch_gemv_m<PRO, 1>(a, st) : launch_gemv_m<PRO, GV_MAXM>(a, st);
+}
+
+}  // namespace
+
+extern "C" int tv_gemv_bf16_fwd(const void* x, const void* W, const void* bias, void* y, int M, int N, int K,
+                                int64_t x_stride, int64_t ldw, int64_t y_stride, int prologue, const void* delta,
+                                int64_t delta_stride, void* sum_out, int64_t sum_stride, const void* norm_weight,
+                                int norm_weight_dtype, float eps, const void* gate, int64_t gate_stride,
+                                int group_size, void* stream) {
+  TV_CHECK_ARG(x && W && y, "gemv: null pointer");
+  TV_CHECK_ARG(M >= 1 && M <= GV_MAXM && N >= 1 && K >= 8, "gemv: M %d must be 1..%d, N %d >= 1, K %d >= 8", M, GV_MAXM, N, K);
+  if (K % 8 || ldw % 8 || x_stride % 8 || ((uintptr_t)x & 15) || ((uintptr_t)W & 15))
+    TV_UNSUPPORTED("gemv: K, the row strides of x and W must be multiples of 8 elements, x and W 16-byte aligned");
+  if ((size_t)M * K * 2 > 128 * 1024) TV_UNSUPPORTED("gemv: M x K = %d x %d does not fit the 128 KiB of LDS f(x) is held in", M, K);
+  TV_CHECK_ARG(prologue >= PRO_NONE && prologue <= PRO_GATED, "gemv: prologue %d", prologue);
+  GemvArgs a;
+  a.x = (const bf16_t*)x; a.W = (const bf16_t*)W; a.bias = (const bf16_t*)bias; a.y = (bf16_t*)y;
+  a.delta = nullptr; a.gate = nullptr; a.norm_w = nullptr; a.sum_out = nullptr;
+  a.M = M; a.N = N; a.K = K; a.group = K; a.norm_w_f32 = 0;
+  a.xs = x_stride; a.ldw = ldw; a.ys = y_stride; a.ds = a.ss = a.gs = 0; a.eps = eps;
+  if (prologue == PRO_RMSNORM || prologue == PRO_GATED) {
+    TV_CHECK_ARG(norm_weight && (norm_weight_dtype == TV_F32 || norm_weight_dtype == TV_BF16), "gemv: norm weight (fp32 or bf16) needed");
+    a.norm_w = norm_weight; a.norm_w_f32 = norm_weight_dtype == TV_F32;
+  }
+  if (prologue == PRO_RMSNORM) {
+    if (K > 8 * GV_THREADS * 4) TV_UNSUPPORTED("gemv: rmsnorm prologue holds a row of <= %d channels", 8 * GV_THREADS * 4);
+    if (delta && (delta_stride % 8 || ((uintptr_t)delta & 15))) TV_UNSUPPORTED("gemv: delta must be 16-byte aligned rows");
+    if (sum_out && (sum_stride % 8 || ((uintptr_t)sum_out & 15))) TV_UNSUPPORTED("gemv: sum_out must be 16-byte aligned rows");
+    a.delta = (const bf16_t*)delta; a.ds = delta_stride; a.sum_out = (bf16_t*)sum_out; a.ss = sum_stride;
+  }
+  if (prologue == PRO_GATED) {
+    TV_CHECK_ARG(group_size > 0 && K % group_size == 0 && group_size % 8 == 0, "gemv: group size %d must divide K %d (multiple of 8)", group_size, K);
+    if (group_size > 8 * 64 * 4) TV_UNSUPPORTED("gemv: gated-norm prologue holds groups of <= %d channels", 8 * 64 * 4);
+    if (gate && (gate_stride % 8 || ((uintptr_t)gate & 15))) TV_UNSUPPORTED("gemv: gate must be 16-byte aligned rows");
+    a.gate = (const bf16_t*)gate; a.gs = gate_stride; a.group = group_size;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  switch (prologue) {
+    case PRO_NONE: return launch_gemv<PRO_NONE>(a, st);
+    case PRO_RMSNORM: return launch_gemv<PRO_RMSNORM>(a, st);
+    case PRO_RELU2: return launch_gemv<PRO_RELU2>(a, st);
+    default: return launch_gemv<PRO_GATED>(a, st);
+  }
+}

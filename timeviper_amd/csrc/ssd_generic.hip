@@ -181,37 +181,48 @@ __global__ __launch_bounds__(256) void state_update_rows_kernel(float* __restric
   const int lane = threadIdx.x & 63;
   const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int sub = lane / LPR, ln = lane % LPR;
+  // every load of the wave's ITERS x RPW rows is issued before the first use (rows past the end re-read the last one)
+  int64_t row[ITERS];
+  f32x4 sv[ITERS];
+  float dtv[ITERS], xr[ITERS];
+  int hh[ITERS];
+  T Bv[ITERS][4], Cv[ITERS][4];
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
-    const int64_t row = (w * ITERS + it) * RPW + sub;          // (b, h, p) flattened
-    const bool ok = row < rows_total;
-    float part = 0.f, xr = 0.f, dh = 0.f;
-    if (ok) {
-      const int64_t bh = row / P;
-      const int h = (int)(bh % H);
-      const int64_t b = bh / H;
-      const int g = h / (H / G);
-      float d = to_f32(dt[bh]) + (dt_bias ? dt_bias[h] : 0.f);
-      if (softplus) d = softplus_f(d);
-      const float dec = expf(d * A[h]);
-      xr = to_f32(x[row]);
-      dh = D ? D[h] : 0.f;
-      const float xv = d * xr;
-      f32x4* sp = (f32x4*)(state + row * N) + ln;
-      const f32x4 sv = *sp;
-      const T* Br = Bm + (b * G + g) * N + 4 * ln;
-      const T* Cr = Cm + (b * G + g) * N + 4 * ln;
-      f32x4 v;
+    row[it] = (w * ITERS + it) * RPW + sub;             // (b, h, p) flattened
+    const int64_t rc = row[it] < rows_total ? row[it] : rows_total - 1;
+    const int64_t bh = rc / P;
+    hh[it] = (int)(bh % H);
+    const int64_t b = bh / H;
+    const int g = hh[it] / (H / G);
+    sv[it] = *((const f32x4*)(state + rc * N) + ln);
+    dtv[it] = to_f32(dt[bh]);
+    xr[it] = to_f32(x[rc]);
+    const T* Br = Bm + (b * G + g) * N + 4 * ln;
+    const T* Cr = Cm + (b * G + g) * N + 4 * ln;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        v[i] = fmaf(dec, sv[i], xv * to_f32(Br[i]));
-        part = fmaf(v[i], to_f32(Cr[i]), part);
-      }
-      *sp = v;
+    for (int i = 0; i < 4; ++i) { Bv[it][i] = Br[i]; Cv[it][i] = Cr[i]; }
+  }
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const bool ok = row[it] < rows_total;
+    const int h = hh[it];
+    float d = dtv[it] + (dt_bias ? dt_bias[h] : 0.f);
+    if (softplus) d = softplus_f(d);
+    const float dec = expf(d * A[h]);
+    const float dh = D ? D[h] : 0.f;
+    const float xv = d * xr[it];
+    float part = 0.f;
+    f32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[i] = fmaf(dec, sv[it][i], xv * to_f32(Bv[it][i]));
+      part = fmaf(v[i], to_f32(Cv[it][i]), part);
     }
+    if (ok) *((f32x4*)(state + row[it] * N) + ln) = v;
 #pragma unroll
     for (int o = LPR / 2; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
-    if (ok && ln == 0) y[row] = from_f32<T>(fmaf(dh, xr, part));
+    if (ok && ln == 0) y[row[it]] = from_f32<T>(fmaf(dh, xr[it], part));
   }
 }
 

@@ -526,6 +526,52 @@ def flash_attn_func(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False,
     return (o, lse) if return_lse else o
 
 
+GEMV_NONE, GEMV_RMSNORM, GEMV_RELU2, GEMV_GATED = 0, 1, 2, 3
+
+
+def gemv_takes(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    """Shapes tv_gemv_bf16_fwd is written for: 1..4 rows of bf16 against a bf16 (N, K) weight, f(x) within 128 KiB of LDS."""
+    K = x.shape[-1]
+    rows = x.numel() // max(K, 1)
+    return (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and weight.dim() == 2
+            and 1 <= rows <= 4 and K % 8 == 0 and rows * K * 2 <= 128 * 1024 and weight.stride(1) == 1
+            and weight.stride(0) % 8 == 0)
+
+
+def gemv_fused(x, weight, bias=None, prologue=GEMV_NONE, delta=None, sum_out=None, norm_weight=None, eps=0.0,
+               gate=None, group_size=0):
+    """y = f(x) @ weight.T (+ bias) for 1..4 rows — the linear layers of a decode step (torch.nn.Linear at q_len 1) with
+    the single-row operator in front of them computed in the kernel's prologue: GEMV_RMSNORM (NemotronHRMSNorm with the
+    block's residual add: `delta` is added to x first, the sum goes to `sum_out`), GEMV_RELU2 (the MLP activation),
+    GEMV_GATED (MambaRMSNormGated with `gate`), rounding where the stand-alone operators round."""
+    _gpu(x, weight, bias, delta, sum_out, norm_weight, gate)
+    K = x.shape[-1]
+    x2 = _rows2d(x)
+    M, N = x2.shape[0], weight.shape[0]
+    if weight.shape[1] != K:
+        raise TimeViperHipError(f"gemv_fused: weight {tuple(weight.shape)} against rows of {K}")
+    y = torch.empty(x.shape[:-1] + (N,), dtype=x.dtype, device=x.device)
+    d2 = None if delta is None else _rows2d(delta)
+    g2 = None if gate is None else _rows2d(gate)
+    s2 = None if sum_out is None else sum_out.view(-1, K)
+    for t in (d2, g2, s2):
+        if t is not None and (t.shape != x2.shape or t.dtype != x.dtype):
+            raise TimeViperHipError("gemv_fused: delta / gate / sum_out must have x's shape and dtype")
+    if bias is not None and (bias.dtype != x.dtype or not bias.is_contiguous()):
+        raise TimeViperHipError("gemv_fused: bias must be contiguous, of x's dtype")
+    nw_dt = 0
+    if norm_weight is not None:
+        if not norm_weight.is_contiguous() or norm_weight.numel() != K:
+            raise TimeViperHipError("gemv_fused: norm_weight must be a contiguous vector of K entries")
+        nw_dt = _dt(norm_weight)
+    check(_capi.lib().tv_gemv_bf16_fwd(
+        _p(x2), _p(weight), _p(bias), _p(y), M, N, K, x2.stride(0), weight.stride(0), N, int(prologue),
+        _p(d2), 0 if d2 is None else d2.stride(0), _p(s2), 0 if s2 is None else s2.stride(0),
+        _p(norm_weight), nw_dt, float(eps), _p(g2), 0 if g2 is None else g2.stride(0), int(group_size),
+        _stream()), "tv_gemv_bf16_fwd")
+    return y
+
+
 def _decode_attn_takes(q, k, v) -> bool:
     """Shapes tv_attn_decode_fwd is written for (the rest stays on tv_flash_attn_fwd with one query row)."""
     return (q.dtype == torch.bfloat16 and q.shape[-1] == 128 and k.shape[1] >= 256

@@ -16,6 +16,7 @@ What is deliberately different from the reference (SURVEY.md §3.2 notes):
 from __future__ import annotations
 
 import math
+import os
 import re
 from dataclasses import dataclass
 from typing import Any, Dict, List, Optional, Tuple
@@ -279,6 +280,20 @@ class HybridMambaAttentionDynamicCache:
         return new_ssm_state
 
 
+# ------------------------------------------------------------------ decode-step helpers
+def _fused_decode(x: torch.Tensor) -> bool:
+    """The linear layers of a decode step (1..4 rows) run on tv_gemv_bf16_fwd with the operator in front of them in
+    the prologue; TV_DECODE_FUSED=0 keeps torch.nn.Linear + the stand-alone kernels (same arithmetic, library GEMV)."""
+    return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 3 and x.shape[1] == 1 and x.shape[0] <= 4
+            and not torch.is_grad_enabled() and os.environ.get("TV_DECODE_FUSED", "1") != "0")
+
+
+def _linear(mod: nn.Linear, x: torch.Tensor) -> torch.Tensor:
+    if _fused_decode(x) and K.gemv_takes(x, mod.weight):
+        return K.gemv_fused(x, mod.weight, mod.bias)
+    return mod(x)
+
+
 # ------------------------------------------------------------------ layers
 class MambaRMSNormGated(nn.Module):
     def __init__(self, hidden_size, group_size, eps=1e-5):
@@ -411,6 +426,31 @@ class NemotronHMamba2Mixer(nn.Module):
         return out
 
 
+    def decode_fused(self, hidden, delta, norm, cache_params):
+        """One decode token with the block's RMSNorm (+ residual add) inside in_proj and the gated norm inside out_proj:
+        in_proj -> conv update -> state update -> out_proj, 4 launches.  Returns (residual stream, mixer output)."""
+        B = hidden.shape[0]
+        new_hidden = torch.empty_like(hidden) if delta is not None else hidden
+        proj = K.gemv_fused(hidden, self.in_proj.weight, self.in_proj.bias, K.GEMV_RMSNORM, delta=delta,
+                            sum_out=new_hidden if delta is not None else None, norm_weight=norm.weight,
+                            eps=norm.variance_epsilon)
+        gts = self.n_groups * self.ssm_state_size
+        d_in = self.intermediate_size
+        gate, xBC, dt = proj.split([d_in, self.conv_dim, self.num_heads], dim=-1)
+        negA, D32, dtb32 = self._consts()
+        xBC = K.causal_conv1d_update(xBC[:, 0], cache_params.conv_states[self.layer_idx], self.conv1d.weight.squeeze(1),
+                                     self.conv1d.bias, self.activation)
+        x, Bm, Cm = torch.split(xBC, [d_in, gts, gts], dim=-1)
+        y = K.selective_state_update(
+            cache_params.ssm_states[self.layer_idx], x.reshape(B, self.num_heads, self.head_dim), dt[:, 0], negA,
+            Bm.reshape(B, self.n_groups, -1), Cm.reshape(B, self.n_groups, -1), D32, z=None, dt_bias=dtb32,
+            dt_softplus=True)
+        out = K.gemv_fused(y.reshape(B, 1, d_in), self.out_proj.weight, self.out_proj.bias, K.GEMV_GATED,
+                           norm_weight=self.norm.weight, eps=self.norm.variance_epsilon, gate=gate,
+                           group_size=self.norm.group_size)
+        return new_hidden, out
+
+
 class ReLUSquared(nn.Module):
     def forward(self, x):
         return torch.square(F.relu(x))
@@ -429,6 +469,14 @@ class NemotronHMLP(nn.Module):
     def forward(self, x):
         # `act_fn` stays for the module tree; the activation runs as one in-place HIP pass
         return self.down_proj(K.relu2(self.up_proj(x), inplace=True))
+
+    def decode_fused(self, hidden, delta, norm):
+        """One decode token: RMSNorm (+ residual add) inside up_proj, relu^2 inside down_proj — 2 launches."""
+        new_hidden = torch.empty_like(hidden) if delta is not None else hidden
+        u = K.gemv_fused(hidden, self.up_proj.weight, self.up_proj.bias, K.GEMV_RMSNORM, delta=delta,
+                         sum_out=new_hidden if delta is not None else None, norm_weight=norm.weight,
+                         eps=norm.variance_epsilon)
+        return new_hidden, K.gemv_fused(u, self.down_proj.weight, self.down_proj.bias, K.GEMV_RELU2)
 
 
 class NemotronHAttention(nn.Module):
@@ -457,9 +505,9 @@ class NemotronHAttention(nn.Module):
             raise NotImplementedError("padding masks are not on the inference path (mask is None "
                                       "under flash_attention_2, reference :2208-2213)")
         bsz, q_len, _ = hidden_states.size()
-        q = self.q_proj(hidden_states).view(bsz, q_len, self.num_heads, self.head_dim)
-        k = self.k_proj(hidden_states).view(bsz, q_len, self.num_key_value_heads, self.head_dim)
-        v = self.v_proj(hidden_states).view(bsz, q_len, self.num_key_value_heads, self.head_dim)
+        q = _linear(self.q_proj, hidden_states).view(bsz, q_len, self.num_heads, self.head_dim)
+        k = _linear(self.k_proj, hidden_states).view(bsz, q_len, self.num_key_value_heads, self.head_dim)
+        v = _linear(self.v_proj, hidden_states).view(bsz, q_len, self.num_key_value_heads, self.head_dim)
         if past_key_value is not None:
             k, v = past_key_value.update(k, v, self.layer_idx)
         if past_key_value is not None and q_len == 1 and past_key_value.static_decode:
@@ -469,7 +517,7 @@ class NemotronHAttention(nn.Module):
         else:
             o = K._flash_attention_forward(q, k, v, attention_mask=None, query_length=q_len,
                                            is_causal=self.is_causal)
-        o = self.o_proj(o.reshape(bsz, q_len, self.num_heads * self.head_dim))
+        o = _linear(self.o_proj, o.reshape(bsz, q_len, self.num_heads * self.head_dim))
         return o, None, past_key_value
 
 
@@ -644,6 +692,10 @@ class NemotronHModel(PdropMixin, nn.Module):
         train_pdrop_args = kwargs.get("train_pdrop_args")
         self.last_pdrop_trace = []
         delta = None  # pending mixer output, added inside the next fused norm
+        fused_step = (_fused_decode(hidden) and past_key_values is not None and cache_position is not None
+                      and int(cache_position[0]) > 0 and not output_hidden_states and not self.check_nan
+                      and hidden.shape[-1] % 8 == 0 and hidden.shape[-1] <= 8192
+                      and all(p.dtype == torch.bfloat16 for p in self.layers[0].mixer.parameters() if p.dim() == 2))
         for layer_idx, block in enumerate(self.layers):
             if self.use_pdrop and train_pdrop_args is not None \
                     and layer_idx in self.pdrop_layers \
@@ -665,6 +717,13 @@ class NemotronHModel(PdropMixin, nn.Module):
             if output_hidden_states:
                 all_hidden += ((hidden if delta is None else hidden + delta),)
             # x_{i+1} = x_i + mixer(norm(x_i)); the add of layer i-1 is fused into this norm
+            if fused_step and block.block_type != "attention":
+                # decode token: the norm (+ add) runs in the prologue of the block's first matrix-vector product
+                if block.block_type == "mamba":
+                    hidden, delta = block.mixer.decode_fused(hidden, delta, block.norm, past_key_values)
+                else:
+                    hidden, delta = block.mixer.decode_fused(hidden, delta, block.norm)
+                continue
             if delta is None:
                 normed = block.norm(hidden)
             else:
@@ -750,6 +809,6 @@ class NemotronHForCausalLM(nn.Module):
         keep = self.config.num_logits_to_keep if logits_to_keep is None else logits_to_keep
         if isinstance(keep, int) and keep > 0:
             hidden = hidden[:, -keep:]
-        logits = self.lm_head(hidden.to(self.lm_head.weight.dtype)).float()
+        logits = _linear(self.lm_head, hidden.to(self.lm_head.weight.dtype)).float()
         return CausalLMOutputWithPast(loss=None, logits=logits, past_key_values=out.past_key_values,
                                       hidden_states=out.hidden_states)
