@@ -672,3 +672,44 @@ def test_fused_decode_step_matches_the_unfused_one(monkeypatch):
     for i in range(cfg.num_hidden_layers):
         if c0.ssm_states[i].numel():
             assert relerr(c0.ssm_states[i], c1.ssm_states[i]) < 2e-2 and relerr(c0.conv_states[i], c1.conv_states[i]) < 2e-2
+
+
+def test_generate_with_graphed_decode_step_continues_like_the_eager_loop(monkeypatch):
+    """`generate()` on a Nemotron-H stack with attention head_dim 128, uniform token drop + TransV (attention layers
+    behind a drop stage hold fewer tokens: one device-side key count per distinct length): the captured decode step
+    (TV_DECODE_GRAPH, default) and the host-driven loop produce the same greedy continuation."""
+    from timeviper_amd.model import build_synthetic_timeviper
+    from timeviper_amd.model.llm import decode_graph
+    from timeviper_amd.model.llm.nano import NemotronHConfig
+    cfg = NemotronHConfig(vocab_size=128, hidden_size=256, intermediate_size=384, num_hidden_layers=8,
+                          hybrid_override_pattern="M*-M*-M*", num_attention_heads=4, head_dim=128,
+                          num_key_value_heads=2, ssm_state_size=16, mamba_num_heads=8,
+                          mamba_n_groups=2, mamba_head_dim=16, mamba_chunk_size=16)
+    vlm = build_synthetic_timeviper(cfg, "siglip-vit-b16-224px", pdrop_type="uni_2_0.75-uni_5_0.5",
+                                    merge_module="CrossAttention", vit_depth=2, image_size=96)
+    with torch.no_grad():       # spread the logits so that greedy decoding has no near-ties
+        for blk in vlm.llm_backbone.llm.backbone.layers:
+            if blk.block_type == "attention":
+                blk.mixer.q_proj.weight.mul_(10.0)
+                blk.mixer.k_proj.weight.mul_(10.0)
+        vlm.llm_backbone.llm.lm_head.weight.mul_(20.0)
+    T = 40                       # 40 frames x 16 tokens: every cache holds >= 256 keys (the split-KV kernel's range) after the drops
+    tok = vlm.default_token_id
+    ids = torch.tensor([[5, 6, 7] + [tok] * T + [8, 9, 10, 11]], device=DEV)
+    pix = torch.randn(T, 3, 96, 96, device=DEV, dtype=torch.bfloat16)
+    replays = []
+    orig_step = decode_graph.GraphedDecodeStep.step
+
+    def counting_step(self, t):
+        out = orig_step(self, t)
+        replays.append(self.graph is not None)
+        return out
+    monkeypatch.setattr(decode_graph.GraphedDecodeStep, "step", counting_step)
+    graphed = vlm.generate(ids, pixel_values_videos=pix, max_new_tokens=12, return_ids=True, eos_token_id=-1)
+    assert len(replays) == 12 and replays[:2] == [False, False] and all(replays[2:])
+    monkeypatch.setenv("TV_DECODE_GRAPH", "0")
+    replays.clear()
+    eager = vlm.generate(ids, pixel_values_videos=pix, max_new_tokens=12, return_ids=True, eos_token_id=-1)
+    assert replays == []
+    assert graphed.shape == eager.shape == (1, 12)
+    assert torch.equal(graphed, eager), (graphed.tolist(), eager.tolist())
