@@ -36,8 +36,17 @@ struct GemvArgs {
   float eps;
 };
 
-__device__ __forceinline__ float normw(const void* w, int f32, int i) {
-  return f32 ? ((const float*)w)[i] : (float)((const bf16_t*)w)[i];
+// the 8 norm weights of one 16-byte piece of x, as floats (fp32 weights: two 16-byte loads, bf16: one)
+__device__ __forceinline__ void normw8(const void* w, int f32, int i0, float (&out)[8]) {
+  if (f32) {
+    const f32x4 lo = *(const f32x4*)((const float*)w + i0), hi = *(const f32x4*)((const float*)w + i0 + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { out[j] = lo[j]; out[4 + j] = hi[j]; }
+  } else {
+    const bf16x8 v = *(const bf16x8*)((const bf16_t*)w + i0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) out[j] = (float)v[j];
+  }
 }
 
 __device__ __forceinline__ float dot8(bf16x8 a, bf16x8 b, float acc) {
@@ -69,8 +78,13 @@ __device__ __forceinline__ void gemv_prologue(const GemvArgs& a, bf16_t* fx, flo
       }
     } else if (PRO == PRO_RMSNORM) {
       constexpr int MAXV = 4;                        // K <= 8 * 256 * 4 (launcher)
-      float vals[MAXV][8];
+      float vals[MAXV][8], wv[MAXV][8];              // (the weights are requested with x, not behind the reduction)
       float ssq = 0.f;
+#pragma unroll
+      for (int k = 0; k < MAXV; ++k) {
+        const int iv = tid + k * GV_THREADS;
+        if (iv < nv) normw8(a.norm_w, a.norm_w_f32, 8 * iv, wv[k]);
+      }
 #pragma unroll
       for (int k = 0; k < MAXV; ++k) {
         const int iv = tid + k * GV_THREADS;
@@ -103,61 +117,53 @@ __device__ __forceinline__ void gemv_prologue(const GemvArgs& a, bf16_t* fx, flo
         if (iv < nv) {
           bf16x8 o;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) o[j] = (bf16_t)(normw(a.norm_w, a.norm_w_f32, 8 * iv + j) * (vals[k][j] * rstd));
+          for (int j = 0; j < 8; ++j) o[j] = (bf16_t)(wv[k][j] * (vals[k][j] * rstd));
           *(bf16x8*)(fr + 8 * iv) = o;
         }
       }
-    } else {                                         // PRO_GATED: a wave per group of `group` channels, two groups at a time
+    } else {                                         // PRO_GATED: a wave per group of `group` channels
       constexpr int MAXV = 4;                        // group <= 8 * 64 * 4 (launcher)
       const int ngroups = K / a.group, gv = a.group / 8;
-      for (int g0 = wave; g0 < ngroups; g0 += 2 * GV_WAVES) {
-        bf16x8 xv[2][MAXV], zv[2][MAXV];
+      for (int g = wave; g < ngroups; g += GV_WAVES) {
+        bf16x8 xv[MAXV], zv[MAXV];
+        float wv[MAXV][8];                           // (x, gate and weights of the group are requested together)
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {                // (the loads of both groups before the first use)
-          const int g = min(g0 + q * GV_WAVES, ngroups - 1);
+        for (int k = 0; k < MAXV; ++k) {
+          const int iv = lane + k * 64;
+          if (iv < gv) {
+            xv[k] = *(const bf16x8*)(xr + (int64_t)g * a.group + 8 * iv);
+            if (a.gate) zv[k] = *(const bf16x8*)(a.gate + (int64_t)m * a.gs + (int64_t)g * a.group + 8 * iv);
+            normw8(a.norm_w, a.norm_w_f32, g * a.group + 8 * iv, wv[k]);
+          }
+        }
+        float vals[MAXV][8];
+        float ssq = 0.f;
 #pragma unroll
-          for (int k = 0; k < MAXV; ++k) {
-            const int iv = lane + k * 64;
-            if (iv < gv) {
-              xv[q][k] = *(const bf16x8*)(xr + (int64_t)g * a.group + 8 * iv);
-              if (a.gate) zv[q][k] = *(const bf16x8*)(a.gate + (int64_t)m * a.gs + (int64_t)g * a.group + 8 * iv);
+        for (int k = 0; k < MAXV; ++k) {
+          const int iv = lane + k * 64;
+          if (iv < gv) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              float f = (float)xv[k][j];
+              if (a.gate) {
+                const float gt = (float)zv[k][j];
+                f *= gt * __builtin_amdgcn_rcpf(1.f + __expf(-gt));
+              }
+              vals[k][j] = f;
+              ssq = fmaf(f, f, ssq);
             }
           }
         }
+        ssq = wave_sum(ssq);
+        const float rstd = rsqrtf(ssq / (float)a.group + a.eps);
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const int g = g0 + q * GV_WAVES;
-          if (g >= ngroups) break;
-          float vals[MAXV][8];
-          float ssq = 0.f;
+        for (int k = 0; k < MAXV; ++k) {
+          const int iv = lane + k * 64;
+          if (iv < gv) {
+            bf16x8 o;
 #pragma unroll
-          for (int k = 0; k < MAXV; ++k) {
-            const int iv = lane + k * 64;
-            if (iv < gv) {
-#pragma unroll
-              for (int j = 0; j < 8; ++j) {
-                float f = (float)xv[q][k][j];
-                if (a.gate) {
-                  const float gt = (float)zv[q][k][j];
-                  f *= gt * __builtin_amdgcn_rcpf(1.f + __expf(-gt));
-                }
-                vals[k][j] = f;
-                ssq = fmaf(f, f, ssq);
-              }
-            }
-          }
-          ssq = wave_sum(ssq);
-          const float rstd = rsqrtf(ssq / (float)a.group + a.eps);
-#pragma unroll
-          for (int k = 0; k < MAXV; ++k) {
-            const int iv = lane + k * 64;
-            if (iv < gv) {
-              bf16x8 o;
-#pragma unroll
-              for (int j = 0; j < 8; ++j)
-                o[j] = (bf16_t)(normw(a.norm_w, a.norm_w_f32, g * a.group + 8 * iv + j) * (vals[k][j] * rstd));
-              *(bf16x8*)(fr + (int64_t)g * a.group + 8 * iv) = o;
-            }
+            for (int j = 0; j < 8; ++j) o[j] = (bf16_t)(wv[k][j] * (vals[k][j] * rstd));
+            *(bf16x8*)(fr + (int64_t)g * a.group + 8 * iv) = o;
           }
         }
       }
@@ -174,7 +180,8 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_bf16_kernel(GemvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gv_smem[];
   bf16_t* fx = (bf16_t*)gv_smem;                     // [M][K]
   __shared__ float red[GV_WAVES];
-  __shared__ float part[2][GV_WAVES][R][MT];
+  constexpr int GB = 4;                              // row groups between two meetings of the waves
+  __shared__ float part[2][GB][GV_WAVES][R][MT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = a.K, nv = K / 8;
 
@@ -205,8 +212,8 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_bf16_kernel(GemvArgs a) {
 
   // ---------------------------------------------------------------- the products
   const bf16_t* fl = fx + 8 * (p0 + lane);
-  int par = 0;
-  for (int n0 = blockIdx.x; n0 < a.N; n0 += R * G, par ^= 1) {
+  int par = 0, gi = 0, nflush = blockIdx.x;          // gi: groups since the last meeting; nflush: first row of the first of them
+  for (int n0 = blockIdx.x; n0 < a.N; n0 += R * G) {
     float acc[R][MT];
 #pragma unroll
     for (int r = 0; r < R; ++r)
@@ -240,17 +247,22 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_bf16_kernel(GemvArgs a) {
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         const float sm = wave_sum(acc[r][m]);
-        if (lane == 0) part[par][wave][r][m] = sm;
+        if (lane == 0) part[par][gi][wave][r][m] = sm;
       }
-    __syncthreads();                                 // (the other parity is written by the next group: one barrier a group)
-    if (tid < R * MT) {
-      const int r = tid / MT, m = tid % MT, n = n0 + r * G;
-      if (n < a.N && (MT == 1 || m < a.M)) {
-        float sm = 0.f;
+    // the four partial sums of a row meet in LDS — every GB groups, not every group: between two meetings the waves run
+    // free (a barrier per 2 rows of 20 KB paced the K = 10 240 products); the other parity takes the next GB groups
+    if (++gi == GB || !more) {
+      __syncthreads();
+      for (int i = tid; i < gi * R * MT; i += GV_THREADS) {
+        const int j = i / (R * MT), r = (i / MT) % R, m = i % MT, n = nflush + (j * R + r) * G;
+        if (n < a.N && (MT == 1 || m < a.M)) {
+          float sm = 0.f;
 #pragma unroll
-        for (int w = 0; w < GV_WAVES; ++w) sm += part[par][w][r][m];
-        a.y[(int64_t)m * a.ys + n] = (bf16_t)(sm + (a.bias ? (float)a.bias[n] : 0.f));
+          for (int w = 0; w < GV_WAVES; ++w) sm += part[par][j][w][r][m];
+          a.y[(int64_t)m * a.ys + n] = (bf16_t)(sm + (a.bias ? (float)a.bias[n] : 0.f));
+        }
       }
+      par ^= 1; gi = 0; nflush = n0 + R * G;
     }
     if (more) {
 #pragma unroll
