@@ -278,7 +278,7 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_bf16_kernel(GemvArgs a) {
 // large where K is small in this model (in_proj 22 656 x 4 480, up_proj 15 680 x 4 480: 8 - 11 rows a wave).
 template <int PRO, int MT>
 __global__ __launch_bounds__(GV_THREADS) void gemv_rows_kernel(GemvArgs a) {
-  constexpr int R = 2, NB = 8;
+  constexpr int R = 2, NB = 10;                     // (K = 4 480 is 9 load instructions a row: one batch, 18 loads in flight)
   extern __shared__ __attribute__((aligned(16))) unsigned char gv_smem[];
   bf16_t* fx = (bf16_t*)gv_smem;                     // [M][K]
   __shared__ float red[GV_WAVES];
