@@ -344,12 +344,17 @@ int tv_flash_attn_fp8_fwd(const void* q, const void* k, const void* v, void* o,
  *                                                                             (tv_rmsnorm_gated_fwd; :371-380)
  * norm_weight_dtype TV_F32 or TV_BF16.  M <= 4, M * K * 2 <= 128 KiB, K % 8 == 0; x / W / delta / gate / sum_out rows
  * 16-byte aligned.  The arguments of the prologues not selected are ignored.
+ * Epilogue (conv_state not NULL; K < 8192): the outputs [conv_row0, conv_row0 + conv_channels) — the xBC slice of the
+ * mixer's in_proj — pass through tv_causal_conv1d_update (width 4, SiLU; same arithmetic) before they are stored:
+ * conv_state (M, conv_channels, 4) is shifted and takes the bf16-rounded product, y holds the activation.
+ * Replaces the in_proj -> causal_conv1d_update pair of modeling_nano.py:484-501.
  * --------------------------------------------------------------------- */
 int tv_gemv_bf16_fwd(const void* x, const void* W, const void* bias, void* y, int M, int N, int K,
                      int64_t x_stride, int64_t ldw, int64_t y_stride, int prologue, const void* delta,
                      int64_t delta_stride, void* sum_out, int64_t sum_stride, const void* norm_weight,
                      int norm_weight_dtype, float eps, const void* gate, int64_t gate_stride,
-                     int group_size, void* stream);
+                     int group_size, void* conv_state, const void* conv_weight, const void* conv_bias,
+                     int conv_row0, int conv_channels, void* stream);
 
 /* The decode step of the same operator: ONE query token per sequence against a K / V cache (q_len == 1 in
  * modeling_nano.py:1198-1209; cache layout of HybridMambaAttentionDynamicCache, :205-360).  q (B, Hq, D) and

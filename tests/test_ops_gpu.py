@@ -542,6 +542,32 @@ def test_gemv_fused_prologues(K, M, N, Kd, prologue):
         assert torch.equal(K.gemv_fused(x, eye, None, **kw).view(M, Kd), f.view(M, Kd))
 
 
+@pytest.mark.parametrize("M", [1, 3])
+def test_gemv_fused_conv_epilogue(K, M):
+    """The mixer's in_proj -> causal_conv1d_update pair as one launch: rows [row0, row0 + C) of the product go through the
+    conv update in the epilogue — bit-equal to the two launches (same product kernel, same conv arithmetic), state
+    included, over several tokens."""
+    g = torch.Generator(device=DEV).manual_seed(M)
+    Kd, d_in, C, H = 512, 320, 448, 24
+    N = d_in + C + H
+    W = (torch.randn(N, Kd, device=DEV, generator=g) / math.sqrt(Kd)).bfloat16()
+    nw = torch.ones(Kd, device=DEV)
+    cw = (torch.randn(C, 4, device=DEV, generator=g) * 0.5).bfloat16()
+    cb = torch.randn(C, device=DEV, generator=g).bfloat16()
+    st_a = torch.randn(M, C, 4, device=DEV, generator=g).bfloat16()
+    st_b = st_a.clone()
+    for step in range(5):
+        x = torch.randn(M, 1, Kd, device=DEV, generator=g).bfloat16()
+        two = K.gemv_fused(x, W, None, K.GEMV_RMSNORM, norm_weight=nw, eps=1e-5)
+        conv_two = K.causal_conv1d_update(two[:, 0, d_in:d_in + C], st_a, cw, cb, "silu")
+        one = K.gemv_fused(x, W, None, K.GEMV_RMSNORM, norm_weight=nw, eps=1e-5, conv=(st_b, cw, cb, d_in))
+        assert torch.equal(one[:, 0, d_in:d_in + C], conv_two), step
+        assert torch.equal(one[..., :d_in], two[..., :d_in]) and torch.equal(one[..., d_in + C:], two[..., d_in + C:])
+        assert torch.equal(st_a, st_b), step
+    with pytest.raises(K.TimeViperHipError):
+        K.gemv_fused(x, W, None, conv=(st_b[:, :10], cw, cb, d_in))
+
+
 def test_gemv_fused_strided_rows_and_errors(K):
     g = torch.Generator(device=DEV).manual_seed(0)
     buf = torch.randn(2, 1, 3 * 512, device=DEV, generator=g).bfloat16()

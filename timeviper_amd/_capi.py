@@ -46,7 +46,8 @@ SIGNATURES = {
     "tv_flash_attn_variants_built": (_i, []),
     "tv_flash_attn_fp8_workspace_bytes": (_z, [_i] * 5),
     "tv_flash_attn_fp8_fwd": (_i, [_p] * 5 + [_i] * 6 + [_l] * 12 + [_f, _i, _i, _p, _z, _p]),
-    "tv_gemv_bf16_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _l, _l, _l, _i, _p, _l, _p, _l, _p, _i, _f, _p, _l, _i, _p]),
+    "tv_gemv_bf16_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _l, _l, _l, _i, _p, _l, _p, _l, _p, _i, _f, _p, _l, _i,
+                              _p, _p, _p, _i, _i, _p]),
     "tv_attn_decode_workspace_bytes": (_z, [_i, _i, _i, _i]),
     "tv_attn_decode_fwd": (_i, [_p] * 5 + [_i, _i, _p, _i, _i, _i] + [_l] * 10 + [_f, _i, _p, _z, _p]),
     "tv_attn_rank_workspace_bytes": (_z, [_i, _i]),
@@ -70,7 +71,7 @@ class TimeViperHipError(RuntimeError):
     pass
 
 
-ABI_VERSION = 9      # tv_abi_version() of the library these SIGNATURES describe (csrc/capi.cpp)
+ABI_VERSION = 10      # tv_abi_version() of the library these SIGNATURES describe (csrc/capi.cpp)
 
 
 def lib_path() -> Path:

@@ -16,7 +16,7 @@
 //   PRO_GATED     v = x * silu(z), f = bf16(w * (v * rsqrt(mean_group(v^2) + eps)))     MambaRMSNormGated, :371-380
 // with the rounding points of the stand-alone kernels (norms.hip), so the fused step and the unfused one agree to the
 // accumulation order of the dot products.  fp32 accumulation (v_dot2c_f32_bf16), one rounding of y.
-#include "common.hpp"
+#include "ssd_common.hpp"
 
 namespace {
 
@@ -34,6 +34,10 @@ struct GemvArgs {
   int M, N, K, group, norm_w_f32;
   int64_t xs, ldw, ys, ds, ss, gs;
   float eps;
+  // epilogue (row-per-wave kernel): rows [conv_lo, conv_hi) of y pass through a width-4 causal-conv update + SiLU
+  bf16_t* conv_state;              // (M, conv_hi - conv_lo, 4): shifted left, the new value appended
+  const bf16_t *conv_w, *conv_b;   // (channels, 4), (channels) or NULL
+  int conv_lo, conv_hi;
 };
 
 // the 8 norm weights of one 16-byte piece of x, as floats (fp32 weights: two 16-byte loads, bf16: one)
@@ -47,6 +51,12 @@ __device__ __forceinline__ void normw8(const void* w, int f32, int i0, float (&o
 #pragma unroll
     for (int j = 0; j < 8; ++j) out[j] = (float)v[j];
   }
+}
+
+// sum over the 64 lanes, as a wave-uniform value (DPP row shifts / broadcasts + one readlane: no LDS crossbar)
+__device__ __forceinline__ float wave_total(float v) {
+  v = ssdk::wave_incl_scan_dpp(v);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 __device__ __forceinline__ float dot8(bf16x8 a, bf16x8 b, float acc) {
@@ -246,7 +256,7 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_bf16_kernel(GemvArgs a) {
     for (int r = 0; r < R; ++r)
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        const float sm = wave_sum(acc[r][m]);
+        const float sm = wave_total(acc[r][m]);
         if (lane == 0) part[par][gi][wave][r][m] = sm;
       }
     // the four partial sums of a row meet in LDS — every GB groups, not every group: between two meetings the waves run
@@ -326,19 +336,54 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_rows_kernel(GemvArgs a) {
         }
     };
     if (n0 != gw) load_batch(cur, n0, 0);
+    // lane r finishes row r of the pair; its conv-update operands (epilogue) are requested now, behind the W loads
+    const int nmine = n0 + min(lane, R - 1) * TW;
+    const bool conv_mine = MT == 1 && a.conv_state && lane < R && nmine < a.N && nmine >= a.conv_lo && nmine < a.conv_hi;
+    bf16x4 c_old = {}, c_w = {};
+    float c_b = 0.f;
+    if (conv_mine) {
+      const int c = nmine - a.conv_lo;
+      c_old = *(const bf16x4*)(a.conv_state + (int64_t)c * 4);
+      c_w = *(const bf16x4*)(a.conv_w + (int64_t)c * 4);
+      if (a.conv_b) c_b = (float)a.conv_b[c];
+    }
     fma_batch(cur, 0);
     for (int i0 = NB; i0 < nins; i0 += NB) {
       load_batch(cur, n0, i0);
       fma_batch(cur, i0);
     }
+    float tot[R][MT];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int n = n0 + r * TW;
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) tot[r][m] = (MT == 1 || m < a.M) ? wave_total(acc[r][m]) : 0.f;
+    if (lane < R && nmine < a.N) {
+      const float bs = a.bias ? (float)a.bias[nmine] : 0.f;
 #pragma unroll
       for (int m = 0; m < MT; ++m)
         if (MT == 1 || m < a.M) {
-          const float sm = wave_sum(acc[r][m]);
-          if (lane == 0 && n < a.N) a.y[(int64_t)m * a.ys + n] = (bf16_t)(sm + (a.bias ? (float)a.bias[n] : 0.f));
+          float v = tot[0][m];
+#pragma unroll
+          for (int r = 1; r < R; ++r) v = lane == r ? tot[r][m] : v;
+          bf16_t out = (bf16_t)(v + bs);
+          if (a.conv_state && nmine >= a.conv_lo && nmine < a.conv_hi) {
+            // tv_causal_conv1d_update on this channel, with its arithmetic (conv1d.hip): window = state[1..3], out
+            const int c = nmine - a.conv_lo;
+            bf16_t* st = a.conv_state + ((int64_t)m * (a.conv_hi - a.conv_lo) + c) * 4;
+            bf16x4 old = c_old, wv = c_w;
+            float acc_c = c_b;
+            if (MT != 1) {                           // (several rows of x: loaded here)
+              old = *(const bf16x4*)st;
+              wv = *(const bf16x4*)(a.conv_w + (int64_t)c * 4);
+              acc_c = a.conv_b ? (float)a.conv_b[c] : 0.f;
+            }
+            const bf16x4 win = {old[1], old[2], old[3], out};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc_c = fmaf((float)wv[j], (float)win[j], acc_c);
+            *(bf16x4*)st = win;
+            out = (bf16_t)silu_f(acc_c);
+          }
+          a.y[(int64_t)m * a.ys + nmine] = out;
         }
     }
   }
@@ -389,7 +434,7 @@ int launch_gemv_rows(const GemvArgs& a, hipStream_t st) {
 template <int PRO, int MT>
 int launch_gemv_m(const GemvArgs& a, hipStream_t st) {
   static const int force = [] { const char* e = getenv("TV_GEMV_SPLITK"); return e ? atoi(e) : -1; }();    // (dev: 0 / 1)
-  const bool splitk = force >= 0 ? force != 0 : a.K >= 8192;
+  const bool splitk = a.conv_state ? false : (force >= 0 ? force != 0 : a.K >= 8192);
   return splitk ? launch_gemv_r<PRO, MT, 2, 8>(a, st) : launch_gemv_rows<PRO, MT>(a, st);
 }
 template <int PRO>
@@ -403,7 +448,8 @@ extern "C" int tv_gemv_bf16_fwd(const void* x, const void* W, const void* bias, 
                                 int64_t x_stride, int64_t ldw, int64_t y_stride, int prologue, const void* delta,
                                 int64_t delta_stride, void* sum_out, int64_t sum_stride, const void* norm_weight,
                                 int norm_weight_dtype, float eps, const void* gate, int64_t gate_stride,
-                                int group_size, void* stream) {
+                                int group_size, void* conv_state, const void* conv_weight, const void* conv_bias,
+                                int conv_row0, int conv_channels, void* stream) {
   TV_CHECK_ARG(x && W && y, "gemv: null pointer");
   TV_CHECK_ARG(M >= 1 && M <= GV_MAXM && N >= 1 && K >= 8, "gemv: M %d must be 1..%d, N %d >= 1, K %d >= 8", M, GV_MAXM, N, K);
   if (K % 8 || ldw % 8 || x_stride % 8 || ((uintptr_t)x & 15) || ((uintptr_t)W & 15))
@@ -430,6 +476,15 @@ extern "C" int tv_gemv_bf16_fwd(const void* x, const void* W, const void* bias, 
     if (group_size > 8 * 64 * 4) TV_UNSUPPORTED("gemv: gated-norm prologue holds groups of <= %d channels", 8 * 64 * 4);
     if (gate && (gate_stride % 8 || ((uintptr_t)gate & 15))) TV_UNSUPPORTED("gemv: gate must be 16-byte aligned rows");
     a.gate = (const bf16_t*)gate; a.gs = gate_stride; a.group = group_size;
+  }
+  a.conv_state = nullptr; a.conv_w = a.conv_b = nullptr; a.conv_lo = a.conv_hi = 0;
+  if (conv_state) {
+    TV_CHECK_ARG(conv_weight && conv_row0 >= 0 && conv_channels > 0 && conv_row0 + conv_channels <= N,
+                 "gemv: conv epilogue rows [%d, %d) outside the %d outputs", conv_row0, conv_row0 + conv_channels, N);
+    if (K >= 8192) TV_UNSUPPORTED("gemv: the conv epilogue is built into the row-per-wave kernel (K < 8192)");
+    if (((uintptr_t)conv_state & 7) || ((uintptr_t)conv_weight & 7)) TV_UNSUPPORTED("gemv: conv state / weight must be 8-byte aligned");
+    a.conv_state = (bf16_t*)conv_state; a.conv_w = (const bf16_t*)conv_weight; a.conv_b = (const bf16_t*)conv_bias;
+    a.conv_lo = conv_row0; a.conv_hi = conv_row0 + conv_channels;
   }
   hipStream_t st = (hipStream_t)stream;
   switch (prologue) {

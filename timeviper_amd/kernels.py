@@ -539,11 +539,13 @@ def gemv_takes(x: torch.Tensor, weight: torch.Tensor) -> bool:
 
 
 def gemv_fused(x, weight, bias=None, prologue=GEMV_NONE, delta=None, sum_out=None, norm_weight=None, eps=0.0,
-               gate=None, group_size=0):
+               gate=None, group_size=0, conv=None):
     """y = f(x) @ weight.T (+ bias) for 1..4 rows — the linear layers of a decode step (torch.nn.Linear at q_len 1) with
     the single-row operator in front of them computed in the kernel's prologue: GEMV_RMSNORM (NemotronHRMSNorm with the
     block's residual add: `delta` is added to x first, the sum goes to `sum_out`), GEMV_RELU2 (the MLP activation),
-    GEMV_GATED (MambaRMSNormGated with `gate`), rounding where the stand-alone operators round."""
+    GEMV_GATED (MambaRMSNormGated with `gate`), rounding where the stand-alone operators round.
+    `conv=(conv_state, weight, bias, row0)`: the outputs [row0, row0 + C) go through `causal_conv1d_update` (width 4,
+    SiLU) on conv_state (B, C, 4) before they are stored — the mixer's in_proj -> conv pair as one launch (K < 8192)."""
     _gpu(x, weight, bias, delta, sum_out, norm_weight, gate)
     K = x.shape[-1]
     x2 = _rows2d(x)
@@ -564,11 +566,20 @@ def gemv_fused(x, weight, bias=None, prologue=GEMV_NONE, delta=None, sum_out=Non
         if not norm_weight.is_contiguous() or norm_weight.numel() != K:
             raise TimeViperHipError("gemv_fused: norm_weight must be a contiguous vector of K entries")
         nw_dt = _dt(norm_weight)
+    cst = cw = cb = None
+    row0 = nch = 0
+    if conv is not None:
+        cst, cw, cb, row0 = conv
+        _gpu(cst, cw, cb)
+        nch = cst.shape[1]
+        if (cst.dtype != x.dtype or cw.dtype != x.dtype or not cst.is_contiguous() or not cw.is_contiguous()
+                or cst.shape != (M, nch, 4) or cw.shape != (nch, 4) or (cb is not None and (cb.dtype != x.dtype or not cb.is_contiguous()))):
+            raise TimeViperHipError("gemv_fused: conv needs a contiguous (rows, C, 4) state and (C, 4) weight of x's dtype")
     check(_capi.lib().tv_gemv_bf16_fwd(
         _p(x2), _p(weight), _p(bias), _p(y), M, N, K, x2.stride(0), weight.stride(0), N, int(prologue),
         _p(d2), 0 if d2 is None else d2.stride(0), _p(s2), 0 if s2 is None else s2.stride(0),
         _p(norm_weight), nw_dt, float(eps), _p(g2), 0 if g2 is None else g2.stride(0), int(group_size),
-        _stream()), "tv_gemv_bf16_fwd")
+        _p(cst), _p(cw), _p(cb), int(row0), int(nch), _stream()), "tv_gemv_bf16_fwd")
     return y
 
 

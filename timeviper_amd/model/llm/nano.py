@@ -428,18 +428,23 @@ class NemotronHMamba2Mixer(nn.Module):
 
     def decode_fused(self, hidden, delta, norm, cache_params):
         """One decode token with the block's RMSNorm (+ residual add) inside in_proj and the gated norm inside out_proj:
-        in_proj -> conv update -> state update -> out_proj, 4 launches.  Returns (residual stream, mixer output)."""
+        in_proj (+ conv update in its epilogue) -> state update -> out_proj, 3 launches.  Returns (residual stream, mixer output)."""
         B = hidden.shape[0]
         new_hidden = torch.empty_like(hidden) if delta is not None else hidden
-        proj = K.gemv_fused(hidden, self.in_proj.weight, self.in_proj.bias, K.GEMV_RMSNORM, delta=delta,
-                            sum_out=new_hidden if delta is not None else None, norm_weight=norm.weight,
-                            eps=norm.variance_epsilon)
         gts = self.n_groups * self.ssm_state_size
         d_in = self.intermediate_size
+        conv_state = cache_params.conv_states[self.layer_idx]
+        w = self.conv1d.weight.squeeze(1)
+        # the conv update rides in the product's epilogue where the kernel offers it (width 4, SiLU, K < 8192)
+        conv_in = (self.conv_kernel_size == 4 and self.activation in ("silu", "swish") and hidden.shape[-1] < 8192
+                   and conv_state.dtype == hidden.dtype and conv_state.is_contiguous() and w.is_contiguous())
+        proj = K.gemv_fused(hidden, self.in_proj.weight, self.in_proj.bias, K.GEMV_RMSNORM, delta=delta,
+                            sum_out=new_hidden if delta is not None else None, norm_weight=norm.weight,
+                            eps=norm.variance_epsilon,
+                            conv=(conv_state, w, self.conv1d.bias, d_in) if conv_in else None)
         gate, xBC, dt = proj.split([d_in, self.conv_dim, self.num_heads], dim=-1)
         negA, D32, dtb32 = self._consts()
-        xBC = K.causal_conv1d_update(xBC[:, 0], cache_params.conv_states[self.layer_idx], self.conv1d.weight.squeeze(1),
-                                     self.conv1d.bias, self.activation)
+        xBC = xBC[:, 0] if conv_in else K.causal_conv1d_update(xBC[:, 0], conv_state, w, self.conv1d.bias, self.activation)
         x, Bm, Cm = torch.split(xBC, [d_in, gts, gts], dim=-1)
         y = K.selective_state_update(
             cache_params.ssm_states[self.layer_idx], x.reshape(B, self.num_heads, self.head_dim), dt[:, 0], negA,
