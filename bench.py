@@ -372,9 +372,10 @@ def config_decode(args):
     of `generate()` (modeling_nano.py:484-546, 1666-1689) on tv_causal_conv1d_update, tv_selective_state_update and
     tv_attn_decode_fwd.  `value`: tokens/s of the step replayed as ONE hipGraph (llm/decode_graph.py: static K / V
     buffers, key count on the device), greedy, the token fed back; the host-driven loop is timed beside it
-    (`config.eager_tokens_per_s`) and gives the per-kernel rooflines (events around the operator calls): the state
-    update (HBM: the fp32 state of every head read and written once per token, 2 x 5.24 MB per Mamba layer) and the
-    split-KV attention (HBM: K and V of the cache read once per token and attention layer)."""
+    (`config.eager_tokens_per_s`) and gives the per-kernel rooflines (events around the operator calls): the
+    matrix-vector products (HBM: every weight matrix once per token — the dominant kernel, 16.6 GB of the token's
+    17.5 GB), the state update (the fp32 state of every head read and written once per token, 2 x 5.24 MB per Mamba
+    layer) and the split-KV attention (K and V of the cache read once per token and attention layer)."""
     from timeviper_amd.build import ensure_built
     ensure_built()
     from timeviper_amd import kernels as K
@@ -392,7 +393,7 @@ def config_decode(args):
     emb = (torch.randn(1, L, cfg.hidden_size, device=dev, generator=g) * 0.02).bfloat16()
     steps, warm = max(args.steps, 16), max(args.warmup, 4)
     host_pos = torch.ones(1, dtype=torch.long)
-    recs = {"ssu": [], "attn": []}
+    recs = {"ssu": [], "attn": [], "gemv": []}
 
     def timed(name, orig, nbytes):
         def f(*a, **kw):
@@ -419,7 +420,8 @@ def config_decode(args):
         for _ in range(warm):
             tok = llm(input_ids=tok, past_key_values=cache, use_cache=True, cache_position=host_pos).logits[:, -1].argmax(-1).view(1, 1)
         torch.cuda.synchronize()
-        orig_ssu, orig_attn = K.selective_state_update, K.flash_attn_decode
+        orig_ssu, orig_attn, orig_gemv = K.selective_state_update, K.flash_attn_decode, K.gemv_fused
+        K.gemv_fused = timed("gemv", orig_gemv, lambda x, w, *a, **kw: w.numel() * w.element_size())
         K.selective_state_update = timed("ssu", orig_ssu, lambda state, *a, **kw: 2 * state.numel() * state.element_size())
         K.flash_attn_decode = timed("attn", orig_attn, lambda q, k, v, *a, **kw: 2 * k.shape[0] * k.shape[1] * k.shape[2] * k.shape[3] * k.element_size())
         t0 = time.perf_counter()
@@ -427,7 +429,7 @@ def config_decode(args):
             tok = llm(input_ids=tok, past_key_values=cache, use_cache=True, cache_position=host_pos).logits[:, -1].argmax(-1).view(1, 1)
         torch.cuda.synchronize()
         eager_s = time.perf_counter() - t0
-        K.selective_state_update, K.flash_attn_decode = orig_ssu, orig_attn
+        K.selective_state_update, K.flash_attn_decode, K.gemv_fused = orig_ssu, orig_attn, orig_gemv
         # ---- the same step as one graph launch per token
         gsteps = max(steps, 64)
         cache.begin_static_decode(warm + gsteps + 8)
@@ -446,6 +448,9 @@ def config_decode(args):
         out = stepper.logits
     assert torch.isfinite(out.float()).all()
     weights = sum(p.numel() * p.element_size() for n, p in llm.named_parameters() if "embed" not in n)
+    rl_gemv = roofline("gemv", "gemv_rows_kernel / gemv_bf16_kernel (tv_gemv_bf16_fwd: every linear layer of the token, norm / activation "
+                               "prologues, conv-update epilogue; bytes: the weight matrices)")
+    rl_gemv["bytes_per_launch"] = round(sum(b for _, _, b in recs["gemv"]) / len(recs["gemv"]))
     rl_ssu = roofline("ssu", "state_update_rows_kernel (tv_selective_state_update)")
     rl_attn = roofline("attn", "attn_decode_kernel + attn_decode_merge_kernel (tv_attn_decode_fwd)")
     print(json.dumps({
@@ -460,7 +465,7 @@ def config_decode(args):
                    "eager_tokens_per_s": round(steps / eager_s, 2), "eager_ms_per_step": round(eager_s / steps * 1e3, 3),
                    "weight_bytes_per_token": weights,
                    "weight_stream_floor_ms": round(weights / (HBM_PEAK_GBS * 1e9) * 1e3, 3)},
-        "roofline": rl_ssu, "rooflines": [rl_ssu, rl_attn]}), flush=True)
+        "roofline": rl_gemv, "rooflines": [rl_gemv, rl_ssu, rl_attn]}), flush=True)
 
 
 class CudaEnv:
