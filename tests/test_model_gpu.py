@@ -663,9 +663,10 @@ def test_fused_decode_step_matches_the_unfused_one(monkeypatch):
     assert runs["0"][2] == []
     assert runs["1"][2][0] == K.GEMV_NONE                  # the prefill's lm_head on its last position is one row too
     per_token = runs["1"][2][1:][:(len(runs["1"][2]) - 1) // 6]
-    # M: rmsnorm-in_proj (conv update in its epilogue) + gated-out_proj; -: rmsnorm-up + relu2-down; *: q, k, v, o; the head
-    assert per_token == [K.GEMV_RMSNORM, K.GEMV_GATED, K.GEMV_RMSNORM, K.GEMV_RELU2, 0, 0, 0, 0,
-                         K.GEMV_RMSNORM, K.GEMV_GATED, K.GEMV_RMSNORM, K.GEMV_RELU2, 0, 0, 0, 0, 0], per_token
+    # M: rmsnorm-in_proj (conv update in its epilogue) + gated-out_proj; -: rmsnorm-up + relu2-down; *: rmsnorm-[q; k; v] + o;
+    # the head
+    blocks = [K.GEMV_RMSNORM, K.GEMV_GATED, K.GEMV_RMSNORM, K.GEMV_RELU2, K.GEMV_RMSNORM, K.GEMV_NONE]
+    assert per_token == blocks + blocks + [K.GEMV_NONE], per_token
     for a, b in zip(runs["0"][0], runs["1"][0]):
         assert relerr(a, b) < 2e-2, relerr(a, b)
     c0, c1 = runs["0"][1], runs["1"][1]

@@ -526,6 +526,38 @@ class NemotronHAttention(nn.Module):
         return o, None, past_key_value
 
 
+    def _qkv_weight(self):
+        """[q; k; v] as one (N, K) matrix for the decode token's single product (a copy: 64 MB per layer at 9B dims), rebuilt
+        when a projection's storage or version changes."""
+        ws = (self.q_proj.weight, self.k_proj.weight, self.v_proj.weight)
+        key = tuple((w.data_ptr(), w._version, w.dtype, w.device) for w in ws)
+        if getattr(self, "_qkv_key", None) != key:
+            self._qkv_cat = torch.cat([w.detach() for w in ws], dim=0).contiguous()
+            self._qkv_key = key
+        return self._qkv_cat
+
+    def decode_fused(self, hidden, delta, norm, cache):
+        """One decode token: the block's RMSNorm (+ residual add) in the prologue of ONE q / k / v product, cache append,
+        split-KV attention, o_proj — 4 launches + the cache writes, against 7."""
+        B = hidden.shape[0]
+        new_hidden = torch.empty_like(hidden) if delta is not None else hidden
+        nq, nkv = self.num_heads * self.head_dim, self.num_key_value_heads * self.head_dim
+        qkv = K.gemv_fused(hidden, self._qkv_weight(), None, K.GEMV_RMSNORM, delta=delta,
+                           sum_out=new_hidden if delta is not None else None, norm_weight=norm.weight,
+                           eps=norm.variance_epsilon)
+        q, k, v = qkv.split([nq, nkv, nkv], dim=-1)
+        q = q.view(B, 1, self.num_heads, self.head_dim)
+        k = k.view(B, 1, self.num_key_value_heads, self.head_dim)
+        v = v.view(B, 1, self.num_key_value_heads, self.head_dim)
+        kc, vc = cache.update(k, v, self.layer_idx)
+        if cache.static_decode:
+            kb, vb = cache.kv_buffers(self.layer_idx)
+            o = K.flash_attn_decode(q, kb, vb, seqlens_k=cache.decode_lens(self.layer_idx))
+        else:
+            o = K._flash_attention_forward(q, kc, vc, attention_mask=None, query_length=1, is_causal=self.is_causal)
+        return new_hidden, _linear(self.o_proj, o.reshape(B, 1, nq))
+
+
 NemotronHFlashAttention2 = NemotronHAttention
 NemotronHSdpaAttention = NemotronHAttention
 NEMOTRONH_ATTENTION_CLASSES = {"eager": NemotronHAttention,
@@ -701,6 +733,8 @@ class NemotronHModel(PdropMixin, nn.Module):
                       and int(cache_position[0]) > 0 and not output_hidden_states and not self.check_nan
                       and hidden.shape[-1] % 8 == 0 and hidden.shape[-1] <= 8192
                       and all(p.dtype == torch.bfloat16 for p in self.layers[0].mixer.parameters() if p.dim() == 2))
+        # attention blocks join when their projections carry no bias (the stacked q / k / v product takes none)
+        attn_fused = fused_step and not self.config.attention_bias
         for layer_idx, block in enumerate(self.layers):
             if self.use_pdrop and train_pdrop_args is not None \
                     and layer_idx in self.pdrop_layers \
@@ -722,12 +756,12 @@ class NemotronHModel(PdropMixin, nn.Module):
             if output_hidden_states:
                 all_hidden += ((hidden if delta is None else hidden + delta),)
             # x_{i+1} = x_i + mixer(norm(x_i)); the add of layer i-1 is fused into this norm
-            if fused_step and block.block_type != "attention":
+            if fused_step and (block.block_type != "attention" or attn_fused):
                 # decode token: the norm (+ add) runs in the prologue of the block's first matrix-vector product
-                if block.block_type == "mamba":
-                    hidden, delta = block.mixer.decode_fused(hidden, delta, block.norm, past_key_values)
-                else:
+                if block.block_type == "mlp":
                     hidden, delta = block.mixer.decode_fused(hidden, delta, block.norm)
+                else:
+                    hidden, delta = block.mixer.decode_fused(hidden, delta, block.norm, past_key_values)
                 continue
             if delta is None:
                 normed = block.norm(hidden)
