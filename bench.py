@@ -123,6 +123,10 @@ class OpTimers:
 
         def gelu(x, inplace=False):
             return ("gelu", 2 * x.numel() * x.element_size())
+        def gemm(x, weight, bias=None, epilogue=0, out=None):
+            rows = x.numel() // x.shape[-1]
+            return ("gemm_fused", 2.0 * rows * weight.shape[0] * weight.shape[1])      # the activation's flops are not counted
+        self._wrap("linear_fused", gemm)
         self._wrap("mamba_chunk_scan_combined", scan)
         self._wrap("flash_attn_func", attn)
         self._wrap("patch_embed", patch)
@@ -223,6 +227,8 @@ class OpTimers:
         out = [self.scan_roofline(bytes_per_token),
                self.mfma_roofline("attn_vit", "flash_fwd_stream_kernel, ViT frames (non-causal, head_dim 72; useful FLOPs)"),
                self.mfma_roofline("attn_causal", "flash_fwd_kernel, causal GQA (LLM attention layers; useful FLOPs)")]
+        out.append(self.mfma_roofline("gemm_fused", "gemm_bf16_kernel<bias + erf-GELU> (tv_gemm_bf16_fwd: ViT fc1 with the activation in "
+                                                    "the epilogue; GEMM FLOPs only)"))
         out += self.patch_rooflines()
         out += [self.hbm_roofline("conv", "conv1d_xbc_kernel + conv1d_bc_cb_kernel (tv_causal_conv1d_xbc_cb_fwd: conv + SiLU + "
                                           "x|B|C split + causal C.B^T fragments; bytes: xBC read, x|B|C written)"),
