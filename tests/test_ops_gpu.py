@@ -1065,6 +1065,70 @@ def test_gemm_fused_gelu_equals_gemm_then_gelu(K):
     close(one, ref.float().cpu(), 2e-2, 2e-2, "vs torch (hipBLASLt + GELU)")
 
 
+@pytest.mark.parametrize("M,N,Kd,grid", [(1024, 1024, 1152, 8), (2187, 4352, 1152, 8), (1500, 1160, 1152, 16),
+                                         (1300, 1152, 4352, 8), (729 * 8, 3456, 1408, 64), (256, 256, 1152, 8),
+                                         (4096, 1152, 256, 8)])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_gemm_persistent_kernel(K, M, N, Kd, grid, epi):
+    """The persistent GEMM (csrc/gemm_persist.hip: tile epilogue inside the next tile's main loop, old C through the
+    matrix pipe) forced onto small grids so that every work-group walks several tiles, shifted edge tiles in M and N
+    included: against the fp64 product, and bit-equal to the per-tile kernel for the bias epilogues."""
+    if epi == 2 and Kd < 1152:
+        pytest.skip("accumulate variant takes K >= 1 152")
+    g = torch.Generator().manual_seed(M + N + Kd + epi)
+    a = (torch.randn(M, Kd, generator=g) * 0.5).bfloat16().to(DEV)
+    w = (torch.randn(N, Kd, generator=g) * (1.0 / math.sqrt(Kd))).bfloat16().to(DEV)
+    b = torch.randn(N, generator=g).bfloat16()
+    b = (b if M % 2 else b.float()).to(DEV)
+    c0 = torch.randn(M, N, generator=g).bfloat16().to(DEV)
+    acc = a.double().cpu() @ w.double().cpu().t()
+
+    def run():
+        if epi == 2:
+            return K.linear_fused(a, w, None, epilogue=2, out=c0.clone())
+        return K.linear_fused(a, w, b, epilogue=epi)
+    try:
+        K.gemm_set_persist(1, grid)
+        out = run()
+        torch.cuda.synchronize()
+        K.gemm_set_persist(0, 0)
+        tile = run()
+    finally:
+        K.gemm_set_persist(-1, 0)
+    if epi == 2:
+        ref = acc + c0.double().cpu()
+    else:
+        pre = acc + b.double().cpu()
+        ref = torch.nn.functional.gelu(pre.float().bfloat16().double()) if epi == 1 else pre
+    close(out, ref, 2.0 ** -8 * (2.2 if epi == 1 else 1.0), 1e-2 if epi == 1 else 2e-3, f"persistent gemm epi {epi}")
+    if epi != 2:
+        assert torch.equal(out, tile), "persistent and per-tile kernel differ"
+    else:
+        close(out, tile.float().cpu(), 2.0 ** -7, 2e-3, "persistent vs per-tile accumulate")
+
+
+def test_gemm_persistent_repeated_runs_are_identical(K):
+    """Race screen for the counted waits: 20 launches of each epilogue on a 64-work-group grid give the same bits."""
+    g = torch.Generator().manual_seed(11)
+    M, N, Kd = 729 * 16, 1152, 1152
+    a = (torch.randn(M, Kd, generator=g) * 0.5).bfloat16().to(DEV)
+    w = (torch.randn(N, Kd, generator=g) * 0.03).bfloat16().to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    c0 = torch.randn(M, N, generator=g).bfloat16().to(DEV)
+    try:
+        K.gemm_set_persist(1, 64)
+        for epi in (0, 1, 2):
+            outs = []
+            for _ in range(20):
+                outs.append(K.linear_fused(a, w, None, epilogue=2, out=c0.clone()) if epi == 2
+                            else K.linear_fused(a, w, b, epilogue=epi))
+            torch.cuda.synchronize()
+            for o in outs[1:]:
+                assert torch.equal(o, outs[0]), f"epilogue {epi}: two launches differ"
+    finally:
+        K.gemm_set_persist(-1, 0)
+
+
 # ---------------------------------------------------------------- ragged / padded batches (flash_attention_class.py:59-91)
 def test_flash_attn_varlen_ragged_and_key_padding_mask(K):
     """flash_attn_varlen_qkvpacked_func on a ragged batch (runs of equal and unequal lengths, an empty sequence) against the

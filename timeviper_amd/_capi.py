@@ -41,6 +41,7 @@ SIGNATURES = {
     "tv_ssd_scan_set_impl": (None, [_i]),
     "tv_selective_state_update": (_i, [_p] * 9 + [_i] * 7 + [_p]),
     "tv_gemm_bf16_fwd": (_i, [_p, _p, _p, _p, _l, _i, _i, _l, _l, _l, _i, _i, _p]),
+    "tv_gemm_set_persist": (None, [_i, _i]),
     "tv_flash_attn_fwd": (_i, [_p] * 5 + [_i] * 6 + [_l] * 12 + [_f, _i, _i, _p]),
     "tv_flash_attn_set_variant": (None, [_i]),
     "tv_flash_attn_variants_built": (_i, []),
@@ -71,7 +72,7 @@ class TimeViperHipError(RuntimeError):
     pass
 
 
-ABI_VERSION = 10      # tv_abi_version() of the library these SIGNATURES describe (csrc/capi.cpp)
+ABI_VERSION = 11      # tv_abi_version() of the library these SIGNATURES describe (csrc/capi.cpp)
 
 
 def lib_path() -> Path:

@@ -32,47 +32,12 @@
 //     SIMD always has one wave feeding it (MI355X guide, "two waves per SIMD": pair matrix with memory).
 //     Rules the schedule obeys (derived in DESIGN.md section 3): data retired by the wait in phase j is read in phase
 //     j + 1 or later; a half-tile is overwritten no earlier than 2 phases after the phase of its last fragment read.
-#include <math.h>
-#include <stdlib.h>
-#include <type_traits>
-#include "ssd_common.hpp"
+#include "gemm_common.hpp"
 
+namespace tvgemm {
 namespace {
-using namespace ssdk;
 
-enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_ACCUM = 2 };
-
-constexpr int BM = 256, BN = 256, BK = 64;
-constexpr int HALF_BYTES = 128 * BK * 2;          // one half-tile: 128 rows x 128 bytes
-constexpr int TILE_BYTES = 4 * HALF_BYTES;        // A0 A1 W0 W1 of one K-tile
-constexpr int LDS_BYTES = 2 * TILE_BYTES;         // two K-tiles
-
-struct GemmArgs {
-  const bf16_t *A, *W;
-  const void* bias;        // fp32 or bf16 (bias_f32), may be NULL
-  bf16_t* C;
-  int M, N, K;
-  int64_t lda, ldw, ldc;
-  int tiles_m, tiles_n, group_m;
-  int bias_f32;
-};
-
-// same formula as norms.hip's gelu_erf (A&S 7.1.26): the fused and the two-pass path agree bit for bit
-__device__ __forceinline__ float gelu_erf_f(float x) {
-  const float z = fabsf(x) * 0.70710678118654752f;
-  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.f));
-  float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
-  p = __builtin_fmaf(p, t, 1.421413741f);
-  p = __builtin_fmaf(p, t, -0.284496736f);
-  p = __builtin_fmaf(p, t, 0.254829592f);
-  p *= t;
-  const float e = __builtin_amdgcn_exp2f(z * z * -1.4426950408889634f);
-  const float erf_abs = __builtin_fmaf(-p, e, 1.f);
-  const float hx = 0.5f * x;
-  return __builtin_fmaf(hx, copysignf(erf_abs, x), hx);
-}
-
-#define GEMM_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+constexpr int LDS_BYTES = RING_BYTES;
 
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_bf16_kernel(GemmArgs a) {
@@ -372,6 +337,9 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
 }
 
 }  // namespace
+}  // namespace tvgemm
+
+using namespace tvgemm;
 
 extern "C" int tv_gemm_bf16_fwd(const void* A, const void* W, const void* bias, void* C, int64_t M, int N, int K,
                                 int64_t lda, int64_t ldw, int64_t ldc, int epilogue, int bias_dtype, void* stream) {
@@ -400,6 +368,8 @@ extern "C" int tv_gemm_bf16_fwd(const void* A, const void* W, const void* bias, 
   }
   if ((int64_t)a.tiles_m * a.tiles_n >= (1ll << 31)) TV_UNSUPPORTED("gemm: too many tiles");
   hipStream_t st = (hipStream_t)stream;
+  // the ViT's big shapes: persistent work-groups, tile epilogue inside the main loop (gemm_persist.hip)
+  if (persist_takes(a, epilogue)) return launch_persist(a, epilogue, st);
   switch (epilogue) {
     case EPI_BIAS: return launch_gemm<EPI_BIAS>(a, st);
     case EPI_BIAS_GELU: return launch_gemm<EPI_BIAS_GELU>(a, st);

@@ -286,6 +286,14 @@ def linear_fused(x, weight, bias=None, epilogue: int = GEMM_BIAS, out=None):
     return out
 
 
+def gemm_set_persist(mode: int = -1, grid: int = 0) -> None:
+    """Which of the two GEMM kernels `linear_fused` runs on: -1 automatic (the persistent kernel from 4 tiles per
+    compute unit on), 0 the per-tile kernel only, 1 the persistent kernel wherever the shape allows; `grid`:
+    work-groups of the persistent kernel (0 = one per compute unit; tests use 8 so that small problems still give
+    every work-group several tiles)."""
+    _capi.lib().tv_gemm_set_persist(int(mode), int(grid))
+
+
 # ------------------------------------------------------------------- SSD scan
 def _row_view(t: torch.Tensor, inner: int):
     """(B, L, ...) tensor whose trailing dims are contiguous with `inner`
