@@ -107,7 +107,12 @@ class Attention(nn.Module):
     def heads(self, x):
         """qkv projection + attention, without the output projection"""
         B, N, C = x.shape
-        if ZeroPaddedLinears.wanted(x, 3 * C):
+        if self._own_qkv(x):
+            # the persistent GEMM (csrc/gemm_persist.hip) on the weights as stored: 3 456 columns are 13 tiles and one
+            # shifted back — no padded copies, and the bias is added in the kernel's epilogue
+            qkv = K.linear_fused(x, self.qkv.weight, self.qkv.bias, epilogue=K.GEMM_BIAS)
+            qkv = qkv.view(B, N, 3, self.num_heads, self.head_dim)
+        elif ZeroPaddedLinears.wanted(x, 3 * C):
             w, b = self._padded.get((self.qkv.weight, self.qkv.bias), lambda: (
                 _pad_rows(self.qkv.weight.detach(), _aligned(3 * C)),
                 _pad_rows(self.qkv.bias.detach(), _aligned(3 * C))))
@@ -117,6 +122,18 @@ class Attention(nn.Module):
         o = K.flash_attn_func(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], softmax_scale=self.scale,
                               causal=False)
         return o.reshape(B, N, C)
+
+    def _own_qkv(self, x) -> bool:
+        """qkv projection + bias on the hand-written persistent GEMM instead of hipBLASLt — opt-in (TV_VIT_OWN_QKV=1).
+        Stand-alone on 2 048 SigLIP frames it wins (9.5 ms against 10.2 ms for the library on the weights as stored and
+        9.7 ms on the copies zero-padded to 3 584 columns, same box); inside the 10 240-frame forward the library on the
+        padded copies is 0.5 % of the step ahead (1 225.6 against 1 219.9 frames/s, same box, round 5), so that stays
+        the default.  bf16 on the GPU, inference, K a multiple of 128, N of 8, enough rows for every compute unit to
+        walk a few tiles."""
+        w = self.qkv.weight
+        return (os.environ.get("TV_VIT_OWN_QKV", "0") == "1" and x.is_cuda and x.dtype == torch.bfloat16
+                and w.dtype == torch.bfloat16 and self.qkv.bias is not None and not torch.is_grad_enabled()
+                and w.shape[1] % 128 == 0 and w.shape[0] % 8 == 0 and x.numel() // x.shape[-1] >= 65536)
 
     def forward(self, x):
         return self.proj(self.heads(x))
@@ -150,9 +167,9 @@ class Mlp(nn.Module):
         return h, w2
 
     def _fused_fc1(self, x, w1) -> bool:
-        """fc1 + bias + exact GELU in ONE kernel (csrc/gemm.hip: the activation is applied to the accumulators, same
-        rounding points as GEMM-then-GELU): 15.3 ms against 16.2 ms for hipBLASLt + tv_gelu_fwd per 2 048 SigLIP
-        frames.  bf16 on the GPU, inference, K a multiple of 128, enough rows to fill the chip; TV_VIT_FUSED_FC1=0
+        """fc1 + bias + exact GELU in ONE kernel (csrc/gemm_persist.hip from 4 tiles per compute unit on, csrc/gemm.hip
+        below: the activation is applied to the accumulators, same rounding points as GEMM-then-GELU): 14.0 ms
+        (persistent) / 14.8 ms (per tile) against 16.7 ms for hipBLASLt + tv_gelu_fwd per 2 048 SigLIP frames.  bf16 on the GPU, inference, K a multiple of 128, enough rows to fill the chip; TV_VIT_FUSED_FC1=0
         switches it off."""
         return (self.exact_gelu and x.is_cuda and x.dtype == torch.bfloat16 and w1.dtype == torch.bfloat16
                 and not torch.is_grad_enabled() and w1.shape[1] % 128 == 0 and w1.shape[0] % 4 == 0
