@@ -247,6 +247,8 @@ int tv_ssd_state_correction(void* y, const void* dt, const void* A, const void* 
  * 4 / 5 = whole-head slice march (8 / 12 waves) x sequence segments,
  * 6 = head-per-wave march (csrc/ssd_head.hip; head_dim 32 / 64 / 80). */
 void tv_ssd_scan_set_impl(int impl);
+/* kernel family (same numbers) the most recent scan call of this process ran on; 0 before the first call */
+int tv_ssd_scan_last_impl(void);
 
 /* Single-token decode step, replaces selective_state_update (:528-539) with
  * the head-broadcast arguments the reference passes (A,D,dt_bias per head). */

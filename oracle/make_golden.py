@@ -451,3 +451,34 @@ def make_multi_projector_golden():
 
 if __name__ == "__main__" and os.environ.get("GOLDEN_ONLY") in (None, "multi_projector"):
     make_multi_projector_golden()
+
+
+@torch.no_grad()
+def make_realshape_golden():
+    """Two fixtures at the REAL head shapes of Nemotron-Nano-9B-v2 (mamba_head_dim 80, ssm_state_size 128, attention
+    head_dim 128; 8 Mamba heads, hidden 128, layers `M*-`): the toy goldens above run the generic scan kernel and the
+    small attention instance; these reach ssd_head_kernel<5,4,2>, the d-128 attention kernels and the decode kernels.
+      toy_realshape_g2: 2 B/C groups, the reference's prefill over 300 tokens.  (Its CPU prefill maps head h to group
+                        h % G — `repeat`, modeling_nano.py:781-782 — which the test mirrors with group_map = "tile".)
+      toy_realshape_g1: 1 group (both maps agree), the reference's prefill over 300 + 4 tokens: positions 300 .. 303 are
+                        what a prefill of 300 tokens followed by four decode steps must produce.  (The reference's own
+                        CPU decode branch cannot be run: `cache_params.ssm_states.device` on a list, :718.)"""
+    torch.manual_seed(0)
+    torch.set_num_threads(4)
+    nano = import_reference()
+    L, ndec = 300, 4
+    for tag, G in (("g2", 2), ("g1", 1)):
+        cfg = tiny_config(nano, vocab_size=96, hidden_size=128, intermediate_size=192, num_hidden_layers=3,
+                          hybrid_override_pattern="M*-", num_attention_heads=4, head_dim=128, num_key_value_heads=2,
+                          ssm_state_size=128, mamba_num_heads=8, mamba_n_groups=G, mamba_head_dim=80, mamba_chunk_size=64)
+        model = nano.NemotronHForCausalLM(cfg).eval()
+        randomize(model, 21 + G)
+        model.config._attn_implementation = "flash_attention_2"   # mask-free path, SDPA modules stay (SURVEY 8c)
+        emb = torch.randn(1, L + ndec, cfg.hidden_size)
+        n = L if G == 2 else L + ndec
+        out = model(inputs_embeds=emb[:, :n])
+        npz(f"toy_realshape_{tag}", embeds=emb[:, :n], logits=out.logits, meta=np.array([L, ndec, G]), **sd_arrays(model))
+
+
+if __name__ == "__main__" and os.environ.get("GOLDEN_ONLY") in (None, "realshape"):
+    make_realshape_golden()

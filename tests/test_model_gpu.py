@@ -579,6 +579,72 @@ def _toy_hybrid_d128(pattern="M-*M*-"):
     return cfg, model
 
 
+def _realshape_model(tag, group_map):
+    from timeviper_amd.model.llm.nano import NemotronHConfig, NemotronHForCausalLM
+    g = load_golden(f"toy_realshape_{tag}")
+    L, ndec, G = (int(v) for v in g["meta"])
+    cfg = NemotronHConfig(vocab_size=96, hidden_size=128, intermediate_size=192, num_hidden_layers=3,
+                          hybrid_override_pattern="M*-", num_attention_heads=4, head_dim=128, num_key_value_heads=2,
+                          ssm_state_size=128, mamba_num_heads=8, mamba_n_groups=G, mamba_head_dim=80, mamba_chunk_size=64,
+                          rescale_prenorm_residual=False)
+    model = NemotronHForCausalLM(cfg)
+    model.load_state_dict(golden_state_dict(g), strict=True)
+    model = model.to(DEV).bfloat16().eval()
+    for blk in model.backbone.layers:
+        if blk.block_type == "mamba":
+            blk.mixer.group_map = group_map
+    return cfg, model, g, L, ndec
+
+
+def test_realshape_prefill_bf16_vs_reference_golden():
+    """Model-level parity at Nano-9B's real head shapes against numbers the REFERENCE produced (tests/golden/
+    toy_realshape_g2.npz; the toy goldens above stop at the generic scan kernel and the small attention instance): the
+    bf16 prefill runs ssd_head_kernel<5,4,2> (asserted) and the d-128 causal attention.  group_map "tile" = the
+    reference CPU prefill's h % G (modeling_nano.py:781-782)."""
+    from timeviper_amd import kernels as K
+    cfg, model, g, L, _ = _realshape_model("g2", "tile")
+    emb = torch.from_numpy(g["embeds"]).to(DEV).bfloat16()
+    with torch.no_grad():
+        out = model(inputs_embeds=emb, logits_to_keep=0).logits
+    assert K.ssd_scan_last_impl() == 6, "the prefill did not run on the head-per-wave march"
+    assert out.shape == (1, L, 96)
+    assert relerr(out, g["logits"]) < 3e-2, relerr(out, g["logits"])
+
+
+def test_realshape_prefill_plus_graphed_fused_decode_vs_reference_golden(monkeypatch):
+    """... and the decode kernels at those shapes: a bf16 prefill of 300 tokens + four decode tokens through the fused
+    decode step (TV_DECODE_FUSED=1: tv_gemv_bf16_fwd prologues, tv_selective_state_update at P 80 / N 128,
+    tv_attn_decode_fwd at d 128) under GraphedDecodeStep reproduce positions 300 .. 303 of the reference's 304-token
+    forward (tests/golden/toy_realshape_g1.npz; one B/C group, where the reference's prefill and decode group maps agree)."""
+    from timeviper_amd import kernels as K
+    from timeviper_amd.model.llm.decode_graph import GraphedDecodeStep
+    from timeviper_amd.model.llm.nano import HybridMambaAttentionDynamicCache
+    monkeypatch.setenv("TV_DECODE_FUSED", "1")
+    cfg, model, g, L, ndec = _realshape_model("g1", "block")
+    emb = torch.from_numpy(g["embeds"]).to(DEV).bfloat16()
+    ref = torch.from_numpy(g["logits"])
+    host_pos = torch.ones(1, dtype=torch.long)
+    with torch.inference_mode():
+        cache = HybridMambaAttentionDynamicCache(cfg, 1, dtype=torch.bfloat16, device=DEV)
+        pre = model(inputs_embeds=emb[:, :L], past_key_values=cache, use_cache=True,
+                    cache_position=torch.zeros(1, dtype=torch.long), logits_to_keep=0).logits
+        assert K.ssd_scan_last_impl() == 6
+        assert relerr(pre, ref[:, :L]) < 3e-2, relerr(pre, ref[:, :L])
+        cache.begin_static_decode(ndec)
+        cur = {}
+        stepper = GraphedDecodeStep(
+            lambda ids: model(inputs_embeds=cur["e"], past_key_values=cache, use_cache=True, cache_position=host_pos).logits,
+            cache, 1, DEV)
+        buf = torch.empty(1, 1, cfg.hidden_size, dtype=torch.bfloat16, device=DEV)     # static input of the captured step
+        cur["e"] = buf
+        for i in range(ndec):
+            buf.copy_(emb[:, L + i:L + i + 1])
+            stepper.step(torch.zeros(1, 1, dtype=torch.long, device=DEV))
+            err = relerr(stepper.logits, ref[:, L + i])
+            assert err < 3e-2, (i, err)
+        assert stepper.graph is not None
+
+
 def test_kv_cache_grows_in_place_and_matches_concatenation():
     """`update` writes a token into spare capacity instead of re-concatenating the cache (modeling_nano.py:246-251):
     the views it hands out hold exactly what torch.cat would."""

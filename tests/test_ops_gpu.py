@@ -150,7 +150,7 @@ def run_scan(K, x, dt, A, Bm, Cm, D, dt_bias, **kw):
                                        return_final_states=True, return_total_decay=True, **kw)
 
 
-@pytest.mark.parametrize("impl", [1, 0, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("impl", [1, 0, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("dtype,B,L,H,P,G,N", [
     (torch.float32, 1, 1024, 32, 64, 1, 16),      # BASELINE config 1
     (torch.float32, 2, 77, 8, 8, 2, 16),
@@ -195,7 +195,7 @@ def test_ssd_scan_initial_state_and_sharding(K, dtype, H, P, G, N):
     close(f1, fin_ref, rt, at)
 
 
-@pytest.mark.parametrize("impl", [2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("impl", [2, 3, 4, 5, 6])
 @pytest.mark.parametrize("B,L,H,P,G", [(1, 1000, 16, 80, 8), (2, 449, 8, 64, 2), (1, 64, 4, 48, 1),
                                        (1, 2049, 8, 80, 4), (1, 130, 4, 128, 2), (1, 65, 6, 24, 3),
                                        (1, 5000, 8, 80, 8), (1, 4100, 4, 72, 2), (2, 2500, 4, 56, 1)])
@@ -222,7 +222,7 @@ def test_ssd_scan_march_kernels(K, impl, B, L, H, P, G):
         K.ssd_scan_set_impl(0)
 
 
-@pytest.mark.parametrize("impl", [6, 4, 7])
+@pytest.mark.parametrize("impl", [6, 4])
 @pytest.mark.parametrize("regime,a_lo,a_hi,dt_mean,dt_std", [
     ("no decay to speak of", 1e-4, 1e-3, -3.0, 0.3),       # 2^-0.01 a chunk: the frame never moves, the state grows with L
     ("slow", 0.05, 0.3, -1.0, 0.5),                       # a few bits a chunk: floating steps, a re-base every few chunks
@@ -936,8 +936,8 @@ def test_conv_xbc_with_cb_fragments(K, Bsz, L, H, P, G):
         A = -(torch.rand(H, generator=g) * 15 + 1).to(DEV)
         D, dtb = torch.ones(H, device=DEV), torch.full((H,), -2.0, device=DEV)
         kw = dict(chunk_size=64, D=D, dt_bias=dtb, dt_softplus=True, return_final_states=True)
-        for impl in (3, 4, 6, 7, 0):   # (6 / 7 = the head-per-wave marches, which consume the fragments unmasked; 0 = auto)
-            if impl in (6, 7) and P not in (32, 64, 80):
+        for impl in (3, 4, 6, 0):   # (6 = the head-per-wave march, which consumes the fragments unmasked; 0 = auto)
+            if impl == 6 and P not in (32, 64, 80):
                 continue
             K.ssd_scan_set_impl(impl)
             try:

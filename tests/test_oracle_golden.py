@@ -171,6 +171,22 @@ def test_toy_model_matches_reference(tag, pd, merge):
         assert [len(k) for k in col["kept"]] == [30, 20, 10]
 
 
+@pytest.mark.parametrize("tag", ["g2", "g1"])
+def test_realshape_model_matches_reference(tag):
+    """The oracle at Nano-9B's REAL head shapes (mamba_head_dim 80, ssm_state_size 128, attention head_dim 128; layers
+    `M*-`) against the reference's own forward: g2 = two B/C groups under the reference CPU prefill's h % G map, g1 = one
+    group, 304 tokens (the positions a prefill of 300 + four decode steps must reproduce)."""
+    g = load_golden(f"toy_realshape_{tag}")
+    L, ndec, G = (int(v) for v in g["meta"])
+    cfg = om.OracleConfig(hidden_size=128, num_hidden_layers=3, hybrid_override_pattern="M*-", mamba_num_heads=8,
+                          mamba_head_dim=80, ssm_state_size=128, n_groups=G, conv_kernel=4, chunk_size=64,
+                          num_attention_heads=4, num_key_value_heads=2, head_dim=128, intermediate_size=192,
+                          group_map="tile")
+    logits = om.causal_lm_ref(golden_state_dict(g), cfg, T(g["embeds"]), None)
+    assert logits.shape == g["logits"].shape == (1, L if G == 2 else L + ndec, 96)
+    close(logits, g["logits"], 5e-4, 1e-4)
+
+
 def test_fused_embedding_layout_matches_reference():
     g = load_golden("fused_embeddings")
     tok = int(g["image_token_id"])

@@ -39,6 +39,7 @@ SIGNATURES = {
     "tv_ssd_state_correction_workspace_bytes": (_z, [_i] * 3),
     "tv_ssd_state_correction": (_i, [_p] * 6 + [_i] * 6 + [_l] * 7 + [_i, _i, _f, _f, _i, _p, _z, _p]),
     "tv_ssd_scan_set_impl": (None, [_i]),
+    "tv_ssd_scan_last_impl": (_i, []),
     "tv_selective_state_update": (_i, [_p] * 9 + [_i] * 7 + [_p]),
     "tv_gemm_bf16_fwd": (_i, [_p, _p, _p, _p, _l, _i, _i, _l, _l, _l, _i, _i, _p]),
     "tv_gemm_set_persist": (None, [_i, _i]),

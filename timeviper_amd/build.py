@@ -61,59 +61,14 @@ def source_id() -> str:
     return _hash(_sources() + _headers(), " ".join(FLAGS))
 
 
-# Kernels whose accumulation / vector register split hipcc cannot express from source.  A 512-thread work-group has 256
-# registers a lane; as soon as a kernel uses accumulation registers the backend splits them 128 / 128 unless the function
-# carries the LLVM attribute "amdgpu-agpr-alloc" (SIRegisterInfo::getMaxNumVectorRegs), for which clang has no spelling.
-# Such sources are compiled in the steps hipcc itself runs — device IR, code object, bundle, host object — with the
-# attribute added to the kernel's attribute group in between.  {source: {kernel name fragment: attribute text}}
-IR_ATTRS = {"ssd_pair.hip": {"ssd_pair_kernel": '"amdgpu-agpr-alloc"="144"'}}
-LLVM_BIN = Path(os.environ.get("TV_LLVM_BIN", "/opt/rocm/lib/llvm/bin"))
-
-
-def _run(cmd):
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError(f"{' '.join(map(str, cmd[:3]))} ... failed:\n{r.stdout}\n{r.stderr}")
-    return r
-
-
-def _compile_ir_patched(src: Path, obj: Path, flags) -> None:
-    import re
-    work = OBJ / (src.name + ".ir")
-    work.mkdir(parents=True, exist_ok=True)
-    ll, llp, dev_o, dev_out, fb = (work / n for n in ("dev.ll", "dev_patched.ll", "dev.o", "dev.out", "dev.hipfb"))
-    dev_flags = [f for f in flags if f != "-fPIC"]
-    _run([HIPCC, *dev_flags, "-x", "hip", "--cuda-device-only", "-emit-llvm", "-S", str(src), "-o", str(ll)])
-    text = ll.read_text()
-    for frag, attr in IR_ATTRS[src.name].items():
-        m = re.search(r"define [^\n]*@[A-Za-z0-9_]*%s[A-Za-z0-9_]*\([^\n]*\)[^\n{]*#(\d+)" % re.escape(frag), text)
-        if not m:
-            raise RuntimeError(f"{src.name}: kernel `{frag}` not found in the device IR")
-        text, n = re.subn(r"(attributes #%s = \{)" % m.group(1), r"\1 " + attr, text, count=1)
-        if n != 1:
-            raise RuntimeError(f"{src.name}: attribute group #{m.group(1)} not found")
-    llp.write_text(text)
-    _run([str(LLVM_BIN / "clang"), "-x", "ir", str(llp), "-target", "amdgcn-amd-amdhsa", f"-mcpu={ARCH}", "-O3", "-c", "-o", str(dev_o)])
-    _run([str(LLVM_BIN / "lld"), "-flavor", "gnu", "-m", "elf64_amdgpu", "--no-undefined", "-shared", "-o", str(dev_out), str(dev_o)])
-    _run([str(LLVM_BIN / "clang-offload-bundler"), "-type=o", "-bundle-align=4096",
-          f"-targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--{ARCH}", "-input=/dev/null", f"-input={dev_out}",
-          f"-output={fb}"])
-    _run([HIPCC, *flags, "-x", "hip", "--cuda-host-only", "-Xclang", "-fcuda-include-gpubinary", "-Xclang", str(fb),
-          "-c", str(src), "-o", str(obj)])
-
-
 def _compile(src: Path, force: bool, build_id: str) -> Path:
     obj = OBJ / (src.name + ".o")
     tag = OBJ / (src.name + ".hash")
     flags = list(FLAGS)
     if src.name == "capi.cpp":                    # the one translation unit that carries the id
         flags.append(f'-DTV_BUILD_ID="{build_id}"')
-    want = _hash([src] + _headers(), " ".join(flags) + repr(IR_ATTRS.get(src.name, "")))
+    want = _hash([src] + _headers(), " ".join(flags))
     if not force and obj.exists() and tag.exists() and tag.read_text() == want:
-        return obj
-    if src.name in IR_ATTRS:
-        _compile_ir_patched(src, obj, flags)
-        tag.write_text(want)
         return obj
     cmd = [HIPCC, *flags, "-x", "hip", "-c", str(src), "-o", str(obj)]
     r = subprocess.run(cmd, capture_output=True, text=True)

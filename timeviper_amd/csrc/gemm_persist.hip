@@ -20,7 +20,9 @@
 //     is never too lenient.  Measured: letting them allow for exactly the stores in front of them changes nothing, and
 //     neither does moving all stores to waves that never wait (wave group 0 copies, group 1 stores, hand-over through
 //     LDS: built, correct, slower): what a tile's 128 KB of stores cost (~2.8 us, 23 B/clk and CU) they cost in the CU's
-//     memory pipeline, in front of the copies, whoever issues them and whoever waits;
+//     memory pipeline, in front of the copies, whoever issues them and whoever waits.  Store shapes measured on qkv
+//     (9.95 ms): 16 rows x 64 B per instruction 10.05, whole 128-byte lines (values misplaced, timing only) 9.70,
+//     `nt` 12.5, `sc0 sc1` 11.1 ms;
 //   * bias: 1 KiB per tile by LDS-DMA into one of two slots (every wave issues the same copy: the counts stay uniform),
 //     read back in the epilogue;
 //   * tiles: ids that share an XCD (blockIdx % 8, observed dispatch order; speed only) own one contiguous eighth of the
@@ -212,13 +214,6 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(PArgs pa) {
         }
         const int row_t = 128 * MH + 16 * mp + lane_r;
         unsigned char* cp = (unsigned char*)(Cb + (int64_t)(128 * MH + 16 * mp) * ldc + (128 * NH + 16 * n)) + lane_coff;
-        if (pa.dbg & 4) {
-          // dev: the same bytes as full 128-byte lines (8 rows x 128 B per instruction; the values land in the wrong
-          // places): what would whole-line stores cost?
-          const int qi = 2 * n + (mp >> 1);
-          const int rr = 128 * MH + 64 * wr + 32 * (wc & 1) + 8 * qi + (lx >> 3), cc = 128 * NH + 64 * (wc >> 1) + 8 * (lx & 7);
-          *(u32x4e*)(Cb + (int64_t)rr * ldc + cc) = o;
-        } else
         if (pa.dbg & 2) asm volatile("" ::"v"(o));        // dev: the epilogue's arithmetic without its stores
         else if (!edge || (row_t >= skr && col_t >= skc)) *(u32x4e*)cp = o;
       }

@@ -57,29 +57,21 @@ int tv_ssd_head_launch(const void* x, const void* dt, const void* A, const void*
                        void* workspace, size_t workspace_bytes, const void* cb_pre, hipStream_t st);
 
 // ssd_pair.hip
-bool tv_ssd_pair_supported(int seqlen, int nheads, int headdim, int ngroups, int dstate, int dtype,
-                           int64_t xsl, int64_t bsl, int64_t bsg, int64_t csl, int64_t csg, int64_t ysl,
-                           const void* x, const void* Bm, const void* Cm, const void* y);
-size_t tv_ssd_pair_workspace_bytes(int batch, int seqlen, int nheads, int ngroups);
-int tv_ssd_pair_launch(const void* x, const void* dt, const void* A, const void* Bm, const void* Cm,
-                       const void* D, const void* dt_bias, const void* init_state, void* y,
-                       void* final_state, void* total_decay, int batch, int seqlen, int nheads,
-                       int ngroups, int64_t xsb, int64_t xsl, int64_t dsb, int64_t dsl, int64_t bsb,
-                       int64_t bsl, int64_t bsg, int64_t csb, int64_t csl, int64_t csg, int64_t ysb,
-                       int64_t ysl, int dt_softplus, float dt_min, float dt_max, int group_map,
-                       void* workspace, size_t workspace_bytes, const void* cb_pre, hipStream_t st);
-
 // 0 auto, 1 generic recurrence, 2 chunk march (ssd_march.hip), 3 slice march, two work-groups per
 // head (ssd_slice.hip), 4 slice march, whole-head work-groups x concurrent sequence segments +
 // carried-in state correction (ssd_slice.hip + ssd_correct.hip), 8 waves with two column tiles per
 // slice-wave, 5 the same with 12 waves and one column tile per slice-wave, 6 head-per-wave march (ssd_head.hip:
-// a wave owns a head, a work-group the heads of one B/C group, up to 16 sequence segments + correction), 7 the same march
-// with a head's columns split over two waves of <= 256 registers, two waves per SIMD (ssd_pair.hip; head_dim 80)
+// a wave owns a head, a work-group the heads of one B/C group, up to 16 sequence segments + correction).  (7 was round 4's
+// two-waves-per-SIMD variant of it, ssd_pair.hip: 3.2 ms against 2.5 ms, removed in round 5; the number now means 6.)
 // process-wide override for tests / dev tools; atomic so that concurrent callers never race on it
 static std::atomic<int> g_ssd_impl{0};
 static const int kAutoImpl = 6;   // head-per-wave march; falls back to 4, 3, the chunk march, the generic kernel
 
 extern "C" void tv_ssd_scan_set_impl(int impl) { g_ssd_impl.store(impl, std::memory_order_relaxed); }
+// which kernel family the most recent tv_ssd_scan_fwd / _cb_fwd of this process ran on (the numbers above; tests assert
+// that a shape reached the kernel they mean to check)
+static std::atomic<int> g_ssd_last{0};
+extern "C" int tv_ssd_scan_last_impl(void) { return g_ssd_last.load(std::memory_order_relaxed); }
 
 extern "C" size_t tv_ssd_scan_workspace_bytes(int batch, int seqlen, int nheads, int headdim,
                                               int ngroups, int dstate, int dtype) {
@@ -88,10 +80,6 @@ extern "C" size_t tv_ssd_scan_workspace_bytes(int batch, int seqlen, int nheads,
   const size_t wide = tv_ssd_slice_workspace_bytes(batch, seqlen, nheads, headdim, ngroups, dstate, 1);
   const size_t head = tv_ssd_head_workspace_bytes(batch, seqlen, nheads, headdim, ngroups);
   size_t m = narrow > wide ? narrow : wide;             // any variant may be selected (tv_ssd_scan_set_impl)
-  if (headdim == 80 && nheads % ngroups == 0) {
-    const size_t pair = tv_ssd_pair_workspace_bytes(batch, seqlen, nheads, ngroups);
-    m = m > pair ? m : pair;
-  }
   return ((m > head ? m : head) + 255) / 256 * 256;
 }
 
@@ -131,18 +119,11 @@ static int scan_impl(const void* x, const void* dt, const void* A, const void* B
   if (forced >= 2 && !march)
     TV_UNSUPPORTED("ssd_scan: MFMA march kernel forced but shape/dtype unsupported");
   const int impl = forced ? forced : kAutoImpl;
-  if (march && impl == 7 && workspace && (((uintptr_t)dt) & 1) == 0 &&
-      tv_ssd_pair_supported(seqlen, nheads, headdim, ngroups, dstate, dtype, x_stride_l, b_stride_l, b_stride_g, c_stride_l,
-                            c_stride_g, y_stride_l, x, Bm, Cm, y)) {
-    return tv_ssd_pair_launch(x, dt, A, Bm, Cm, D, dt_bias, init_state, y, final_state, total_decay, batch, seqlen,
-                              nheads, ngroups, x_stride_b, x_stride_l, dt_stride_b, dt_stride_l, b_stride_b,
-                              b_stride_l, b_stride_g, c_stride_b, c_stride_l, c_stride_g, y_stride_b, y_stride_l,
-                              dt_softplus, dt_min, dt_max, group_map, workspace, workspace_bytes, cb, st);
-  }
   const bool head_ok = march && (impl == 6 || impl == 7) && workspace && (((uintptr_t)dt) & 1) == 0 &&
       tv_ssd_head_supported(seqlen, nheads, headdim, ngroups, dstate, dtype, x_stride_l, b_stride_l, b_stride_g,
                             c_stride_l, c_stride_g, y_stride_l, x, Bm, Cm, y);
   if (head_ok) {
+    g_ssd_last.store(6, std::memory_order_relaxed);
     // the head-per-wave march takes every chunk itself (floating, reset and standard steps in the one kernel)
     return tv_ssd_head_launch(x, dt, A, Bm, Cm, D, dt_bias, init_state, y, final_state, total_decay, batch, seqlen,
                               nheads, headdim, ngroups, x_stride_b, x_stride_l, dt_stride_b, dt_stride_l, b_stride_b,
@@ -155,6 +136,7 @@ static int scan_impl(const void* x, const void* dt, const void* A, const void* B
     if (march && impl >= 3 && workspace &&
         tv_ssd_slice_supported(seqlen, nheads, headdim, ngroups, dstate, dtype, x_stride_l, b_stride_l,
                                b_stride_g, c_stride_l, c_stride_g, y_stride_l, x, Bm, Cm, y, wide)) {
+      g_ssd_last.store(wide == 2 ? 5 : wide == 1 ? 4 : 3, std::memory_order_relaxed);
       return tv_ssd_slice_launch(x, dt, A, Bm, Cm, D, dt_bias, init_state, y, final_state,
                                  total_decay, batch, seqlen, nheads, headdim, ngroups, dstate,
                                  x_stride_b, x_stride_l, dt_stride_b, dt_stride_l, b_stride_b,
@@ -164,6 +146,7 @@ static int scan_impl(const void* x, const void* dt, const void* A, const void* B
     }
   }
   if (march) {
+    g_ssd_last.store(2, std::memory_order_relaxed);
     return tv_ssd_march_launch(x, dt, A, Bm, Cm, D, dt_bias, init_state, y, final_state,
                                total_decay, batch, seqlen, nheads, headdim, ngroups, dstate,
                                x_stride_b, x_stride_l, dt_stride_b, dt_stride_l, b_stride_b,
@@ -171,6 +154,7 @@ static int scan_impl(const void* x, const void* dt, const void* A, const void* B
                                dt_softplus, dt_min, dt_max, group_map, workspace, workspace_bytes,
                                st);
   }
+  g_ssd_last.store(1, std::memory_order_relaxed);
   return tv_ssd_generic_launch(x, dt, A, Bm, Cm, D, dt_bias, init_state, y, final_state,
                                total_decay, batch, seqlen, nheads, headdim, ngroups, dstate,
                                x_stride_b, x_stride_l, dt_stride_b, dt_stride_l, b_stride_b,

@@ -426,9 +426,13 @@ def selective_state_update(state, x, dt, A, B, C, D=None, z=None, dt_bias=None,
 def ssd_scan_set_impl(impl: int) -> None:
     """0 auto (= 6 where it applies, else 4, 3, 2, 1), 1 generic fp32-recurrence kernel, 2 MFMA chunk-march kernel,
     3 MFMA slice march with two work-groups per head, 4 / 5 whole-head slice march (8 / 12 waves) x sequence
-    segments, 6 head-per-wave march (ssd_head.hip), 7 the same with a head's columns split over two waves, two waves per SIMD
-    (ssd_pair.hip, head_dim 80; elsewhere 6).  Process-global (dev tools and tests)."""
+    segments, 6 head-per-wave march (ssd_head.hip).  Process-global (dev tools and tests)."""
     _capi.lib().tv_ssd_scan_set_impl(int(impl))
+
+
+def ssd_scan_last_impl() -> int:
+    """Kernel family (the numbers of `ssd_scan_set_impl`) the most recent scan call of this process ran on."""
+    return int(_capi.lib().tv_ssd_scan_last_impl())
 
 
 # ------------------------------------------------------------------ attention
