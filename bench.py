@@ -465,8 +465,8 @@ def config_decode(args):
         "ms_per_step": round(dt_s / gsteps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"Nemotron-Nano-9B-v2 hybrid decode step (27 Mamba2 / 25 MLP / 4 attention layers), cache of "
-                               f"{L} tokens (2 048 frames, no token drop), greedy, one hipGraph launch per token, GEMVs on "
-                               f"hipBLASLt",
+                               f"{L} tokens (2 048 frames, no token drop), greedy, one hipGraph launch per token, matrix-vector "
+                               f"products on tv_gemv_bf16_fwd (norm / activation prologues)",
                    "cache_tokens": L, "weights": "random init, seed 0",
                    "eager_tokens_per_s": round(steps / eager_s, 2), "eager_ms_per_step": round(eager_s / steps * 1e3, 3),
                    "weight_bytes_per_token": weights,

@@ -22,6 +22,60 @@ needs2 = pytest.mark.skipif(NGPU < 2, reason="needs two GPUs: RCCL refuses two r
 UNI3 = "uni_2_0.75-uni_3_0.5-uni_6_0.25"
 
 
+class CollectiveTimer:
+    """Wall time of every torch.distributed collective the runner issues (rank 0 prints a table when the test runs: the
+    first numbers RCCL over xGMI gives this code, to be held against profiles/r05_sp_prediction.json).  Blocking calls are
+    bracketed by device synchronisations; an asynchronous one is timed from its issue to the return of `wait()`."""
+    NAMES = ("all_gather_into_tensor", "all_gather", "broadcast", "all_to_all_single", "all_reduce", "barrier")
+
+    def __init__(self):
+        self.rows, self.saved = [], {}
+
+    def __enter__(self):
+        import time
+        for name in self.NAMES:
+            fn = getattr(dist, name, None)
+            if fn is None:
+                continue
+            self.saved[name] = fn
+
+            def wrapped(*a, _fn=fn, _name=name, **kw):
+                nbytes = sum(t.numel() * t.element_size() for t in a if isinstance(t, torch.Tensor))
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                work = _fn(*a, **kw)
+                if kw.get("async_op") and work is not None:
+                    timer, wait = self, work.wait
+
+                    def timed_wait(*wa, **wk):
+                        r = wait(*wa, **wk)
+                        torch.cuda.synchronize()
+                        timer.rows.append((_name + " (async)", nbytes, (time.perf_counter() - t0) * 1e3))
+                        return r
+                    work.wait = timed_wait
+                    return work
+                torch.cuda.synchronize()
+                self.rows.append((_name, nbytes, (time.perf_counter() - t0) * 1e3))
+                return work
+            setattr(dist, name, wrapped)
+        return self
+
+    def __exit__(self, *exc):
+        for name, fn in self.saved.items():
+            setattr(dist, name, fn)
+
+    def report(self, rank, world):
+        if rank != 0 or not self.rows:
+            return
+        agg = {}
+        for name, nbytes, ms in self.rows:
+            n, b, t, mx = agg.get(name, (0, 0, 0.0, 0.0))
+            agg[name] = (n + 1, b + nbytes, t + ms, max(mx, ms))
+        print(f"[rccl timing, world {world}] collective: calls, MB moved through the call's tensors, total ms, max ms")
+        for name, (n, b, t, mx) in sorted(agg.items()):
+            print(f"[rccl timing]   {name:32s} {n:5d} {b / 1e6:10.2f} {t:9.3f} {mx:8.3f}", flush=True)
+
+
 def worker(rank, world, port, merge, T, q, pd, family, rebalance=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     torch.cuda.set_device(rank)
@@ -49,7 +103,10 @@ def worker(rank, world, port, merge, T, q, pd, family, rebalance=None):
         with torch.no_grad():
             runner = SequenceParallelTimeViper(vlm, rank, world, rebalance=rebalance)
             lo, hi = runner.frame_range(T)
-            logits = runner.forward(ids, pix[lo:hi], T)
+            runner.forward(ids, pix[lo:hi], T)          # warm-up (communicator set-up, lazy initialisations)
+            with CollectiveTimer() as timer:
+                logits = runner.forward(ids, pix[lo:hi], T)
+            timer.report(rank, world)
             trace = [t.cpu().numpy() for t in runner.trace]
             if rank == 0:
                 ref = vlm(input_ids=ids, pixel_values_videos=pix).logits

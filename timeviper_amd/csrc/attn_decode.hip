@@ -363,8 +363,9 @@ extern "C" int tv_attn_decode_fwd(const void* q, const void* k, const void* v, v
   const int gq = nheads_q / nheads_kv, hblocks = (gq + 15) / 16;
   const int nsplit = pick_splits(batch, nheads_kv, hblocks, seqlen_k);
   // V rows are addressed with 32-bit byte offsets from the first key of a split
-  if (((int64_t)seqlen_k / nsplit + 2 * AD_STEP) * v_stride_l * 2 >= (1ll << 31))
-    TV_UNSUPPORTED("attn_decode: v row stride too large for a split of %d keys", seqlen_k / nsplit);
+  if (((int64_t)seqlen_k / nsplit + 2 * AD_STEP) * v_stride_l * 2 >= (1ll << 31) ||
+      ((int64_t)seqlen_k / nsplit + 2 * AD_STEP) * k_stride_l * 2 >= (1ll << 31))
+    TV_UNSUPPORTED("attn_decode: k / v row stride too large for a split of %d keys", seqlen_k / nsplit);
   const size_t need = (size_t)batch * nheads_q * nsplit * (AD_D + 2) * sizeof(float);
   TV_CHECK_ARG(workspace && workspace_bytes >= need && ((uintptr_t)workspace & 15) == 0,
                "attn_decode: workspace of %zu bytes (16-byte aligned) needed, got %zu", need, workspace_bytes);

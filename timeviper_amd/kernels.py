@@ -286,6 +286,21 @@ def linear_fused(x, weight, bias=None, epilogue: int = GEMM_BIAS, out=None):
     return out
 
 
+def param_key(params):
+    """Cache key for tensors derived from parameters (stacked / padded / fp32 copies): storage, version counter, dtype
+    and device of each.  Tensors created under `torch.inference_mode()` track no version ("Inference tensors do not
+    track version counter"): they count as version 0 — such a model must not be written in place after its first forward.
+    Note that writes through `.data` never bump the counter either: reload weights with `load_state_dict` / `copy_`."""
+    key = []
+    for p in params:
+        try:
+            v = p._version
+        except RuntimeError:
+            v = 0
+        key.append((p.data_ptr(), v, p.dtype, p.device))
+    return tuple(key)
+
+
 def gemm_set_persist(mode: int = -1, grid: int = 0) -> None:
     """Which of the two GEMM kernels `linear_fused` runs on: -1 automatic (the persistent kernel from 4 tiles per
     compute unit on), 0 the per-tile kernel only, 1 the persistent kernel wherever the shape allows; `grid`:
@@ -564,6 +579,11 @@ def gemv_fused(x, weight, bias=None, prologue=GEMV_NONE, delta=None, sum_out=Non
     M, N = x2.shape[0], weight.shape[0]
     if weight.shape[1] != K:
         raise TimeViperHipError(f"gemv_fused: weight {tuple(weight.shape)} against rows of {K}")
+    # the C ABI carries no weight dtype: anything but dense bf16 rows would be re-interpreted silently
+    if (x.dtype != torch.bfloat16 or weight.dtype != torch.bfloat16 or weight.stride(1) != 1 or weight.stride(0) % 8
+            or K % 8):
+        raise TimeViperHipError("gemv_fused: bf16 x and weight with dense rows of a multiple of 8 elements only "
+                                f"(x {x.dtype}, weight {weight.dtype}, strides {tuple(weight.stride())}, K {K})")
     y = torch.empty(x.shape[:-1] + (N,), dtype=x.dtype, device=x.device)
     d2 = None if delta is None else _rows2d(delta)
     g2 = None if gate is None else _rows2d(gate)

@@ -29,7 +29,8 @@ class GraphedDecodeStep:
     step_fn(ids) runs the language model on ONE token per sequence — ids is a (B, 1) int64 tensor that lives at a fixed
     address — against `cache` (already in static-decode mode) and returns the logits of that token, (B, V) or
     (B, 1, V).  The first `warmup` calls run eagerly (lazy initialisations: kernel attributes, cached constants,
-    library workspaces), the next one is captured, every later one replays."""
+    library workspaces), the next one is captured, every later one replays; if the capture raises, the stepper restores the
+    cache's host bookkeeping and keeps running the eager step (`capture_error` holds the reason)."""
 
     def __init__(self, step_fn: Callable[[torch.Tensor], torch.Tensor], cache, batch_size: int, device,
                  warmup: int = 2):
@@ -40,6 +41,7 @@ class GraphedDecodeStep:
         self.next_ids = None
         self.logits = None
         self.graph = None
+        self.capture_error = None     # set when the capture failed: the stepper then runs every step eagerly
         self.calls = 0
 
     def _run(self):
@@ -58,15 +60,29 @@ class GraphedDecodeStep:
         if self.graph is not None:
             self.graph.replay()
             self.cache.advance_static_host()
-        elif self.calls <= self.warmup:
+        elif self.calls <= self.warmup or self.capture_error is not None:
             self.logits, self.next_ids = self._run()
         else:
-            side = torch.cuda.Stream(device=self.ids.device)
-            side.wait_stream(torch.cuda.current_stream())
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=side):
+            # host bookkeeping the capture is about to advance (no kernel runs during it): restored if it fails
+            lens = {i: self.cache._kv_len[i] for i in self.cache.attention_layers}
+            try:
+                side = torch.cuda.Stream(device=self.ids.device)
+                side.wait_stream(torch.cuda.current_stream())
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side):
+                    self.logits, self.next_ids = self._run()
+                torch.cuda.current_stream().wait_stream(side)
+            except Exception as e:  # a non-capturable op, a lazy library initialisation the warm-up did not reach, ...
+                # the eager step works where the capture does not: fall back to it for the rest of the generation
+                # (the device-side position / key counts were not touched: nothing of the capture executed)
+                self.capture_error = e
+                for i, n in lens.items():
+                    kb, vb = self.cache._kv_buf[i]
+                    self.cache._kv_len[i] = n
+                    self.cache.key_cache[i], self.cache.value_cache[i] = kb[:, :n], vb[:, :n]
+                torch.cuda.synchronize()
                 self.logits, self.next_ids = self._run()
-            torch.cuda.current_stream().wait_stream(side)
+                return self.next_ids
             # the capture ran the host bookkeeping of one step (cache lengths) and no kernel: this replay is that step
             self.graph = graph
             graph.replay()

@@ -357,7 +357,7 @@ class NemotronHMamba2Mixer(nn.Module):
         Derived once per parameter version, not once per call: in a bf16 model the per-call form costs five
         small launches a layer (float, exp, neg, two casts), 27 layers a forward, every decode step."""
         ps = (self.A_log, self.D, self.dt_bias)
-        key = tuple((p.data_ptr(), p._version, p.dtype, p.device) for p in ps)
+        key = K.param_key(ps)
         if key != getattr(self, "_ckey", None):
             with torch.no_grad():
                 self._cval = (-torch.exp(self.A_log.detach().float()), self.D.detach().float().contiguous(),
@@ -530,7 +530,7 @@ class NemotronHAttention(nn.Module):
         """[q; k; v] as one (N, K) matrix for the decode token's single product (a copy: 64 MB per layer at 9B dims), rebuilt
         when a projection's storage or version changes."""
         ws = (self.q_proj.weight, self.k_proj.weight, self.v_proj.weight)
-        key = tuple((w.data_ptr(), w._version, w.dtype, w.device) for w in ws)
+        key = K.param_key(ws)
         if getattr(self, "_qkv_key", None) != key:
             self._qkv_cat = torch.cat([w.detach() for w in ws], dim=0).contiguous()
             self._qkv_key = key
@@ -702,6 +702,25 @@ class NemotronHModel(PdropMixin, nn.Module):
     def set_input_embeddings(self, new_embeddings):
         self.embeddings = new_embeddings
 
+    def _all_matrices_bf16(self) -> bool:
+        """Every 2-D parameter of every block is dense bf16 — what the fused decode step's matrix-vector kernel takes (its
+        C ABI carries no weight dtype).  Decided once per parameter set (`_apply` — .to() / .bfloat16() — and
+        load_state_dict replace or rewrite the parameters: both reset it)."""
+        ok = getattr(self, "_bf16_ok", None)
+        if ok is None:
+            ok = all(p.dtype == torch.bfloat16 and p.stride(-1) == 1
+                     for blk in self.layers for p in blk.mixer.parameters() if p.dim() == 2)
+            self._bf16_ok = ok
+        return ok
+
+    def _apply(self, fn, *a, **kw):
+        self._bf16_ok = None
+        return super()._apply(fn, *a, **kw)
+
+    def load_state_dict(self, *a, **kw):
+        self._bf16_ok = None
+        return super().load_state_dict(*a, **kw)
+
     def _rank_attention(self, rank_layer):
         """the self-attention module whose q/k projections rank the vision tokens (:1822-1830)"""
         assert self.layers[rank_layer].block_type == "attention"
@@ -732,7 +751,7 @@ class NemotronHModel(PdropMixin, nn.Module):
         fused_step = (_fused_decode(hidden) and past_key_values is not None and cache_position is not None
                       and int(cache_position[0]) > 0 and not output_hidden_states and not self.check_nan
                       and hidden.shape[-1] % 8 == 0 and hidden.shape[-1] <= 8192
-                      and all(p.dtype == torch.bfloat16 for p in self.layers[0].mixer.parameters() if p.dim() == 2))
+                      and self._all_matrices_bf16())
         # attention blocks join when their projections carry no bias (the stacked q / k / v product takes none)
         attn_fused = fused_step and not self.config.attention_bias
         for layer_idx, block in enumerate(self.layers):

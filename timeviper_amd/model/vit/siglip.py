@@ -83,7 +83,7 @@ class ZeroPaddedLinears:
         return x.is_cuda and not torch.is_grad_enabled() and n >= 1024 and n % GEMM_ALIGN != 0
 
     def get(self, params, build):
-        key = tuple((p.data_ptr(), p._version, p.dtype) for p in params)
+        key = K.param_key(params)
         if key != self._key:
             self._key, self._val = key, build()
         return self._val
@@ -277,7 +277,7 @@ class VisionTransformer(nn.Module):
         `Block.forward_stream` would make) — built once per parameter version instead of two adds and two
         casts per block and call."""
         ps = [p for b in blocks for p in (b.attn.proj.bias, b.mlp.fc2.bias)]
-        key = tuple((p.data_ptr(), p._version, p.dtype, p.device) for p in ps)
+        key = K.param_key(ps)
         if key != getattr(self, "_pend_key", None):
             rows, pend = [], None
             with torch.no_grad():
