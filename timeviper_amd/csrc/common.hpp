@@ -39,6 +39,22 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// The same sum without LDS: an inclusive scan of DPP row shifts / row broadcasts (6 vector instructions, no
+// ds_bpermute round trips — __shfl_xor costs one per step on gfx9, ~100 cycles each behind an lgkmcnt wait) and one
+// v_readlane of lane 63.  Wave-uniform result; the additions associate differently from wave_sum's butterfly.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float tv_dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROWMASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v = tv_dpp_add<0x111, 0xf>(v);   // row_shr:1
+  v = tv_dpp_add<0x112, 0xf>(v);   // row_shr:2
+  v = tv_dpp_add<0x114, 0xf>(v);   // row_shr:4
+  v = tv_dpp_add<0x118, 0xf>(v);   // row_shr:8
+  v = tv_dpp_add<0x142, 0xa>(v);   // row_bcast:15 -> rows 1, 3
+  v = tv_dpp_add<0x143, 0xc>(v);   // row_bcast:31 -> rows 2, 3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -4,8 +4,13 @@
 // Reference semantics: NemotronHRMSNorm.forward modeling_nano.py:897-903,
 // NemotronHBlock residual add :966, MambaRMSNormGated :371-380 (mamba_ssm
 // rmsnorm_fn with norm_before_gate=False).
+#include <stdlib.h>
 #include "common.hpp"
 
+// -DTV_NORM_SHFL (dev, A/B): the row sums on the __shfl_xor butterfly (one ds_bpermute round trip per step) instead of DPP
+#ifdef TV_NORM_SHFL
+#define wave_sum_dpp wave_sum
+#endif
 namespace {
 
 constexpr int NORM_THREADS = 256;
@@ -72,7 +77,7 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_kernel(
       for (int i = 0; i < V; ++i) ssq = fmaf(vals[k][i], vals[k][i], ssq);
     }
   }
-  ssq = wave_sum(ssq);
+  ssq = wave_sum_dpp(ssq);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ssq;
   __syncthreads();
   float tot = 0.f;
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(NORM_THREADS) void layernorm_kernel(
   }
   // two passes over the registers (mean, then sum of squared deviations), like torch's
   // LayerNorm: E[x^2] - mean^2 loses the variance of rows with |mean| >> std to cancellation
-  s1 = wave_sum(s1);
+  s1 = wave_sum_dpp(s1);
   if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = s1;
   __syncthreads();
   float t1 = 0.f;
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(NORM_THREADS) void layernorm_kernel(
       for (int i = 0; i < V; ++i) { const float d = vals[k][i] - mean; s2 = fmaf(d, d, s2); }
     }
   }
-  s2 = wave_sum(s2);
+  s2 = wave_sum_dpp(s2);
   if ((threadIdx.x & 63) == 0) red[1][threadIdx.x >> 6] = s2;
   __syncthreads();
   float t2 = 0.f;
@@ -225,7 +230,7 @@ __global__ __launch_bounds__(NORM_THREADS) void layernorm_wave_kernel(
       for (int i = 0; i < V; ++i) s1 += vals[k][i];
     }
   }
-  s1 = wave_sum(s1);
+  s1 = wave_sum_dpp(s1);
   const float mean = s1 / (float)D;
   // second register pass: sum of squared deviations (no E[x^2] - mean^2 cancellation)
 #pragma unroll
@@ -236,7 +241,7 @@ __global__ __launch_bounds__(NORM_THREADS) void layernorm_wave_kernel(
       for (int i = 0; i < V; ++i) { const float d = vals[k][i] - mean; s2 = fmaf(d, d, s2); }
     }
   }
-  s2 = wave_sum(s2);
+  s2 = wave_sum_dpp(s2);
   const float var = s2 / (float)D;
   const float rstd = rsqrtf(var + eps);
 #pragma unroll
@@ -252,6 +257,116 @@ __global__ __launch_bounds__(NORM_THREADS) void layernorm_wave_kernel(
         o[i] = from_f32<T>((vals[k][i] - mean) * rstd * to_f32(wv[i]) + to_f32(bv[i]));
       *(vec_t*)(y + row * ys + (int64_t)iv * V) = o;
     }
+  }
+}
+
+// The same rows, RPW consecutive ones per wave: weight, bias and the fp32 row bias are loaded ONCE per wave and stay in
+// registers, and row r + 1 is requested before row r is reduced.  Per row the kernel above issues 5 loads for every
+// 16 bytes of x it reads (x, 2 of the row bias, w, b: 11.5 KB through the CU's L1 for 2.3 KB from HBM); at the ViT's
+// 1.5 M rows x 1 152 that load path, not HBM, set the pace of the row-bias form (4.9 against 5.3 TB/s for the plain one).
+// NV = 16-byte vectors per lane (ceil(D / V / 64)), a template parameter so that the register count follows the row.
+template <typename T, int NV, int RPW, bool DELTA>
+__global__ __launch_bounds__(NORM_THREADS, DELTA ? 3 : 4) void layernorm_rows_kernel(
+    const T* __restrict__ x, const T* __restrict__ delta, const T* __restrict__ w,
+    const T* __restrict__ bias, const float* __restrict__ row_bias, T* __restrict__ sum_out,
+    T* __restrict__ y, int64_t rows, int D, int64_t xs, int64_t ds, int64_t ss, int64_t ys, float eps) {
+  constexpr int V = Vec16<T>::N;
+  typedef typename Vec16<T>::type vec_t;
+  const int64_t row0 = ((int64_t)blockIdx.x * (NORM_THREADS / 64) + (threadIdx.x >> 6)) * RPW;
+  if (row0 >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const int nv = D / V;
+  const int nrow = (int)(rows - row0 < RPW ? rows - row0 : RPW);
+  vec_t wv[NV], bv[NV];
+  float rb[NV][V];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int iv = lane + k * 64;
+    wv[k] = vec_t{};
+    bv[k] = vec_t{};
+#pragma unroll
+    for (int i = 0; i < V; ++i) rb[k][i] = 0.f;
+    if (iv < nv) {
+      wv[k] = *(const vec_t*)(w + (int64_t)iv * V);
+      if (bias) bv[k] = *(const vec_t*)(bias + (int64_t)iv * V);
+      if (row_bias) {
+#pragma unroll
+        for (int i = 0; i < V; i += 4) {
+          const f32x4 r4 = *(const f32x4*)(row_bias + (int64_t)iv * V + i);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) rb[k][i + j] = r4[j];
+        }
+      }
+    }
+  }
+  constexpr int NVD = DELTA ? NV : 1;
+  vec_t xv[NV], dv[NVD], xn[NV], dn[NVD];
+  auto load_row = [&](int64_t row, vec_t (&xo)[NV], vec_t (&dd)[NVD]) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int iv = lane + k * 64;
+      if (iv < nv) {
+        xo[k] = *(const vec_t*)(x + row * xs + (int64_t)iv * V);
+        if (DELTA) dd[k % NVD] = *(const vec_t*)(delta + row * ds + (int64_t)iv * V);
+      }
+    }
+  };
+  load_row(row0, xv, dv);
+  for (int r = 0; r < nrow; ++r) {
+    const int64_t row = row0 + r;
+    if (r + 1 < nrow) load_row(row + 1, xn, dn);
+    float vals[NV][V];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int iv = lane + k * 64;
+      if (iv < nv) {
+        if (DELTA) {
+          vec_t sv;
+#pragma unroll
+          for (int i = 0; i < V; ++i) {
+            sv[i] = from_f32<T>(to_f32(xv[k][i]) + to_f32(dv[k % NVD][i]));
+            vals[k][i] = to_f32(sv[i]);
+          }
+          if (sum_out) *(vec_t*)(sum_out + row * ss + (int64_t)iv * V) = sv;
+        } else {
+#pragma unroll
+          for (int i = 0; i < V; ++i) vals[k][i] = to_f32(xv[k][i]);
+        }
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          vals[k][i] += rb[k][i];
+          s1 += vals[k][i];
+        }
+      }
+    }
+    s1 = wave_sum_dpp(s1);
+    const float mean = s1 / (float)D;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int iv = lane + k * 64;
+      if (iv < nv) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) { const float d = vals[k][i] - mean; s2 = fmaf(d, d, s2); }
+      }
+    }
+    s2 = wave_sum_dpp(s2);
+    const float rstd = rsqrtf(s2 / (float)D + eps);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int iv = lane + k * 64;
+      if (iv < nv) {
+        vec_t o;
+#pragma unroll
+        for (int i = 0; i < V; ++i)
+          o[i] = from_f32<T>((vals[k][i] - mean) * rstd * to_f32(wv[k][i]) + to_f32(bv[k][i]));
+        *(vec_t*)(y + row * ys + (int64_t)iv * V) = o;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) xv[k] = xn[k];
+#pragma unroll
+    for (int k = 0; k < NVD; ++k) dv[k] = dn[k];
   }
 }
 
@@ -362,7 +477,7 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_gated_kernel(
       }
     }
   }
-  ssq = wave_sum(ssq);
+  ssq = wave_sum_dpp(ssq);
   const float rstd = rsqrtf(ssq / (float)gsz + eps);
   T* yr = y + row * ys + (int64_t)g * gsz;
 #pragma unroll
@@ -417,7 +532,23 @@ int launch_ln(const void* x, const void* delta, const void* w, const void* b, co
   if (D % V || D / V > NORM_THREADS * NORM_MAXV)
     TV_UNSUPPORTED("layernorm: dim %d not a multiple of %d or larger than %d", D, V,
                    V * NORM_THREADS * NORM_MAXV);
-  if (D / V <= 64 * NORM_MAXV) {
+  constexpr int RPW = 8;
+  static const int rows_off = [] { const char* e = getenv("TV_LN_ROWS"); return e && atoi(e) == 0; }();     // dev: A/B
+  if (D / V <= 64 * NORM_MAXV && rows >= 4096 * RPW && !rows_off && !delta) {
+    // many rows (the ViT's stream form: row bias, no residual operand): a wave keeps the parameters in registers for RPW
+    // rows — 1 272 against 1 416 us per 1.49 M rows x 1 152 (5.41 against 4.86 TB/s); with a residual operand the
+    // one-row kernel is the faster one (2 502 against 2 654 us: the second operand's registers cost a wave per SIMD)
+    const int64_t nblk = (rows + (NORM_THREADS / 64) * RPW - 1) / ((NORM_THREADS / 64) * RPW);
+    const int nvl = (D / V + 63) / 64;
+#define TV_LN_ROWS(NV)                                                                                              \
+    layernorm_rows_kernel<T, NV, RPW, false><<<dim3((unsigned)nblk), NORM_THREADS, 0, s>>>(                         \
+        (const T*)x, nullptr, (const T*)w, (const T*)b, rb, (T*)sum_out, (T*)y, rows, D, xs, ds, ss, ys, eps)
+    if (nvl == 1) TV_LN_ROWS(1);
+    else if (nvl == 2) TV_LN_ROWS(2);
+    else if (nvl == 3) TV_LN_ROWS(3);
+    else TV_LN_ROWS(4);
+#undef TV_LN_ROWS
+  } else if (D / V <= 64 * NORM_MAXV) {
     const int64_t nblk = (rows + NORM_THREADS / 64 - 1) / (NORM_THREADS / 64);
     layernorm_wave_kernel<T><<<dim3((unsigned)nblk), NORM_THREADS, 0, s>>>(
         (const T*)x, (const T*)delta, (const T*)w, (const T*)b, rb, (T*)sum_out, (T*)y, rows, D, xs, ds, ss,
