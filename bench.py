@@ -125,7 +125,10 @@ class OpTimers:
             return ("gelu", 2 * x.numel() * x.element_size())
         def gemm(x, weight, bias=None, epilogue=0, out=None):
             rows = x.numel() // x.shape[-1]
-            return ("gemm_fused", 2.0 * rows * weight.shape[0] * weight.shape[1])      # the activation's flops are not counted
+            # USEFUL flops: zero-padded weight rows (so400m's fc1: 4 352 rows for 4 304 outputs) are not counted, nor is
+            # the activation.  (The padded rows are all-zero by construction: ZeroPaddedLinears.)
+            n_useful = getattr(weight, "_tv_useful_rows", weight.shape[0])
+            return ("gemm_fused", 2.0 * rows * n_useful * weight.shape[1])
         self._wrap("linear_fused", gemm)
         self._wrap("mamba_chunk_scan_combined", scan)
         self._wrap("flash_attn_func", attn)
@@ -227,15 +230,16 @@ class OpTimers:
         out = [self.scan_roofline(bytes_per_token),
                self.mfma_roofline("attn_vit", "flash_fwd_stream_kernel, ViT frames (non-causal, head_dim 72; useful FLOPs)"),
                self.mfma_roofline("attn_causal", "flash_fwd_kernel, causal GQA (LLM attention layers; useful FLOPs)")]
-        out.append(self.mfma_roofline("gemm_fused", "gemm_bf16_kernel<bias + erf-GELU> (tv_gemm_bf16_fwd: ViT fc1 with the activation in "
-                                                    "the epilogue; GEMM FLOPs only)"))
+        out.append(self.mfma_roofline("gemm_fused", "gemm_persist_kernel<bias + erf-GELU> (tv_gemm_bf16_fwd: ViT fc1 with the activation in "
+                                                    "the epilogue, persistent work-groups; useful GEMM FLOPs only: 4 304 of the "
+                                                    "4 352 zero-padded columns)"))
         out += self.patch_rooflines()
         out += [self.hbm_roofline("conv", "conv1d_xbc_kernel + conv1d_bc_cb_kernel (tv_causal_conv1d_xbc_cb_fwd: conv + SiLU + "
                                           "x|B|C split + causal C.B^T fragments; bytes: xBC read, x|B|C written)"),
                 self.hbm_roofline("gated_norm", "rmsnorm_gated_kernel (tv_rmsnorm_gated_fwd; bytes: y, gate read, out written)"),
                 self.mixer_trio_roofline(cfg) if cfg is not None else None,
                 self.hbm_roofline("rmsnorm", "rmsnorm_kernel (tv_rmsnorm_fwd, residual add fused; bytes: every row read / written once)"),
-                self.hbm_roofline("layernorm", "layernorm_wave_kernel (tv_layernorm_fwd, ViT; bytes: every row read / written once)"),
+                self.hbm_roofline("layernorm", "layernorm_rows_kernel (tv_layernorm_fwd, ViT, 8 rows per wave; bytes: every row read / written once)"),
                 self.hbm_roofline("gelu", "gelu_kernel (tv_gelu_fwd, in place: ViT MLP and projector; bytes: read + write)")]
         return [o for o in out if o]
 

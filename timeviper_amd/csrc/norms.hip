@@ -375,17 +375,18 @@ __global__ __launch_bounds__(NORM_THREADS, DELTA ? 3 : 4) void layernorm_rows_ke
 // kernel is bound by HBM and not by libm's piecewise erff (~45 ops with divergent paths).
 // gelu(x) = 0.5 x (1 + erf(x / sqrt 2)), the reference's nn.GELU() formula.
 __device__ __forceinline__ float gelu_erf(float x) {
+  // A&S 7.1.26 with 0.5 sqrt(2) folded into the polynomial: gelu(x) = x/2 + |x|/2 erf(|x| / sqrt 2) = x/2 + z (k erf(z)),
+  // z = |x| / sqrt 2, k = sqrt(2) / 2 — no copysign, no |x/2| (the packed fp32 forms have no abs modifier), one multiply less
   const float z = fabsf(x) * 0.70710678118654752f;
   const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.f));
-  float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
-  p = __builtin_fmaf(p, t, 1.421413741f);
-  p = __builtin_fmaf(p, t, -0.284496736f);
-  p = __builtin_fmaf(p, t, 0.254829592f);
+  float p = __builtin_fmaf(0.750526965f, t, -1.02753365f);          // k x {1.061405429, -1.453152027, 1.421413741, -0.284496736, 0.254829592}
+  p = __builtin_fmaf(p, t, 1.00509131f);
+  p = __builtin_fmaf(p, t, -0.201169565f);
+  p = __builtin_fmaf(p, t, 0.180191725f);
   p *= t;
   const float e = __builtin_amdgcn_exp2f(z * z * -1.4426950408889634f);
-  const float erf_abs = __builtin_fmaf(-p, e, 1.f);
-  const float hx = 0.5f * x;
-  return __builtin_fmaf(hx, copysignf(erf_abs, x), hx);
+  const float r = __builtin_fmaf(-p, e, 0.70710678118654752f);       // k erf(z)
+  return __builtin_fmaf(z, r, 0.5f * x);
 }
 
 // relu(x)^2 (NemotronHMLP's "relu2" activation, modeling_nano.py:993-994)

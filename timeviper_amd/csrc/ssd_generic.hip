@@ -7,6 +7,7 @@
 // tiles are staged through LDS with coalesced loads.  The bf16 Nano-shape fast
 // path is the MFMA chunk-march kernel in ssd_march.hip.
 // Reference semantics: modeling_nano.py:639-653, CPU twin :775-851.
+#include <type_traits>
 #include "common.hpp"
 
 namespace {
@@ -176,32 +177,35 @@ __global__ __launch_bounds__(256) void state_update_rows_kernel(float* __restric
                                                                 const T* __restrict__ Bm, const T* __restrict__ Cm,
                                                                 const float* __restrict__ D, const float* __restrict__ dt_bias,
                                                                 T* __restrict__ y, int H, int P, int G, int softplus,
-                                                                int64_t rows_total) {
-  constexpr int N = 4 * LPR, RPW = 64 / LPR, ITERS = 4;
+                                                                int rows_total) {
+  // Round 5: ITERS 4 -> 2 (twice the work-groups: a Nano layer is 10 240 rows = 5.2 MB, 20 KB a CU — the launch is a
+  // latency chain, not a stream), 32-bit row arithmetic with ONE division pair per wave (the 64-bit / % of every
+  // iteration were ~100 instructions each in front of the first load), B and C as 8-byte loads.
+  constexpr int N = 4 * LPR, RPW = 64 / LPR, ITERS = 2;
+  typedef typename std::conditional<std::is_same<T, float>::value, f32x4, typename std::conditional<std::is_same<T, bf16_t>::value, bf16x4, f16x4>::type>::type vec4_t;
   const int lane = threadIdx.x & 63;
-  const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int w = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int sub = lane / LPR, ln = lane % LPR;
   // every load of the wave's ITERS x RPW rows is issued before the first use (rows past the end re-read the last one)
-  int64_t row[ITERS];
+  int row[ITERS];
   f32x4 sv[ITERS];
   float dtv[ITERS], xr[ITERS];
   int hh[ITERS];
-  T Bv[ITERS][4], Cv[ITERS][4];
+  vec4_t Bv[ITERS], Cv[ITERS];
+  const int hpg = H / G;
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
     row[it] = (w * ITERS + it) * RPW + sub;             // (b, h, p) flattened
-    const int64_t rc = row[it] < rows_total ? row[it] : rows_total - 1;
-    const int64_t bh = rc / P;
-    hh[it] = (int)(bh % H);
-    const int64_t b = bh / H;
-    const int g = hh[it] / (H / G);
-    sv[it] = *((const f32x4*)(state + rc * N) + ln);
+    const int rc = row[it] < rows_total ? row[it] : rows_total - 1;
+    const int bh = (int)((unsigned)rc / (unsigned)P);
+    const int b = (int)((unsigned)bh / (unsigned)H);
+    hh[it] = bh - b * H;
+    const int g = (int)((unsigned)hh[it] / (unsigned)hpg);
+    sv[it] = *((const f32x4*)(state + (int64_t)rc * N) + ln);
     dtv[it] = to_f32(dt[bh]);
     xr[it] = to_f32(x[rc]);
-    const T* Br = Bm + (b * G + g) * N + 4 * ln;
-    const T* Cr = Cm + (b * G + g) * N + 4 * ln;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { Bv[it][i] = Br[i]; Cv[it][i] = Cr[i]; }
+    Bv[it] = *(const vec4_t*)(Bm + (int64_t)(b * G + g) * N + 4 * ln);
+    Cv[it] = *(const vec4_t*)(Cm + (int64_t)(b * G + g) * N + 4 * ln);
   }
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
@@ -219,7 +223,7 @@ __global__ __launch_bounds__(256) void state_update_rows_kernel(float* __restric
       v[i] = fmaf(dec, sv[it][i], xv * to_f32(Bv[it][i]));
       part = fmaf(v[i], to_f32(Cv[it][i]), part);
     }
-    if (ok) *((f32x4*)(state + row[it] * N) + ln) = v;
+    if (ok) *((f32x4*)(state + (int64_t)row[it] * N) + ln) = v;
 #pragma unroll
     for (int o = LPR / 2; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
     if (ok && ln == 0) y[row[it]] = from_f32<T>(fmaf(dh, xr[it], part));
@@ -266,14 +270,15 @@ extern "C" int tv_selective_state_update(void* state, const void* x, const void*
   hipStream_t s = (hipStream_t)stream;
   // d_state 16 / 32 / 64 / 128 / 256 with 16-byte aligned rows: lanes share a row (coalesced); anything else: a thread per row
   const int lpr = dstate / 4;
-  if (dstate % 4 == 0 && (lpr == 4 || lpr == 8 || lpr == 16 || lpr == 32 || lpr == 64) && (((uintptr_t)state) & 15) == 0) {
+  if (dstate % 4 == 0 && (lpr == 4 || lpr == 8 || lpr == 16 || lpr == 32 || lpr == 64) && (((uintptr_t)state) & 15) == 0 &&
+      (((uintptr_t)Bm | (uintptr_t)Cm) & 15) == 0 && (int64_t)batch * nheads * headdim < (1ll << 31)) {
     const int64_t rows = (int64_t)batch * nheads * headdim;
-    const int64_t rows_per_block = 4 * 4 * (64 / lpr);          // 4 waves x 4 iterations x rows per wave-instruction
+    const int64_t rows_per_block = 4 * 2 * (64 / lpr);          // 4 waves x 2 iterations x rows per wave-instruction
     const dim3 rgrid((unsigned)((rows + rows_per_block - 1) / rows_per_block));
 #define TV_SUR(T, LPR)                                                                                        \
     state_update_rows_kernel<T, LPR><<<rgrid, 256, 0, s>>>((float*)state, (const T*)x, (const T*)dt,          \
         (const float*)A, (const T*)Bm, (const T*)Cm, (const float*)D, (const float*)dt_bias, (T*)y, nheads,   \
-        headdim, ngroups, dt_softplus, rows)
+        headdim, ngroups, dt_softplus, (int)rows)
 #define TV_SUR_T(T)                                                                                           \
     switch (lpr) { case 4: TV_SUR(T, 4); break; case 8: TV_SUR(T, 8); break; case 16: TV_SUR(T, 16); break;     \
                    case 32: TV_SUR(T, 32); break; default: TV_SUR(T, 64); break; }
