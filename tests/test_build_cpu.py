@@ -82,3 +82,16 @@ def test_attention_kernels_with_untracked_q_loads_spill_nothing(tmp_path):
         assert kernels, (src, list(md))
         for k, v in kernels.items():
             assert v.get("private_segment_fixed_size") == 0 and v.get("vgpr_spill_count", 0) == 0, (src, k, v)
+
+
+@needs_tools
+def test_gemm_kernels_spill_nothing(tmp_path):
+    """Both GEMM kernels keep five half-tiles of LDS-DMA copies in flight behind hand-counted waits and, at two waves per
+    SIMD, live within 256 registers: a spill would put scratch loads — which the compiler waits for with vmcnt(0) — into
+    the copy queue and drain the pipeline every K-tile.  (Scalar spills into vector lanes are allowed: no memory.)"""
+    for src, pat, n in (("gemm.hip", "gemm_bf16_kernel", 3), ("gemm_persist.hip", "gemm_persist_kernel", 2)):
+        md = kernel_metadata(src, tmp_path)
+        kernels = {k: v for k, v in md.items() if pat in k}
+        assert len(kernels) == n, (src, list(md))
+        for k, v in kernels.items():
+            assert v.get("private_segment_fixed_size") == 0 and v.get("vgpr_spill_count", 0) == 0, (src, k, v)

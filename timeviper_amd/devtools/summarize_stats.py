@@ -25,8 +25,8 @@ def share(pred):
 
 
 print()
-for pat in ("ssd_head_kernel", "ssd_pair_kernel", "ssd_dt_transpose", "ssd_slice_kernel", "ssd_cb_kernel", "ssd_correct_kernel", "ssd_seg_chain",
-            "ssd_decay_prefix", "gemm_bf16_kernel", "conv1d_xbc", "conv1d_bc_cb", "rmsnorm_gated"):
+for pat in ("ssd_head_kernel", "ssd_dt_transpose", "ssd_slice_kernel", "ssd_cb_kernel", "ssd_correct_kernel", "ssd_seg_chain",
+            "ssd_decay_prefix", "gemm_persist_kernel", "gemm_bf16_kernel", "layernorm_rows", "conv1d_xbc", "conv1d_bc_cb", "rmsnorm_gated"):
     for r in rows:
         if pat in r["Name"]:
             print(f"- `{r['Name'][:60]}`: {r['Calls']} calls, avg {float(r['AverageNs']) / 1e3:.1f} µs, "
@@ -37,7 +37,7 @@ print(f"\n`bench.py` measured the scan with events on the launch stream: {rf['la
       f"{rf['peak'] / 1000:.0f} TB/s**; HBM traffic {rf['traffic']} GB/s ({rf.get('traffic_source', '')}).\n")
 print("Share of GPU time: hipBLASLt GEMMs %.1f %%, own GEMM (fc1 + GELU) %.1f %%, attention kernels %.1f %%, GELU %.1f %%, LayerNorm %.1f %%, "
       "patch embed %.1f %%, ToMe %.1f %%, Mamba kernels (scan, conv, gated norm) %.1f %%." % (
-          share(lambda n: n.startswith("Cijk") or "Cijk_" in n), share(lambda n: "gemm_bf16_kernel" in n), share(lambda n: "flash_fwd" in n),
+          share(lambda n: n.startswith("Cijk") or "Cijk_" in n), share(lambda n: "gemm_bf16_kernel" in n or "gemm_persist_kernel" in n), share(lambda n: "flash_fwd" in n),
           share(lambda n: "gelu_kernel" in n), share(lambda n: "layernorm" in n), share(lambda n: "patch_embed" in n),
           share(lambda n: "tome_" in n),
           share(lambda n: any(k in n for k in ("ssd_", "conv1d", "rmsnorm_gated")))))
