@@ -45,7 +45,8 @@ def _sources():
 
 
 def _headers():
-    return sorted(list(CSRC.glob("*.hpp")) + list((ROOT.parent / "include").glob("*.h")))
+    incs = [p for p in CSRC.glob("*.inc") if not p.name.endswith("_stamp.inc")]      # generated asm bodies (devtools/gen_head_step.py)
+    return sorted(list(CSRC.glob("*.hpp")) + incs + list((ROOT.parent / "include").glob("*.h")))
 
 
 def _hash(paths, extra: str = "") -> str:

@@ -841,6 +841,297 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// head_dim 80, four heads per work-group: the step as ONE hand-scheduled instruction stream (ssd_head_step.inc,
+// generated by devtools/gen_head_step.py).  The C++ below keeps what runs once per chunk outside the matrix work —
+// the vectors of the next chunk (prep), the mode decision, the scalar addresses — and hands everything else to the
+// asm body: state in a0..a159 and the y accumulators in a160..a239 for the whole march, v86..v255 are the body's,
+// nothing lives in those registers across a statement except the state.  Same arithmetic in the same order per
+// accumulator as ssd_head_kernel<5,4,2> (bit-identical y and final state).
+#ifdef TV_HEAD_STAMP
+#include "ssd_head_step_stamp.inc"       // dev: python devtools/gen_head_step.py --stamps > csrc/ssd_head_step_stamp.inc
+#define TV_STEP_STAMP_OPS , [stl] "+s"(st_last), [st0] "+s"(st0), [st1] "+s"(st1), [st2] "+s"(st2), [st3] "+s"(st3), [st4] "+s"(st4), [st5] "+s"(st5), \
+    [st6] "+s"(st6), [st7] "+s"(st7), [st8] "+s"(st8), [st9] "+s"(st9), [st10] "+s"(st10)
+#else
+#include "ssd_head_step.inc"
+#define TV_STEP_STAMP_OPS
+#endif
+
+struct __attribute__((aligned(16))) HeadVecA {
+  HeadVec v;
+  float one[HQ];      // weights / row factors of a standard step's Ydiag and epilogue
+};
+struct __attribute__((aligned(16))) HeadSmemA {
+  bf16_t bt[2][HQ * HN];
+  bf16_t ct[2][HQ * HN];
+  bf16_t xr[4][2][HQ * 80 + 256];
+  HeadVecA v[4];
+};
+
+__global__ __launch_bounds__(256) void ssd_head_asm_kernel(HeadArgs a) {
+  typedef HeadSmemA Smem;
+  constexpr int PT = 5, NW = 4, NB = 2, P = 80, KP = 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  Smem& sm = *reinterpret_cast<Smem*>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lc = lane & 15, kq = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+  const int b = blockIdx.y;
+  const int hpg = a.H / a.G;
+  const int g = blockIdx.x % a.G;
+  const int hig = (blockIdx.x / a.G) * NW + wave;
+  const int h = a.group_map ? (hig * a.G + g) : (g * hpg + hig);
+  const int seg = blockIdx.z;
+  const int c_first = seg * a.seg_chunks;
+  const int t_first = c_first * HQ;
+  const int nchunks = min(a.seg_chunks, a.nchunks - c_first);
+  const int L = min(a.L - t_first, nchunks * HQ);
+  HeadVec& vec = sm.v[wave].v;
+  const unsigned lds0 = lds_addr_of(smem_raw);
+  const unsigned lds_bt = lds0 + (unsigned)offsetof(Smem, bt), lds_ct = lds0 + (unsigned)offsetof(Smem, ct);
+  const unsigned lds_xr = lds0 + (unsigned)offsetof(Smem, xr) + wave * (unsigned)sizeof(sm.xr[0]);
+  const unsigned lds_vec = lds0 + (unsigned)offsetof(Smem, v) + wave * (unsigned)sizeof(HeadVecA);
+  constexpr unsigned XSLOT = sizeof(sm.xr[0][0]);
+  {
+    float* vz = reinterpret_cast<float*>(&sm.v[wave]);
+    for (int i = lane; i < (int)(sizeof(HeadVecA) / 4); i += 64) vz[i] = 0.f;
+    sm.v[wave].one[lane] = 1.f;
+  }
+
+  // ---- B / C copies (as in ssd_head_kernel): piece k of this wave = token rows 16 wave + 4 k + (lane >> 4)
+  const bf16_t* Bg = a.Bm + (int64_t)b * a.bsb + (int64_t)g * a.bsg + (int64_t)t_first * a.bsl;
+  const bf16_t* Cg = a.Cm + (int64_t)b * a.csb + (int64_t)g * a.csg + (int64_t)t_first * a.csl;
+  const int bc_row0 = 4 * KP * wave + (lane >> 4);
+  const unsigned off_b0 = (unsigned)((bc_row0 * a.bsl + ((lane & 15) ^ (4 * ((lane >> 4) & 3))) * 8) * 2);
+  const unsigned off_c0 = (unsigned)(bc_row0 * a.csl * 2);
+  const unsigned cgc0 = (unsigned)(((lane & 15) ^ (lane >> 4)) << 4);
+  const unsigned r4b = (unsigned)(4 * a.bsl * 2), r4c = (unsigned)(4 * a.csl * 2);
+  const unsigned ob0 = off_b0, ob1 = off_b0 + r4b - 1024u, ob2 = off_b0 + 2 * r4b - 2048u, ob3 = off_b0 + 3 * r4b - 3072u;
+  const unsigned oc0 = off_c0 + cgc0, oc1 = off_c0 + r4c + (cgc0 ^ 64u) - 1024u, oc2 = off_c0 + 2 * r4c + (cgc0 ^ 128u) - 2048u,
+                 oc3 = off_c0 + 3 * r4c + (cgc0 ^ 192u) - 3072u;
+  auto issue_bc_tail = [&](int c, int which) {       // a chunk with fewer than 64 rows: rows past the end repeat the last row
+    const int slot = c % NB;
+    const int t0 = c * HQ;
+    const bf16_t* Tc = which ? Cg + (int64_t)t0 * a.csl : Bg + (int64_t)t0 * a.bsl;
+    const int64_t rl = which ? a.csl : a.bsl;
+    const unsigned dst = (which ? lds_ct : lds_bt) + slot * (HQ * HN * 2);
+    const void* sp = uniform_ptr(Tc);
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+      const int row = 4 * KP * wave + 4 * k + (lane >> 4);
+      const int rr = min(row, L - 1 - t0);
+      const int cg = which ? (lane & 15) ^ (row & 15) : (lane & 15) ^ (4 * (row & 3));
+      glds16(sp, (unsigned)((rr * rl + cg * 8) * 2), dst + (KP * wave + k) * 1024);
+    }
+  };
+  // ---- x copies
+  constexpr int XROW = 2 * P, NPC = P / 8, RPI = 64 / NPC, NXI = (HQ + RPI - 1) / RPI;
+  const bf16_t* xg = a.x + (int64_t)b * a.xsb + (int64_t)t_first * a.xsl + (int64_t)h * P;
+  const int x_lrow = lane / NPC;
+  const unsigned x_off = (unsigned)((x_lrow * a.xsl + (lane % NPC) * 8) * 2);
+  const unsigned x_off_last = (unsigned)((min(x_lrow, HQ - 1 - RPI * (NXI - 1)) * a.xsl + (lane % NPC) * 8) * 2);
+  const unsigned dj = (unsigned)(RPI * a.xsl * 2) - (unsigned)(RPI * XROW);
+  const unsigned ox0 = x_off, ox1 = x_off + dj, ox2 = x_off + 2 * dj, ox3 = x_off + 3 * dj, oxl = x_off_last + 2 * dj;
+  const unsigned xg4 = (unsigned)(RPI * 4 * a.xsl * 2);
+  auto issue_x_tail = [&](int c) {
+    const int t0 = c * HQ;
+    const bf16_t* xc = xg + (int64_t)t0 * a.xsl;
+#pragma unroll
+    for (int k = 0; k < NXI; ++k)
+      glds16(uniform_ptr(xc), (unsigned)((min(RPI * k + x_lrow, L - 1 - t0) * a.xsl + (lane % NPC) * 8) * 2),
+             lds_xr + (c & 1) * XSLOT + RPI * k * XROW);
+  };
+  auto issue_full = [&](int c) {        // a whole chunk from C++ (prologue only)
+    const void* sb = uniform_ptr(Bg + (int64_t)c * HQ * a.bsl);
+    glds16x4(sb, ob0, ob1, ob2, ob3, lds_bt + (c % NB) * (HQ * HN * 2) + KP * wave * 1024);
+    const void* sc = uniform_ptr(Cg + (int64_t)c * HQ * a.csl);
+    glds16x4(sc, oc0, oc1, oc2, oc3, lds_ct + (c % NB) * (HQ * HN * 2) + KP * wave * 1024);
+#pragma unroll
+    for (int k = 0; k < NXI; ++k) {
+      const void* sx = uniform_ptr(xg + (int64_t)(c * HQ + RPI * k) * a.xsl);
+      glds16(sx, k == NXI - 1 ? x_off_last : x_off, lds_xr + (c & 1) * XSLOT + RPI * k * XROW);
+    }
+  };
+  auto issue_chunk = [&](int c) {
+    if ((c + 1) * HQ <= L) issue_full(c);
+    else { issue_bc_tail(c, 0); issue_bc_tail(c, 1); issue_x_tail(c); }
+  };
+
+  // ---- lane parts of the LDS addresses the step reads (slot 0; the step adds the slot offsets)
+  const int xr_lo = (8 * kq + q4) * XROW + 8 * p4, xv_lo = lc * XROW + 8 * kq;
+  const int c_lo = lc * 256, c_z = (kq ^ lc) << 4, bsw = q4 << 6, b_lo = (8 * kq + q4) * 256 + p4 * 16;
+  const unsigned ca0 = lds_ct + ((c_z ^ 0) + c_lo), ca1 = lds_ct + ((c_z ^ 64) + c_lo), ca2 = lds_ct + ((c_z ^ 128) + c_lo),
+                 ca3 = lds_ct + ((c_z ^ 192) + c_lo);
+  const unsigned ba0 = lds_bt + ((bsw ^ 0) + b_lo), ba1 = lds_bt + ((bsw ^ 64) + b_lo), ba2 = lds_bt + ((bsw ^ 128) + b_lo),
+                 ba3 = lds_bt + ((bsw ^ 192) + b_lo);
+  const unsigned xtr = lds_xr + xr_lo, xvr = lds_xr + xv_lo;
+  const unsigned vw_wts = lds_vec + (unsigned)offsetof(HeadVec, wts) + 32 * kq;
+  const unsigned vw_one = lds_vec + (unsigned)offsetof(HeadVecA, one) + 32 * kq;
+  const unsigned vev_ecs = lds_vec + (unsigned)offsetof(HeadVec, ecs) + 4 * lc;
+  const unsigned vev_one = lds_vec + (unsigned)offsetof(HeadVecA, one) + 4 * lc;
+  // standard steps: the mask factors' addresses (token t = 16 (kq >> 1) + lc, columns s = 8 kq + j) and the diagonal test
+  const unsigned sa_t = lds_vec + 4 * (16 * (kq >> 1) + lc), sa_s = lds_vec + 32 * kq, sa_lc = lds_vec + 4 * lc, sa_s15 = lds_vec + 32 * (kq & 1);
+  const int sd0 = 16 * (kq >> 1) + lc - 8 * kq;
+  const unsigned cbo = lane * 16, dto = lane * 2;
+  const unsigned yo16 = (unsigned)(((16 * (kq & 1) + lc) * a.ysl + 8 * (kq >> 1)) * 2);
+  bf16_t* const ygs = a.y + (int64_t)b * a.ysb + (int64_t)t_first * a.ysl + (int64_t)h * P;
+  const bf16_t* cbg = a.cb + (((int64_t)b * a.G + g) * a.nchunks + c_first) * CBE;
+  const unsigned y32 = (unsigned)(64 * a.ysl);
+
+  // ---- per-chunk vectors (the same decisions and arithmetic as ssd_head_kernel's prep)
+  const float Ah = a.A[h];
+  const float bias = a.dt_bias ? a.dt_bias[h] : 0.f;
+  const float Dh = a.D ? a.D[h] : 0.f;
+  const bf16_t* dtg = a.dt + (int64_t)b * a.dsb + (int64_t)t_first * a.dsl + (int64_t)h * a.dsh;      // head-major: dsl == 1
+  float decay_total = 0.f;
+  float E = 0.f;
+  bool reset_next = false, std_next = false;
+  auto prep = [&](int c, unsigned raw_bits, float& f_out) __attribute__((always_inline)) {
+    const int t = c * HQ + lane;
+    float d = 0.f;
+    if (t < L) {
+      d = bf16_lo(raw_bits) + bias;
+      if (a.softplus) d = softplus_fast(d);
+      d = fminf(fmaxf(d, a.dt_min), a.dt_max);
+    }
+    const float cs = wave_incl_scan_dpp(d * Ah);
+    const float cl = rdlane(cs, 63);
+    const float cs2 = cs * 1.4426950408889634f, cl2 = cl * 1.4426950408889634f;
+    const int mode = -(E + cl2) <= RMAX ? 0 : -cl2 <= 2.f * RMAX - 1.f ? 1 : 2;
+    const float mshift = mode == 1 ? __builtin_floorf(RMAX - E) : 0.f;
+    const float Euse = E + mshift;
+    f_out = mode == 1 ? -mshift : 1.f;
+    vec.cs[lane] = cs2;
+    vec.dtv[lane] = d;
+    vec.ecs[lane] = __builtin_amdgcn_exp2f(cs2 + Euse);
+    const bool rst = TV_HEAD_RESET && mode != 2 && cl2 <= -RESET_THR;
+    const bool ustd = mode == 2;
+    reset_next = rst || ustd;
+    std_next = ustd;
+    vec.wts[lane] = __builtin_amdgcn_exp2f(mode == 2 ? cl2 - cs2 : rst ? cl2 - cs2 - RMAX : -cs2 - Euse) * d;
+    if (rst) vec.wtd[c & 1][lane] = __builtin_amdgcn_exp2f(-cs2 - Euse) * d;
+    if (a.chunk_tot && lane == 0) a.chunk_tot[((int64_t)b * a.H + h) * a.nchunks + c_first + c] = cl2;
+    if (__builtin_expect(mode == 2, 0)) {
+      const float p0 = rdlane(cs2, 0), p1 = rdlane(cs2, 16), p2 = rdlane(cs2, 32), p3 = rdlane(cs2, 48);
+      const float pv = lane < 16 ? p0 : lane < 32 ? p1 : lane < 48 ? p2 : p3;
+      vec.ut[lane] = __builtin_amdgcn_exp2f(fminf(cs2 - pv, 0.f));
+      if (lane < 16) vec.ws[lane] = __builtin_amdgcn_exp2f(fminf(p1 - cs2, 0.f)) * d;
+      if (lane < 32) vec.ws[16 + lane] = __builtin_amdgcn_exp2f(fminf(p2 - cs2, 0.f)) * d;
+      if (lane < 48) vec.ws[48 + lane] = __builtin_amdgcn_exp2f(fminf(p3 - cs2, 0.f)) * d;
+    }
+    decay_total += cl;
+    E = mode == 2 ? 0.f : rst ? RMAX : Euse + cl2;
+    return __builtin_amdgcn_readfirstlane(ustd ? 0 : mode);
+  };
+
+  // ---- state: zero, or the caller's initial state (first segment)
+  asm volatile(TV_HEAD_STATE_ZERO ::: TV_HEAD_STATE_CLOBBERS);
+  if (a.init && seg == 0) {
+#pragma unroll
+    for (int ct = 0; ct < PT; ++ct)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const f32x4 v = *(const f32x4*)(a.init + (((int64_t)b * a.H + h) * P + 16 * ct + lc) * HN + 32 * (i >> 1) + 8 * kq + 4 * (i & 1));
+        asm volatile("v_accvgpr_write_b32 a[%c4], %0\n\tv_accvgpr_write_b32 a[%c5], %1\n\tv_accvgpr_write_b32 a[%c6], %2\n\tv_accvgpr_write_b32 a[%c7], %3"
+                     :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "n"(32 * ct + 4 * i), "n"(32 * ct + 4 * i + 1), "n"(32 * ct + 4 * i + 2), "n"(32 * ct + 4 * i + 3)
+                     : TV_HEAD_STATE_CLOBBERS);
+      }
+  }
+
+  // ---- prologue: chunk 0's copies, its vectors
+  issue_chunk(0);
+  unsigned dt_next = *(const unsigned short*)(dtg + lane);
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(dt_next) :: "memory");
+  float f_step;
+  int mode = prep(0, dt_next, f_step);
+  bool reset_cur = __builtin_amdgcn_readfirstlane((int)reset_next) != 0;
+  bool std_cur = __builtin_amdgcn_readfirstlane((int)std_next) != 0;
+  dt_next = *(const unsigned short*)(dtg + (int64_t)min(1, nchunks - 1) * HQ + lane);
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(dt_next) :: "memory");
+  HEAD_BARRIER(0);
+
+#ifdef TV_HEAD_STAMP
+  unsigned st_last = (unsigned)clock64(), st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, st5 = 0, st6 = 0, st7 = 0, st8 = 0, st9 = 0, st10 = 0;
+#endif
+  for (int c = 0; c < nchunks; ++c) {
+    const bool more = c + 1 < nchunks;
+    const bool copy = more && (c + 2) * HQ <= L;
+    const bool full = (c + 1) * HQ <= L;
+    const int rem = L - c * HQ;
+    const unsigned long long m01 = full ? ~0ull : __builtin_amdgcn_ballot_w64(16 * (kq & 1) + lc < rem);
+    const unsigned long long m23 = full ? ~0ull : __builtin_amdgcn_ballot_w64(32 + 16 * (kq & 1) + lc < rem);
+    const unsigned flags = __builtin_amdgcn_readfirstlane((mode == 1 ? 1u : 0u) | (reset_cur ? 2u : 0u) | (std_cur ? 4u : 0u) | (copy ? 8u : 0u));
+    const int sh = __builtin_amdgcn_readfirstlane(mode == 1 ? (int)f_step : 0);
+    const unsigned sbc = (unsigned)(c % NB) * (HQ * HN * 2), sxs = (unsigned)(c & 1) * XSLOT;
+    // weights of x~ for Ydiag (phase A) and for the state update (phase B, reset steps); row factors of the epilogue
+    const unsigned vw = std_cur ? vw_one : reset_cur ? lds_vec + (unsigned)offsetof(HeadVec, wtd) + (c & 1) * 256 + 32 * kq : vw_wts;
+    const unsigned vev = std_cur ? vev_one : vev_ecs;
+    const void* pcb = uniform_ptr(cbg + (int64_t)c * CBE + 1024);       // (the step's offsets are -2048 .. 3072)
+    const void* py = uniform_ptr(ygs + (int64_t)c * HQ * a.ysl);
+    const void* pdt = uniform_ptr(dtg + (int64_t)min(c + 2, nchunks - 1) * HQ);
+    const int cn = more ? c + 1 : c;
+    const void* pb = uniform_ptr(Bg + (int64_t)cn * HQ * a.bsl);
+    const void* pc = uniform_ptr(Cg + (int64_t)cn * HQ * a.csl);
+    const void* px = uniform_ptr(xg + (int64_t)cn * HQ * a.xsl);
+    const unsigned lb = lds_bt + ((c + 1) % NB) * (HQ * HN * 2) + KP * wave * 1024;
+    const unsigned lcc = lds_ct + ((c + 1) % NB) * (HQ * HN * 2) + KP * wave * 1024;
+    const unsigned lx = lds_xr + ((c + 1) & 1) * XSLOT;
+    unsigned dt_new;
+    asm volatile(TV_HEAD_STEP_ASM
+                 : [dtout] "=&v"(dt_new) TV_STEP_STAMP_OPS
+                 : [ca0] "v"(ca0), [ca1] "v"(ca1), [ca2] "v"(ca2), [ca3] "v"(ca3), [ba0] "v"(ba0), [ba1] "v"(ba1), [ba2] "v"(ba2), [ba3] "v"(ba3),
+                   [xtr] "v"(xtr), [xvr] "v"(xvr), [vw] "v"(vw), [vw2] "v"(vw_wts), [vev] "v"(vev), [cbo] "v"(cbo), [yo16] "v"(yo16), [dto] "v"(dto),
+                   [ob0] "v"(ob0), [ob1] "v"(ob1), [ob2] "v"(ob2), [ob3] "v"(ob3), [oc0] "v"(oc0), [oc1] "v"(oc1), [oc2] "v"(oc2), [oc3] "v"(oc3),
+                   [ox0] "v"(ox0), [ox1] "v"(ox1), [ox2] "v"(ox2), [ox3] "v"(ox3), [oxl] "v"(oxl),
+                   [at] "v"(sa_t), [as] "v"(sa_s), [alc] "v"(sa_lc), [as15] "v"(sa_s15), [d0] "v"(sd0),
+                   [sbc] "s"(sbc), [sxs] "s"(sxs), [flags] "s"(flags), [sh] "s"(sh), [dh] "s"(Dh), [pcb] "s"(pcb), [py] "s"(py), [y32] "s"(y32),
+                   [pdt] "s"(pdt), [pb] "s"(pb), [pc] "s"(pc), [px] "s"(px), [xg4] "s"(xg4), [lb] "s"(lb), [lc] "s"(lcc), [lx] "s"(lx),
+                   [m01] "s"(m01), [m23] "s"(m23)
+                 : TV_HEAD_STEP_CLOBBERS);
+    if (more && !copy) {       // the next chunk is the sequence's last, partial one
+      issue_bc_tail(c + 1, 0);
+      issue_bc_tail(c + 1, 1);
+      issue_x_tail(c + 1);
+    }
+    if (more) {
+      mode = prep(c + 1, dt_next, f_step);
+      reset_cur = __builtin_amdgcn_readfirstlane((int)reset_next) != 0;
+      std_cur = __builtin_amdgcn_readfirstlane((int)std_next) != 0;
+    }
+    dt_next = dt_new;
+    if (copy) HEAD_BARRIER(2 * PT);
+    else HEAD_BARRIER(0);
+  }
+#ifdef TV_HEAD_STAMP
+  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0 && wave < 2) {
+    const unsigned sv[11] = {st0, st1, st2, st3, st4, st5, st6, st7, st8, st9, st10};
+    for (int i = 0; i < 11; ++i) g_head_phases[16 * wave + i] = sv[i];
+  }
+#endif
+  // ---- final state of this segment, X = 2^E X'
+  {
+    const float sc = __builtin_amdgcn_exp2f(E);
+    float* fin = a.nseg > 1 ? a.seg_state + (int64_t)seg * gridDim.y * a.H * P * HN : a.final_state;
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+    if (fin) {
+#pragma unroll
+      for (int ct = 0; ct < PT; ++ct)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          float v0, v1, v2, v3;
+          asm volatile("v_accvgpr_read_b32 %0, a[%c4]\n\tv_accvgpr_read_b32 %1, a[%c5]\n\tv_accvgpr_read_b32 %2, a[%c6]\n\tv_accvgpr_read_b32 %3, a[%c7]"
+                       : "=v"(v0), "=v"(v1), "=v"(v2), "=v"(v3)
+                       : "n"(32 * ct + 4 * i), "n"(32 * ct + 4 * i + 1), "n"(32 * ct + 4 * i + 2), "n"(32 * ct + 4 * i + 3));
+          *(f32x4*)(fin + (((int64_t)b * a.H + h) * P + 16 * ct + lc) * HN + 32 * (i >> 1) + 8 * kq + 4 * (i & 1)) =
+              f32x4{v0 * sc, v1 * sc, v2 * sc, v3 * sc};
+        }
+    }
+    float* td = a.nseg > 1 ? a.seg_decay + (int64_t)seg * gridDim.y * a.H : a.total_decay;
+    if (td && lane == 0) td[(int64_t)b * a.H + h] = decay_total;
+  }
+}
+
 // dt (B, L, H) -> (B, H, Lp) with Lp = 64 nchunks: a wave (= a head) then reads the 64 tokens of a chunk as ONE 128-byte line.
 // Token-major, the same 64 values are 2 bytes each out of 64 lines that all 128 heads share; the lines are evicted between
 // the visits of the work-groups that want them and came from HBM 11 times over (profiles/r04_ssd_scan_read_attribution.json:
@@ -880,6 +1171,13 @@ __global__ __launch_bounds__(256) void ssd_dt_transpose_kernel(const bf16_t* __r
     __syncthreads();
   }
 }
+
+// TV_HEAD_ASM=0 sends head_dim 80 x 4 heads back to the C++ step (A/B runs, dev only)
+bool head_asm_enabled() {
+  static const bool on = [] { const char* e = getenv("TV_HEAD_ASM"); return !e || atoi(e) != 0; }();
+  return on;
+}
+static_assert(sizeof(HeadSmemA) <= 160 * 1024, "LDS budget");
 
 // heads of one group per work-group: 4, 2 or 1
 int pick_nw(int hpg) { return hpg % 4 == 0 ? 4 : hpg % 2 == 0 ? 2 : 1; }
@@ -1007,7 +1305,14 @@ int tv_ssd_head_launch(const void* x, const void* dt, const void* A, const void*
   hipError_t e = hipSuccess;
   const int key = headdim / 16 * 10 + nw;
   switch (key) {
-    case 54: e = launch_head<5, 4>(a, grid, st); break;
+    case 54:
+      if (head_asm_enabled()) {
+        e = hipFuncSetAttribute((const void*)ssd_head_asm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(HeadSmemA));
+        if (e == hipSuccess) ssd_head_asm_kernel<<<grid, 256, sizeof(HeadSmemA), st>>>(a);
+      } else {
+        e = launch_head<5, 4>(a, grid, st);
+      }
+      break;
     case 52: e = launch_head<5, 2>(a, grid, st); break;
     case 51: e = launch_head<5, 1>(a, grid, st); break;
     case 44: e = launch_head<4, 4>(a, grid, st); break;

@@ -1,0 +1,679 @@
+#!/usr/bin/env python3
+"""Generator of csrc/ssd_head_step.inc: the 64-token step of the head-per-wave SSD march (ssd_head.hip,
+head_dim 80, 4 waves) as ONE hand-scheduled instruction stream.
+
+Why generated assembly: at one wave per SIMD nothing hides a stall, and hipcc's stream for the step clumps the
+vector work between groups of MFMAs, shuttles accumulator tiles between the two register files at the joins of the
+mode branches and exposes every LDS round trip (profiles/r05_ssd_head_isa.md).  Here every MFMA is followed by its
+share of the step's vector / LDS / copy instructions, registers are assigned by this file, and the wait counts and
+wait states are computed by the emitter from the final order.
+
+Step order (one chunk c of 64 tokens, one head = one wave):
+    [re-basing of the frame, when due]
+    preamble   addresses, weights, C.B^T / dt loads, bf16 copy of state rows 0..31
+    phase A    Yoff^T = X'^T C^T in four quarters of 32 state rows (80 MFMAs) beside: the bf16 copy of the next
+               quarter's state rows, x~ = w_s x on the transposed x fragments, the LDS-DMA copies of chunk c + 1;
+               then Ydiag on top (30 MFMAs, A = x~, B = causal C.B^T)
+    [reset steps: x~ again with the new frame's weights]
+    phase B    X' += B^T x~ (80 MFMAs) beside the y epilogue (row factor, D x, bf16, permlane swap, 16-byte stores)
+The arithmetic and its order per accumulator are those of ssd_head.hip's C++ step (bit-identical results).
+
+    python timeviper_amd/devtools/gen_head_step.py  > timeviper_amd/csrc/ssd_head_step.inc
+"""
+import sys
+
+PT = 5
+XROW = 160            # bytes per x row in LDS
+RPI = 6               # whole x rows per copy instruction
+NXI = 11              # copy instructions per x tile
+
+# ---------------------------------------------------------------- registers owned by the asm body
+def A_STATE(ct, i): return 32 * ct + 4 * i           # a[..+3]
+def A_YO(ct, ti): return 160 + 16 * ct + 4 * ti
+def A_RING(k): return 240 + 4 * (k % 4)
+
+V0 = 86
+_v = [V0]
+def valloc(n):
+    b = _v[0]
+    assert n == 1 or b % 2 == 0
+    _v[0] += n
+    return b
+SB = [[valloc(4) for ct in range(PT)] for b in range(2)]
+XW = [[valloc(4) for ks in range(2)] for ct in range(PT)]
+CBV = [valloc(4) for f in range(6)]
+WQ = [[valloc(4) for h in range(2)] for ks in range(2)]
+EV = [valloc(2) for ti in range(4)]
+CA = [valloc(1) for q in range(4)]
+BA = [valloc(1) for m in range(4)]
+XT = valloc(1)
+XV = valloc(1)
+XRP = [valloc(4) for k in range(2)]       # epilogue: x of two tiles, two sets
+T8 = [valloc(8) for k in range(1)][0]     # accumulator reads (snap / epilogue)
+U8 = valloc(8)                            # unpacked halves
+OUT = [valloc(4) for k in range(2)]
+assert _v[0] == 256, _v[0]
+
+S_M0, S_CP, S_Y, S_D, S_T = 80, 82, 84, 86, 88      # s80 saved m0, s[82:83] copy base, s[84:85] y rows, s[86:87] D, s[88:89] temp
+
+FLAG_REBASE, FLAG_RESET, FLAG_STD, FLAG_COPY = 0, 1, 2, 3
+
+
+def vr(b, n=1): return f"v{b}" if n == 1 else f"v[{b}:{b + n - 1}]"
+def ar(b, n=1): return f"a{b}" if n == 1 else f"a[{b}:{b + n - 1}]"
+def regs(p, b, n=1): return [f"{p}{b + i}" for i in range(n)]
+
+
+class Op:
+    def __init__(self, text, kind, r=(), w=(), lds_def=None, lds_use=(), vm_def=None, vm_use=(), cost=None, glue=False):
+        self.text, self.kind, self.r, self.w = text, kind, list(r), list(w)
+        self.lds_def, self.lds_use, self.vm_def, self.vm_use = lds_def, list(lds_use), vm_def, list(vm_use)
+        self.glue = glue
+        self.cost = cost if cost is not None else {"mfma": 8, "valu": 4, "lds": 4, "vmem": 8, "salu": 1, "dma": 8}.get(kind, 1)
+
+
+# required wait states between a producer of a register and a consumer
+def need_states(pk, ck, is_write):
+    if pk == "mfma":
+        if ck == "mfmaC": return 0             # whole accumulate chain
+        return 19                              # any other reader / writer of an MFMA result (covers 16-pass)
+    if pk == "valu":
+        if ck in ("mfma", "mfmaC"): return 2
+        if ck == "perm": return 2
+        return 0
+    if pk == "storedata" and is_write: return 2
+    return 0
+
+
+class Emitter:
+    def __init__(self):
+        self.lines = []
+        self.pos = 0
+        self.wr = {}            # reg -> (pos, kind) of the last write
+        self.rd_store = {}      # reg -> pos of a store reading it
+        self.lds_seq, self.lds_done, self.lds_idx = 0, 0, {}
+        self.vm_seq, self.vm_done, self.vm_idx = 0, 0, {}
+        self.vm_guarded = False
+        self.stats = {}
+
+    def raw(self, text, states=1):
+        self.lines.append(text)
+        self.pos += states
+
+    def nop(self, n):
+        while n > 0:
+            k = min(n, 16)
+            self.raw(f"s_nop {k - 1}", k)
+            self.stats["nop"] = self.stats.get("nop", 0) + k
+            n -= k
+
+    def emit(self, op):
+        # memory waits
+        for t in op.lds_use:
+            i = self.lds_idx[t]
+            if self.lds_done <= i:
+                n = min(self.lds_seq - 1 - i, 15)
+                self.raw(f"s_waitcnt lgkmcnt({n})")
+                self.lds_done = self.lds_seq - n
+        for t in op.vm_use:
+            i = self.vm_idx[t]
+            if self.vm_done <= i:
+                n = min(self.vm_seq - 1 - i, 63)
+                if n > 0 and not self.vm_guarded:
+                    # the counts assume the copies of chunk c + 1 were issued; without them (FLAG_COPY clear) wait for everything
+                    self.raw(f"s_bitcmp1_b32 %[flags], {FLAG_COPY}")
+                    self.raw("s_cbranch_scc1 .Lhs_cbw_%=")
+                    self.raw("s_waitcnt vmcnt(0)")
+                    self.raw(".Lhs_cbw_%=:", 0)
+                    self.vm_guarded = True
+                self.raw(f"s_waitcnt vmcnt({n})")
+                self.vm_done = self.vm_seq - n
+        # wait states
+        need = 0
+        ck = op.kind
+        for reg in op.r:
+            if reg in self.wr:
+                p, pk = self.wr[reg]
+                c = ck
+                if ck == "mfma" and reg in op.w: c = "mfmaC"
+                need = max(need, p + need_states(pk, c, False) + 1 - self.pos)
+        for reg in op.w:
+            if reg in self.wr and not (ck == "mfma" and reg in op.r):
+                p, pk = self.wr[reg]
+                if pk == "mfma": need = max(need, p + 19 + 1 - self.pos)
+            if reg in self.rd_store:
+                need = max(need, self.rd_store[reg] + 2 + 1 - self.pos)
+        if need > 0: self.nop(need)
+        self.lines.append(op.text)
+        kind_w = {"mfma": "mfma", "valu": "valu", "perm": "valu"}.get(ck, "other")
+        for reg in op.w: self.wr[reg] = (self.pos, kind_w)
+        if ck == "store":
+            for reg in op.r: self.rd_store[reg] = self.pos
+        self.pos += 1
+        if op.lds_def is not None or ck in ("lds",):
+            if op.lds_def is not None: self.lds_idx[op.lds_def] = self.lds_seq
+            self.lds_seq += 1
+        if op.vm_def is not None or ck in ("vmem", "dma", "store"):
+            if op.vm_def is not None: self.vm_idx[op.vm_def] = self.vm_seq
+            self.vm_seq += 1
+        self.stats[ck] = self.stats.get(ck, 0) + 1
+
+    def drain_lds(self):
+        if self.lds_done < self.lds_seq:
+            self.raw("s_waitcnt lgkmcnt(0)")
+            self.lds_done = self.lds_seq
+
+
+STAMPS = False
+NOSTORE = False  # timing experiment: no y stores
+PK = True        # packed f32 multiplies / FMAs (False: scalar ones)
+def stamp(em, k):
+    """debug builds: cycles since the previous stamp are added to accumulator k (s_memtime; drains the LDS queue)"""
+    if not STAMPS: return
+    em.raw("s_memtime s[90:91]")
+    em.raw("s_waitcnt lgkmcnt(0)")
+    em.lds_done = em.lds_seq
+    em.raw("s_sub_u32 s92, s90, %[stl]")
+    em.raw(f"s_add_u32 %[st{k}], %[st{k}], s92")
+    em.raw("s_mov_b32 %[stl], s90")
+
+# offsets of HeadVec's fields (bytes)
+VEC_CS, VEC_DTV, VEC_UT, VEC_WTS, VEC_WTD, VEC_ECS, VEC_WS, VEC_ONE = 0, 256, 512, 768, 1024, 1536, 1792, 2304
+N_VM_BEFORE_STD = 7 + 19         # C.B^T, dt, the copies: all issued before the block
+
+
+def gen_std_block(em):
+    """Standard step (a chunk that decays by more than 2^-199: no single frame holds its weights), between Yoff and
+    Ydiag, as in ssd_head.hip's `ustd_step`: (1) the accumulators get their row factor 2^(cs_t + E) now; (2) the
+    per-head mask M = CB .* 2^(cs_t - cs_s) dt_s [s <= t] replaces C.B^T in its registers (diagonal 16x16 blocks one
+    exponential per element, the others separable around the first token of their t-tile: ut[t] ws[s]).  x~ of such a
+    step is x itself (weights 1), the epilogue's row factors are 1."""
+    assert em.vm_seq == N_VM_BEFORE_STD, em.vm_seq
+    em.raw(f"s_bitcmp1_b32 %[flags], {FLAG_STD}")
+    em.raw("s_cbranch_scc0 .Lhs_nostd_%=")
+    sub = Emitter()
+    sub.pos = 100
+    R = sub.raw
+    E_D, E_S = T8, U8
+    CV, DV = XRP[0], XRP[1]
+    CST, UU, TA, TB = OUT[0], OUT[0] + 1, OUT[0] + 2, OUT[0] + 3
+    UN = OUT[1]
+    R("s_nop 15")
+    R("s_nop 3")                                    # the last Yoff MFMAs have written their tiles
+    # (1) row factors
+    for ti in range(4):
+        sub.emit(Op(f"ds_read_b32 {vr(UU)}, %[alc] offset:{VEC_ECS + 64 * ti}", "lds", w=regs("v", UU), lds_def=f"sev{ti}"))
+        for ct in range(PT):
+            y = A_YO(ct, ti)
+            for r in range(4): sub.emit(Op(f"v_accvgpr_read_b32 {vr(T8 + r)}, {ar(y + r)}", "valu", w=regs("v", T8 + r)))
+            for r in range(4): sub.emit(Op(f"v_mul_f32 {vr(T8 + r)}, {vr(UU)}, {vr(T8 + r)}", "valu", r=regs("v", T8 + r) + regs("v", UU), w=regs("v", T8 + r),
+                                           lds_use=[f"sev{ti}"]))
+            for r in range(4): sub.emit(Op(f"v_accvgpr_write_b32 {ar(y + r)}, {vr(T8 + r)}", "valu", r=regs("v", T8 + r)))
+        sub.drain_lds()
+    # (2) the mask.  s[88:89] = lanes 32..63 (hi = kq >> 1)
+    R("s_mov_b32 s88, 0")
+    R("s_mov_b32 s89, -1")
+    R(f"s_bitcmp1_b32 %[flags], {FLAG_COPY}")
+    R("s_cbranch_scc1 .Lhs_stdw_%=")
+    R("s_waitcnt vmcnt(0)")
+    R(".Lhs_stdw_%=:", 0)
+    R(f"s_waitcnt vmcnt({N_VM_BEFORE_STD - 6})")      # C.B^T has landed (dt and the copies may stay in flight)
+    tagn = [0]
+
+    def diag(t_off, s_off, e):
+        """e[j] = 2^(cs_t - cs_(s0 + j)) dt_(s0 + j) for s0 + j <= t, else 0;  t = t_off + 16 hi + lc, s0 = s_off + 8 kq"""
+        tagn[0] += 1
+        tg = f"d{tagn[0]}"
+        sub.emit(Op(f"ds_read_b32 {vr(CST)}, %[at] offset:{VEC_CS + 4 * t_off}", "lds", w=regs("v", CST), lds_def=tg + "c"))
+        for hh in range(2):
+            sub.emit(Op(f"ds_read_b128 {vr(CV, 4)}, %[as] offset:{VEC_CS + 4 * s_off + 16 * hh}", "lds", w=regs("v", CV, 4), lds_def=tg + f"v{hh}"))
+            sub.emit(Op(f"ds_read_b128 {vr(DV, 4)}, %[as] offset:{VEC_DTV + 4 * s_off + 16 * hh}", "lds", w=regs("v", DV, 4), lds_def=tg + f"w{hh}"))
+            for j in range(4):
+                d = e + 4 * hh + j
+                sub.emit(Op(f"v_sub_f32 {vr(d)}, {vr(CST)}, {vr(CV + j)}", "valu", r=regs("v", CST) + regs("v", CV + j), w=regs("v", d),
+                            lds_use=[tg + "c", tg + f"v{hh}"]))
+                sub.emit(Op(f"v_cmp_ge_i32 vcc, %[d0], {4 * hh + j}", "valu"))
+                sub.emit(Op("s_nop 1", "salu"))
+                sub.emit(Op(f"v_cndmask_b32 {vr(d)}, {vr(TA)}, {vr(d)}, vcc", "valu", r=regs("v", d) + regs("v", TA), w=regs("v", d)))
+                sub.emit(Op(f"v_exp_f32 {vr(d)}, {vr(d)}", "valu", r=regs("v", d), w=regs("v", d)))
+                sub.emit(Op("s_nop 0", "salu"))
+                sub.emit(Op(f"v_mul_f32 {vr(d)}, {vr(d)}, {vr(DV + j)}", "valu", r=regs("v", d) + regs("v", DV + j), w=regs("v", d), lds_use=[tg + f"w{hh}"]))
+            sub.drain_lds()
+
+    def sepf(t_off, w_operand, w_off, e):
+        """e[j] = ut[t_off + lc] ws[w_off + j]"""
+        tagn[0] += 1
+        tg = f"s{tagn[0]}"
+        sub.emit(Op(f"ds_read_b32 {vr(UU)}, %[alc] offset:{VEC_UT + 4 * t_off}", "lds", w=regs("v", UU), lds_def=tg + "u"))
+        for hh in range(2):
+            sub.emit(Op(f"ds_read_b128 {vr(CV, 4)}, %[{w_operand}] offset:{VEC_WS + 4 * w_off + 16 * hh}", "lds", w=regs("v", CV, 4), lds_def=tg + f"v{hh}"))
+            for j in range(4):
+                d = e + 4 * hh + j
+                sub.emit(Op(f"v_mul_f32 {vr(d)}, {vr(UU)}, {vr(CV + j)}", "valu", r=regs("v", UU) + regs("v", CV + j), w=regs("v", d), lds_use=[tg + "u", tg + f"v{hh}"]))
+            sub.drain_lds()
+
+    def select(e_lo, e_hi, dst):
+        """dst[j] = hi ? e_hi[j] : e_lo[j]   (None = 0)"""
+        for j in range(8):
+            lo = "0" if e_lo is None else vr(e_lo + j)
+            hi_ = "0" if e_hi is None else vr(e_hi + j)
+            if e_lo is None:
+                sub.emit(Op(f"v_cndmask_b32 {vr(dst + j)}, 0, {hi_}, s[88:89]", "valu", w=regs("v", dst + j)))
+            elif e_hi is None:
+                sub.emit(Op(f"v_cndmask_b32 {vr(dst + j)}, {lo}, {vr(TB)}, s[88:89]", "valu", w=regs("v", dst + j)))
+            else:
+                sub.emit(Op(f"v_cndmask_b32 {vr(dst + j)}, {lo}, {hi_}, s[88:89]", "valu", w=regs("v", dst + j)))
+
+    def apply(f, fac):
+        """cbv[f] <- bf16(CB_f .* fac)"""
+        for jp in range(4):
+            c = CBV[f] + jp
+            sub.emit(Op(f"v_lshlrev_b32 {vr(UN)}, 16, {vr(c)}", "valu", r=regs("v", c), w=regs("v", UN)))
+            sub.emit(Op(f"v_and_b32 {vr(UN + 1)}, 0xffff0000, {vr(c)}", "valu", r=regs("v", c), w=regs("v", UN + 1)))
+            sub.emit(Op(f"v_mul_f32 {vr(UN)}, {vr(UN)}, {vr(fac + 2 * jp)}", "valu", r=regs("v", UN) + regs("v", fac + 2 * jp), w=regs("v", UN)))
+            sub.emit(Op(f"v_mul_f32 {vr(UN + 1)}, {vr(UN + 1)}, {vr(fac + 2 * jp + 1)}", "valu", r=regs("v", UN + 1) + regs("v", fac + 2 * jp + 1), w=regs("v", UN + 1)))
+            sub.emit(Op(f"v_cvt_pk_bf16_f32 {vr(c)}, {vr(UN)}, {vr(UN + 1)}", "valu", r=regs("v", UN, 2), w=regs("v", c)))
+
+    R(f"v_mov_b32 {vr(TA)}, 0xff800000")           # -inf
+    R(f"v_mov_b32 {vr(TB)}, 0")
+    diag(0, 0, E_D)                                 # diagonal blocks of fragments (0,0) [hi = 0] and (1,0) [hi = 1]
+    select(E_D, None, E_S)
+    apply(0, E_S)
+    sepf(16, "as15", 0, E_S)                        # block (1,0)
+    select(E_S, E_D, E_S)
+    apply(1, E_S)
+    sepf(32, "as", 16, E_S)                         # blocks (2,0), (2,1)
+    apply(2, E_S)
+    diag(32, 32, E_D)                               # diagonal blocks of fragments (2,1) [hi = 0] and (3,1) [hi = 1]
+    select(E_D, None, E_S)
+    apply(3, E_S)
+    sepf(48, "as", 48, E_S)                         # blocks (3,0), (3,1)
+    apply(4, E_S)
+    sepf(48, "as15", 80, E_S)                       # block (3,2)
+    select(E_S, E_D, E_S)
+    apply(5, E_S)
+    R("s_nop 1")
+    sub.drain_lds()
+    em.lines += sub.lines
+    em.raw(".Lhs_nostd_%=:", 0)
+    for f in range(6):
+        for r in regs("v", CBV[f], 4): em.wr[r] = (em.pos, "valu")
+    for t in (T8, U8, XRP[0], XRP[1], OUT[0], OUT[1]):
+        pass
+    em.vm_done = max(em.vm_done, 0)
+
+
+class Task:
+    def __init__(self, name, ops, after=-1, deadline=10 ** 9, prio=None):
+        self.name, self.ops, self.after, self.deadline = name, list(ops), after, deadline
+        self.prio = deadline if prio is None else prio
+
+
+# ---------------------------------------------------------------- building blocks
+def mfma(dst, a, b, c, a_is_acc=False, b_is_acc=False):
+    """dst/c accumulator tile (base AGPR; c None = 0); a, b operand bases (VGPR unless flagged)"""
+    at = ar(a, 4) if a_is_acc else vr(a, 4)
+    bt = ar(b, 4) if b_is_acc else vr(b, 4)
+    ct = "0" if c is None else ar(c, 4)
+    r = regs("a" if a_is_acc else "v", a, 4) + regs("a" if b_is_acc else "v", b, 4) + ([] if c is None else regs("a", c, 4))
+    return Op(f"v_mfma_f32_16x16x32_bf16 {ar(dst, 4)}, {at}, {bt}, {ct}", "mfma", r=r, w=regs("a", dst, 4))
+
+
+def snap_ops(q, ct, dst, tmp):
+    """bf16 copy of state rows 32 q + 8 kq + 0..7 of column tile ct (state tiles 2q, 2q + 1) -> v[dst:dst+3]"""
+    ops = []
+    for ii in range(2):
+        s = A_STATE(ct, 2 * q + ii)
+        for r in range(4):
+            ops.append(Op(f"v_accvgpr_read_b32 {vr(tmp + 4 * ii + r)}, {ar(s + r)}", "valu", r=regs("a", s + r), w=regs("v", tmp + 4 * ii + r)))
+    for ii in range(2):
+        for h in range(2):
+            t = tmp + 4 * ii + 2 * h
+            ops.append(Op(f"v_cvt_pk_bf16_f32 {vr(dst + 2 * ii + h)}, {vr(t)}, {vr(t + 1)}", "valu", r=regs("v", t, 2), w=regs("v", dst + 2 * ii + h)))
+    return ops
+
+
+def xw_read_ops(ct, ks, tag):
+    d = XW[ct][ks]
+    off = 32 * ct + ks * 32 * XROW
+    return [Op(f"ds_read_b64_tr_b16 {vr(d, 2)}, {vr(XT)} offset:{off}", "lds", r=regs("v", XT), w=regs("v", d, 2), lds_def=f"{tag}{ct}{ks}a"),
+            Op(f"ds_read_b64_tr_b16 {vr(d + 2, 2)}, {vr(XT)} offset:{off + 4 * XROW}", "lds", r=regs("v", XT), w=regs("v", d + 2, 2), lds_def=f"{tag}{ct}{ks}b")]
+
+
+def xw_comp_ops(ct, ks, tag, wtag):
+    """x~ = w_s x on fragment (ct, ks) in place: element pair e of the fragment times wq[ks][e >> 1][2 (e & 1) ..]"""
+    d = XW[ct][ks]
+    ops = []
+    for e in range(4):
+        t = U8 + 2 * (e & 1) + 4 * (ks & 1)
+        w = WQ[ks][e >> 1] + 2 * (e & 1)
+        use = [f"{tag}{ct}{ks}{'a' if e < 2 else 'b'}"]
+        ops.append(Op(f"v_lshlrev_b32 {vr(t)}, 16, {vr(d + e)}", "valu", r=regs("v", d + e), w=regs("v", t), lds_use=use))
+        ops.append(Op(f"v_and_b32 {vr(t + 1)}, 0xffff0000, {vr(d + e)}", "valu", r=regs("v", d + e), w=regs("v", t + 1)))
+        if PK:
+            ops.append(Op(f"v_pk_mul_f32 {vr(t, 2)}, {vr(w, 2)}, {vr(t, 2)}", "valu", r=regs("v", t, 2) + regs("v", w, 2), w=regs("v", t, 2),
+                          lds_use=[f"{wtag}{ks}{e >> 1}"]))
+        else:
+            for k in range(2):
+                ops.append(Op(f"v_mul_f32 {vr(t + k)}, {vr(w + k)}, {vr(t + k)}", "valu", r=regs("v", t + k) + regs("v", w + k), w=regs("v", t + k),
+                              lds_use=[f"{wtag}{ks}{e >> 1}"]))
+        ops.append(Op(f"v_cvt_pk_bf16_f32 {vr(d + e)}, {vr(t)}, {vr(t + 1)}", "valu", r=regs("v", t, 2), w=regs("v", d + e)))
+    return ops
+
+
+def wq_read_ops(vw_operand, wtag):
+    ops = []
+    for ks in range(2):
+        for h in range(2):
+            ops.append(Op(f"ds_read_b128 {vr(WQ[ks][h], 4)}, %[{vw_operand}] offset:{(32 * ks + 4 * h) * 4}", "lds", w=regs("v", WQ[ks][h], 4),
+                          lds_def=f"{wtag}{ks}{h}"))
+    return ops
+
+
+def copy_group_ops(name, base_operand, add_operand, m0_expr_ops, voffs, ioffs):
+    """one M0 set-up + up to four LDS-DMA pieces, skipped as a whole when FLAG_COPY is clear"""
+    ops = [Op(f"s_bitcmp1_b32 %[flags], {FLAG_COPY}", "salu"),
+           Op(f"s_cbranch_scc0 .Lhs_{name}_%=", "salu")]
+    ops.append(Op(f"s_mov_b64 s[{S_CP}:{S_CP + 1}], %[{base_operand}]", "salu", w=[f"s{S_CP}", f"s{S_CP + 1}"]))
+    for k in range(add_operand[1]):
+        ops.append(Op(f"s_add_u32 s{S_CP}, s{S_CP}, %[{add_operand[0]}]", "salu"))
+        ops.append(Op(f"s_addc_u32 s{S_CP + 1}, s{S_CP + 1}, 0", "salu"))
+    ops += m0_expr_ops
+    ops.append(Op("s_nop 0", "salu"))
+    for v, io in zip(voffs, ioffs):
+        ops.append(Op(f"global_load_lds_dwordx4 %[{v}], s[{S_CP}:{S_CP + 1}]" + (f" offset:{io}" if io else ""), "dma"))
+    ops.append(Op(f".Lhs_{name}_%=:", "label", cost=0))
+    for o in ops[:-1]: o.glue = True
+    return ops
+
+
+def epi_tile_ops(ct, ti, xr, acc_t, unp, out, xtag):
+    """the lane's 8 bytes of y of tile (ct, ti): out[0:1] = bf16(yo * ev + D x)"""
+    y = A_YO(ct, ti)
+    ops = []
+    for r in range(4):
+        ops.append(Op(f"v_accvgpr_read_b32 {vr(acc_t + r)}, {ar(y + r)}", "valu", r=regs("a", y + r), w=regs("v", acc_t + r)))
+    for h in range(2):
+        ops.append(Op(f"v_lshlrev_b32 {vr(unp + 2 * h)}, 16, {vr(xr + h)}", "valu", r=regs("v", xr + h), w=regs("v", unp + 2 * h), lds_use=[xtag]))
+        ops.append(Op(f"v_and_b32 {vr(unp + 2 * h + 1)}, 0xffff0000, {vr(xr + h)}", "valu", r=regs("v", xr + h), w=regs("v", unp + 2 * h + 1)))
+    if PK:
+        for h in range(2):
+            ops.append(Op(f"v_pk_mul_f32 {vr(unp + 2 * h, 2)}, s[{S_D}:{S_D + 1}], {vr(unp + 2 * h, 2)}", "valu", r=regs("v", unp + 2 * h, 2), w=regs("v", unp + 2 * h, 2)))
+        for h in range(2):
+            ops.append(Op(f"v_pk_fma_f32 {vr(acc_t + 2 * h, 2)}, {vr(acc_t + 2 * h, 2)}, {vr(EV[ti], 2)}, {vr(unp + 2 * h, 2)} op_sel_hi:[1,0,1]", "valu",
+                          r=regs("v", acc_t + 2 * h, 2) + regs("v", EV[ti]) + regs("v", unp + 2 * h, 2), w=regs("v", acc_t + 2 * h, 2), lds_use=[f"ev{ti}"]))
+    else:
+        for k in range(4):
+            ops.append(Op(f"v_mul_f32 {vr(unp + k)}, s{S_D}, {vr(unp + k)}", "valu", r=regs("v", unp + k), w=regs("v", unp + k)))
+        for k in range(4):
+            ops.append(Op(f"v_fma_f32 {vr(acc_t + k)}, {vr(acc_t + k)}, {vr(EV[ti])}, {vr(unp + k)}", "valu",
+                          r=regs("v", acc_t + k) + regs("v", EV[ti]) + regs("v", unp + k), w=regs("v", acc_t + k), lds_use=[f"ev{ti}"]))
+    for h in range(2):
+        ops.append(Op(f"v_cvt_pk_bf16_f32 {vr(out + h)}, {vr(acc_t + 2 * h)}, {vr(acc_t + 2 * h + 1)}", "valu", r=regs("v", acc_t + 2 * h, 2), w=regs("v", out + h)))
+    return ops
+
+
+def epi_xread_ops(ct, tp, xr, tagbase):
+    ops = []
+    for k in range(2):
+        ti = tp + k
+        ops.append(Op(f"ds_read_b64 {vr(xr + 2 * k, 2)}, {vr(XV)} offset:{32 * ct + ti * 16 * XROW}", "lds", r=regs("v", XV), w=regs("v", xr + 2 * k, 2),
+                      lds_def=f"{tagbase}{ct}{ti}"))
+    return ops
+
+
+# ---------------------------------------------------------------- scheduler
+def schedule(em, mfmas, tasks, budget, first_index=0, stamps=None, blocks=None):
+    """emit MFMAs in order; behind each one, filler ops of the tasks that may run (after < index) by earliest
+    deadline, up to `budget` cycles; tasks due before an MFMA are completed in front of it"""
+    tasks = list(tasks)
+    cur = None
+    for k, m in enumerate(mfmas):
+        idx = first_index + k
+        # complete what is due
+        while True:
+            due = [t for t in tasks if t.deadline <= idx and t.ops]
+            if cur is not None and cur.ops and cur.deadline <= idx and cur not in due: due.append(cur)
+            if not due: break
+            t = min(due, key=lambda t: t.prio)
+            assert t.after < idx, (t.name, t.after, idx)
+            while t.ops: em.emit(t.ops.pop(0))
+        if blocks and idx in blocks:
+            while cur is not None and cur.ops: em.emit(cur.ops.pop(0))
+            blocks[idx](em)
+        if stamps and idx in stamps: stamp(em, stamps[idx])
+        em.emit(m)
+        left = budget
+        glued = False
+        while left > 0 or glued:
+            if cur is None or not cur.ops:
+                ready = [t for t in tasks if t.ops and t.after < idx + 1]
+                if not ready: break
+                cur = min(ready, key=lambda t: t.prio)
+            op = cur.ops.pop(0)
+            em.emit(op)
+            left -= op.cost
+            glued = op.glue and bool(cur.ops)
+    # whatever is left
+    last = first_index + len(mfmas)
+    for t in sorted(tasks, key=lambda t: t.prio):
+        while t.ops:
+            assert t.after < last, (t.name, t.after)
+            em.emit(t.ops.pop(0))
+
+
+def gen_rebase(em):
+    """X' *= 2^sh (sh a negative integer in an SGPR): out of and back into the accumulation registers"""
+    em.raw(f"s_bitcmp1_b32 %[flags], {FLAG_REBASE}")
+    em.raw("s_cbranch_scc0 .Lhs_norebase_%=")
+    for b in range(0, 160, 8):
+        for k in range(8): em.raw(f"v_accvgpr_read_b32 {vr(T8 + k)}, {ar(b + k)}")
+        for k in range(8): em.raw(f"v_ldexp_f32 {vr(T8 + k)}, {vr(T8 + k)}, %[sh]")
+        for k in range(8): em.raw(f"v_accvgpr_write_b32 {ar(b + k)}, {vr(T8 + k)}")
+    em.raw("s_nop 1")
+    em.raw(".Lhs_norebase_%=:", 0)
+
+
+def gen_step():
+    em = Emitter()
+    em.raw("s_nop 4", 5)
+    stamp(em, 0)
+    em.raw(f"s_mov_b32 s{S_M0}, m0")
+    em.raw(f"s_mov_b32 s{S_D}, %[dh]")
+    em.raw(f"s_mov_b32 s{S_D + 1}, %[dh]")
+    gen_rebase(em)
+
+    # ---------------- preamble
+    for q in range(4): em.emit(Op(f"v_add_u32 {vr(CA[q])}, %[sbc], %[ca{q}]", "valu", w=regs("v", CA[q])))
+    em.emit(Op(f"v_add_u32 {vr(XT)}, %[sxs], %[xtr]", "valu", w=regs("v", XT)))
+    em.emit(Op(f"v_add_u32 {vr(XV)}, %[sxs], %[xvr]", "valu", w=regs("v", XV)))
+    for op in wq_read_ops("vw", "wq"): em.emit(op)
+    for k in range(4):       # C fragments of quarter 0
+        em.emit(Op(f"ds_read_b128 {ar(A_RING(k), 4)}, {vr(CA[0])} offset:{k * 4096}", "lds", r=regs("v", CA[0]), w=regs("a", A_RING(k), 4), lds_def=f"c{k}"))
+    for op in xw_read_ops(0, 0, "x"): em.emit(op)
+    for f in range(6):       # causal C.B^T of this chunk (the pointer is 2 KiB into the chunk's 6 KiB: 13-bit signed offsets)
+        em.emit(Op(f"global_load_dwordx4 {vr(CBV[f], 4)}, %[cbo], %[pcb] offset:{f * 1024 - 2048}", "vmem", w=regs("v", CBV[f], 4), vm_def=f"cb{f}"))
+    em.emit(Op("global_load_ushort %[dtout], %[dto], %[pdt]", "vmem", vm_def="dt"))
+    for ct in range(PT):
+        for op in snap_ops(0, ct, SB[0][ct], T8): em.emit(op)
+
+    stamp(em, 1)
+    # ---------------- phase A: Yoff (80 MFMAs), Ydiag (30)
+    mf = []
+    for q in range(4):
+        for ti in range(4):
+            for ct in range(PT):
+                mf.append(mfma(A_YO(ct, ti), SB[q & 1][ct], A_RING(4 * q + ti), None if q == 0 else A_YO(ct, ti), b_is_acc=True))
+                mf[-1].lds_use = [f"c{4 * q + ti}"]
+    ydiag = [(0, 0, 0), (1, 0, 1), (2, 0, 2), (3, 0, 4), (2, 1, 3), (3, 1, 5)]        # (ti, ks, fragment)
+    for ti, ks, f in ydiag:
+        for ct in range(PT):
+            m = mfma(A_YO(ct, ti), XW[ct][ks], CBV[f], A_YO(ct, ti))
+            m.vm_use = [f"cb{f}"]
+            mf.append(m)
+    tasks = []
+    for k in range(4, 16):       # C fragments of quarters 1..3 through the ring
+        q, ti = k // 4, k % 4
+        tasks.append(Task(f"c{k}", [Op(f"ds_read_b128 {ar(A_RING(k), 4)}, {vr(CA[q])} offset:{ti * 4096}", "lds", r=regs("v", CA[q]),
+                                       w=regs("a", A_RING(k), 4), lds_def=f"c{k}")], after=(k - 4) * 5 + 4, deadline=k * 5 - 6, prio=k * 5 - 40))
+    for q in range(1, 4):
+        for ct in range(PT):
+            after = -1 if q == 1 else (q - 2) * 20 + 15 + ct
+            tasks.append(Task(f"snap{q}{ct}", snap_ops(q, ct, SB[q & 1][ct], T8), after=after, deadline=q * 20 + ct, prio=q * 20 + ct - 2))
+    order = [(ct, 0) for ct in range(PT)] + [(ct, 1) for ct in range(PT)]
+    for n, (ct, ks) in enumerate(order):
+        ops = []
+        if n + 1 < len(order): ops += xw_read_ops(order[n + 1][0], order[n + 1][1], "x")
+        ops += xw_comp_ops(ct, ks, "x", "wq")
+        tasks.append(Task(f"xw{ct}{ks}", ops, after=-1, deadline=80 + (0 if ks == 0 else 20) + ct, prio=8 * n + 3))
+    # copies of chunk c + 1 (B, C, three groups of x)
+    m0b = [Op("s_mov_b32 m0, %[lb]", "salu")]
+    m0c = [Op("s_mov_b32 m0, %[lc]", "salu")]
+    tasks.append(Task("cpB", copy_group_ops("cpb", "pb", ("z", 0), m0b, ["ob0", "ob1", "ob2", "ob3"], [0, 1024, 2048, 3072]), after=4, deadline=100, prio=10))
+    tasks.append(Task("cpC", copy_group_ops("cpc", "pc", ("z", 0), m0c, ["oc0", "oc1", "oc2", "oc3"], [0, 1024, 2048, 3072]), after=18, deadline=100, prio=24))
+    for g in range(3):
+        n = min(4, NXI - 4 * g)
+        vo = ["ox0", "ox1", "ox2", "ox3"][:n]
+        if 4 * g + n == NXI: vo[-1] = "oxl"
+        m0x = [Op(f"s_add_u32 m0, %[lx], {RPI * 4 * g * XROW}" if g else "s_mov_b32 m0, %[lx]", "salu")]
+        tasks.append(Task(f"cpX{g}", copy_group_ops(f"cpx{g}", "px", ("xg4", g), m0x, vo, [j * RPI * XROW for j in range(n)]),
+                          after=32 + 14 * g, deadline=100, prio=38 + 14 * g))
+    # phase B operands that may already be fetched: addresses, ev, the first B fragments (ring slots free after the last C use)
+    pre_b = [Op(f"v_add_u32 {vr(BA[m])}, %[sbc], %[ba{m}]", "valu", w=regs("v", BA[m])) for m in range(4)]
+    pre_b += [Op(f"ds_read_b32 {vr(EV[ti])}, %[vev] offset:{64 * ti}", "lds", w=regs("v", EV[ti]), lds_def=f"ev{ti}") for ti in range(4)]
+    tasks.append(Task("preB", pre_b, after=70, deadline=108, prio=95))
+
+    def b_read_ops(m):
+        i, ks = m // 2, m % 2
+        base = BA[i // 2]
+        off = (i & 1) * 8 + ks * 8192
+        d = A_RING(m)
+        return [Op(f"ds_read_b64_tr_b16 {ar(d, 2)}, {vr(base)} offset:{off}", "lds", r=regs("v", base), w=regs("a", d, 2), lds_def=f"b{m}a"),
+                Op(f"ds_read_b64_tr_b16 {ar(d + 2, 2)}, {vr(base)} offset:{off + 1024}", "lds", r=regs("v", base), w=regs("a", d + 2, 2), lds_def=f"b{m}b")]
+    for m in range(4):
+        tasks.append(Task(f"b{m}", b_read_ops(m), after=(12 + m) * 5 + 4, deadline=110 + m * 5 - 4, prio=100 + m))
+    va = sum(op.cost for t in tasks for op in t.ops)
+    schedule(em, mf, tasks, budget=va / len(mf) + 1.0, stamps={20: 2, 40: 3, 60: 4, 80: 5}, blocks={80: gen_std_block})
+    stamp(em, 6)
+
+    # ---------------- reset steps: x~ again with the new frame's weights (the state update builds the new state)
+    em.raw(f"s_bitcmp1_b32 %[flags], {FLAG_RESET}")
+    em.raw("s_cbranch_scc0 .Lhs_noreset_%=")
+    sub = Emitter()
+    sub.pos = 100
+    for op in wq_read_ops("vw2", "wr"): sub.emit(op)
+    for ct in range(PT):
+        for ks in range(2):
+            for op in xw_read_ops(ct, ks, "r"): sub.emit(op)
+    for ct in range(PT):
+        for ks in range(2):
+            for op in xw_comp_ops(ct, ks, "r", "wr"): sub.emit(op)
+    sub.raw("s_nop 1")
+    sub.drain_lds()
+    em.lines += sub.lines
+    em.raw(".Lhs_noreset_%=:", 0)
+    stamp(em, 7)
+    for ct in range(PT):
+        for ks in range(2):
+            for r in regs("v", XW[ct][ks], 4): em.wr[r] = (em.pos, "valu")
+
+    # ---------------- phase B: state update (80 MFMAs) beside the y epilogue; two copies (reset: first k-step onto zero)
+    def phase_b(em, reset):
+        mf = []
+        for i in range(8):
+            for ks in range(2):
+                for ct in range(PT):
+                    m = mfma(A_STATE(ct, i), A_RING(2 * i + ks), XW[ct][ks], None if (reset and ks == 0) else A_STATE(ct, i), a_is_acc=True)
+                    m.lds_use = [f"b{2 * i + ks}a", f"b{2 * i + ks}b"]
+                    mf.append(m)
+        tasks = []
+        for m in range(4, 16):
+            tasks.append(Task(f"b{m}", b_read_ops(m), after=110 + (m - 4) * 5 + 4, deadline=110 + m * 5 - 6, prio=110 + m * 5 - 40))
+        seq = [(tp, ct) for tp in (0, 2) for ct in range(PT)]
+        pri = 200
+        for n, (tp, ct) in enumerate(seq):
+            ops = []
+            if n == 0: ops += epi_xread_ops(ct, tp, XRP[0], "ex")
+            if n + 1 < len(seq): ops += epi_xread_ops(seq[n + 1][1], seq[n + 1][0], XRP[(n + 1) & 1], "ex")
+            if ct == 0:
+                ops.append(Op(f"s_mov_b64 s[{S_Y}:{S_Y + 1}], %[py]", "salu"))
+                if tp == 2:
+                    ops.append(Op(f"s_add_u32 s{S_Y}, s{S_Y}, %[y32]", "salu"))
+                    ops.append(Op(f"s_addc_u32 s{S_Y + 1}, s{S_Y + 1}, 0", "salu"))
+            xr, out = XRP[n & 1], OUT[n & 1]
+            ops += epi_tile_ops(ct, tp, xr, T8, U8, out, f"ex{ct}{tp}")
+            ops += epi_tile_ops(ct, tp + 1, xr + 2, T8 + 4, U8 + 4, out + 2, f"ex{ct}{tp + 1}")
+            ops.append(Op(f"v_permlane16_swap_b32 {vr(out)}, {vr(out + 2)}", "perm", r=regs("v", out) + regs("v", out + 2), w=regs("v", out) + regs("v", out + 2)))
+            ops.append(Op(f"v_permlane16_swap_b32 {vr(out + 1)}, {vr(out + 3)}", "perm", r=regs("v", out + 1) + regs("v", out + 3), w=regs("v", out + 1) + regs("v", out + 3)))
+            ops.append(Op(f"s_mov_b64 exec, %[m{'01' if tp == 0 else '23'}]", "salu", glue=True))
+            ops.append(Op("s_nop 0", "salu", glue=True))
+            if not NOSTORE: ops.append(Op(f"global_store_dwordx4 %[yo16], {vr(out, 4)}, s[{S_Y}:{S_Y + 1}] offset:{32 * ct}", "store", r=regs("v", out, 4), glue=True))
+            ops.append(Op("s_mov_b64 exec, -1", "salu", glue=True))
+            ops.append(Op("s_nop 0", "salu"))
+            tasks.append(Task(f"epi{tp}{ct}", ops, after=111 if tp == 0 else 114, prio=pri))
+            pri += 1
+        va = sum(op.cost for t in tasks for op in t.ops)
+        schedule(em, mf, tasks, budget=va / len(mf) + 1.0, first_index=110, stamps={150: 8})
+        stamp(em, 9)
+
+    import copy
+    em.raw(f"s_bitcmp1_b32 %[flags], {FLAG_RESET}")
+    em.raw("s_cbranch_scc1 .Lhs_pb_reset_%=")
+    base_state = copy.deepcopy({k: v for k, v in em.__dict__.items() if k != "lines"})
+    phase_b(em, False)
+    em.raw("s_branch .Lhs_pb_join_%=")
+    end_state = {k: v for k, v in em.__dict__.items() if k != "lines"}
+    em2 = Emitter()
+    em2.__dict__.update(copy.deepcopy(base_state))
+    em2.lines = []
+    em2.raw(".Lhs_pb_reset_%=:", 0)
+    phase_b(em2, True)
+    em.lines += em2.lines
+    em.raw(".Lhs_pb_join_%=:", 0)
+    assert em2.vm_seq == em.vm_seq and em2.lds_seq == em.lds_seq
+
+    # ---------------- end: the copies of chunk c + 1 have landed (the y stores may stay in flight); without copies: everything
+    em.raw(f"s_bitcmp1_b32 %[flags], {FLAG_COPY}")
+    em.raw("s_cbranch_scc1 .Lhs_endw_%=")
+    em.raw("s_waitcnt vmcnt(0)")
+    em.raw(".Lhs_endw_%=:", 0)
+    em.raw(f"s_waitcnt vmcnt({0 if NOSTORE else 10}) lgkmcnt(0)")
+    stamp(em, 10)
+    em.raw(f"s_mov_b32 m0, s{S_M0}")
+    return em
+
+
+def clobbers():
+    c = ["memory", "vcc", "scc"]
+    c += [f"s{i}" for i in range(80, 94)]
+    c += [f"v{i}" for i in range(V0, 256)]
+    c += [f"a{i}" for i in range(256)]
+    return c
+
+
+def main():
+    global STAMPS
+    STAMPS = "--stamps" in sys.argv
+    global PK
+    PK = "--scalar" not in sys.argv
+    global NOSTORE
+    NOSTORE = "--nostore" in sys.argv
+    em = gen_step()
+    lines = em.lines
+    print("// generated by timeviper_amd/devtools/gen_head_step.py — do not edit")
+    print(f"// {sum(1 for l in lines if l.startswith('v_mfma'))} MFMA lines (phase B twice), {len(lines)} lines; emitter stats {em.stats}")
+    print("#define TV_HEAD_STEP_ASM \\")
+    for ln in lines:
+        print(f'  "{ln}\\n\\t" \\')
+    print('  ""')
+    print("#define TV_HEAD_STEP_CLOBBERS " + ", ".join(f'"{c}"' for c in clobbers()))
+    print(f"#define TV_HEAD_STEP_V0 {V0}")
+    # small statements of the kernel's prologue / epilogue (the state lives in a0 .. a159 between the steps)
+    print("#define TV_HEAD_STATE_ZERO \\")
+    for i in range(160): print(f'  "v_accvgpr_write_b32 a{i}, 0\\n\\t" \\')
+    print('  ""')
+    print("#define TV_HEAD_STATE_CLOBBERS " + ", ".join(f'"a{i}"' for i in range(160)))
+
+
+if __name__ == "__main__":
+    main()
