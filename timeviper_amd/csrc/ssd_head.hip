@@ -967,17 +967,18 @@ __global__ __launch_bounds__(256) void ssd_head_asm_kernel(HeadArgs a) {
                  ba3 = lds_bt + ((bsw ^ 192) + b_lo);
   const unsigned xtr = lds_xr + xr_lo, xvr = lds_xr + xv_lo;
   const unsigned vw_wts = lds_vec + (unsigned)offsetof(HeadVec, wts) + 32 * kq;
-  const unsigned vw_one = lds_vec + (unsigned)offsetof(HeadVecA, one) + 32 * kq;
   const unsigned vev_ecs = lds_vec + (unsigned)offsetof(HeadVec, ecs) + 4 * lc;
   const unsigned vev_one = lds_vec + (unsigned)offsetof(HeadVecA, one) + 4 * lc;
   // standard steps: the mask factors' addresses (token t = 16 (kq >> 1) + lc, columns s = 8 kq + j) and the diagonal test
   const unsigned sa_t = lds_vec + 4 * (16 * (kq >> 1) + lc), sa_s = lds_vec + 32 * kq, sa_lc = lds_vec + 4 * lc, sa_s15 = lds_vec + 32 * (kq & 1);
   const int sd0 = 16 * (kq >> 1) + lc - 8 * kq;
   const unsigned cbo = lane * 16, dto = lane * 2;
-  const unsigned yo16 = (unsigned)(((16 * (kq & 1) + lc) * a.ysl + 8 * (kq >> 1)) * 2);
+  const unsigned yst = (unsigned)(((lane / 10) * a.ysl + (lane % 10) * 8) * 2);      // row stores: lane = 16-byte piece of 6 rows of 160 bytes
+  const int lrow = lane / 10;
+  const unsigned xsr = lds_xr + 16 * lane;
   bf16_t* const ygs = a.y + (int64_t)b * a.ysb + (int64_t)t_first * a.ysl + (int64_t)h * P;
   const bf16_t* cbg = a.cb + (((int64_t)b * a.G + g) * a.nchunks + c_first) * CBE;
-  const unsigned y32 = (unsigned)(64 * a.ysl);
+  const unsigned y6 = (unsigned)(12 * a.ysl);      // bytes of 6 rows of y
 
   // ---- per-chunk vectors (the same decisions and arithmetic as ssd_head_kernel's prep)
   const float Ah = a.A[h];
@@ -987,6 +988,7 @@ __global__ __launch_bounds__(256) void ssd_head_asm_kernel(HeadArgs a) {
   float decay_total = 0.f;
   float E = 0.f;
   bool reset_next = false, std_next = false;
+  unsigned dead_next = 0;        // standard steps: bit ti = every row factor of t-tile ti has underflowed to zero
   auto prep = [&](int c, unsigned raw_bits, float& f_out) __attribute__((always_inline)) {
     const int t = c * HQ + lane;
     float d = 0.f;
@@ -1004,7 +1006,13 @@ __global__ __launch_bounds__(256) void ssd_head_asm_kernel(HeadArgs a) {
     f_out = mode == 1 ? -mshift : 1.f;
     vec.cs[lane] = cs2;
     vec.dtv[lane] = d;
-    vec.ecs[lane] = __builtin_amdgcn_exp2f(cs2 + Euse);
+    const float rowf = __builtin_amdgcn_exp2f(cs2 + Euse);
+    vec.ecs[lane] = rowf;
+    {
+      const unsigned long long nz = __builtin_amdgcn_ballot_w64(rowf != 0.f);
+      dead_next = ((nz & 0xffffull) == 0 ? 1u : 0u) | (((nz >> 16) & 0xffffull) == 0 ? 2u : 0u) | (((nz >> 32) & 0xffffull) == 0 ? 4u : 0u) |
+                  ((nz >> 48) == 0 ? 8u : 0u);
+    }
     const bool rst = TV_HEAD_RESET && mode != 2 && cl2 <= -RESET_THR;
     const bool ustd = mode == 2;
     reset_next = rst || ustd;
@@ -1047,6 +1055,7 @@ __global__ __launch_bounds__(256) void ssd_head_asm_kernel(HeadArgs a) {
   int mode = prep(0, dt_next, f_step);
   bool reset_cur = __builtin_amdgcn_readfirstlane((int)reset_next) != 0;
   bool std_cur = __builtin_amdgcn_readfirstlane((int)std_next) != 0;
+  unsigned dead_cur = dead_next;
   dt_next = *(const unsigned short*)(dtg + (int64_t)min(1, nchunks - 1) * HQ + lane);
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(dt_next) :: "memory");
   HEAD_BARRIER(0);
@@ -1057,15 +1066,12 @@ __global__ __launch_bounds__(256) void ssd_head_asm_kernel(HeadArgs a) {
   for (int c = 0; c < nchunks; ++c) {
     const bool more = c + 1 < nchunks;
     const bool copy = more && (c + 2) * HQ <= L;
-    const bool full = (c + 1) * HQ <= L;
-    const int rem = L - c * HQ;
-    const unsigned long long m01 = full ? ~0ull : __builtin_amdgcn_ballot_w64(16 * (kq & 1) + lc < rem);
-    const unsigned long long m23 = full ? ~0ull : __builtin_amdgcn_ballot_w64(32 + 16 * (kq & 1) + lc < rem);
-    const unsigned flags = __builtin_amdgcn_readfirstlane((mode == 1 ? 1u : 0u) | (reset_cur ? 2u : 0u) | (std_cur ? 4u : 0u) | (copy ? 8u : 0u));
+    const int rem = min(L - c * HQ, HQ);
+    const unsigned flags = __builtin_amdgcn_readfirstlane((mode == 1 ? 1u : 0u) | (reset_cur ? 2u : 0u) | (std_cur ? 4u : 0u) | (copy ? 8u : 0u) | (dead_cur << 4));
     const int sh = __builtin_amdgcn_readfirstlane(mode == 1 ? (int)f_step : 0);
     const unsigned sbc = (unsigned)(c % NB) * (HQ * HN * 2), sxs = (unsigned)(c & 1) * XSLOT;
-    // weights of x~ for Ydiag (phase A) and for the state update (phase B, reset steps); row factors of the epilogue
-    const unsigned vw = std_cur ? vw_one : reset_cur ? lds_vec + (unsigned)offsetof(HeadVec, wtd) + (c & 1) * 256 + 32 * kq : vw_wts;
+    // row factors of the epilogue (a standard step's accumulators already carry theirs)
+    const unsigned vw2 = lds_vec + (unsigned)offsetof(HeadVec, wtd) + (c & 1) * 256 + 32 * kq;       // (reset steps: Ydiag's weights, the old frame's)
     const unsigned vev = std_cur ? vev_one : vev_ecs;
     const void* pcb = uniform_ptr(cbg + (int64_t)c * CBE + 1024);       // (the step's offsets are -2048 .. 3072)
     const void* py = uniform_ptr(ygs + (int64_t)c * HQ * a.ysl);
@@ -1081,13 +1087,12 @@ __global__ __launch_bounds__(256) void ssd_head_asm_kernel(HeadArgs a) {
     asm volatile(TV_HEAD_STEP_ASM
                  : [dtout] "=&v"(dt_new) TV_STEP_STAMP_OPS
                  : [ca0] "v"(ca0), [ca1] "v"(ca1), [ca2] "v"(ca2), [ca3] "v"(ca3), [ba0] "v"(ba0), [ba1] "v"(ba1), [ba2] "v"(ba2), [ba3] "v"(ba3),
-                   [xtr] "v"(xtr), [xvr] "v"(xvr), [vw] "v"(vw), [vw2] "v"(vw_wts), [vev] "v"(vev), [cbo] "v"(cbo), [yo16] "v"(yo16), [dto] "v"(dto),
+                   [xtr] "v"(xtr), [xvr] "v"(xvr), [vw] "v"(vw_wts), [vw2] "v"(vw2), [vev] "v"(vev), [cbo] "v"(cbo), [yst] "v"(yst), [lrow] "v"(lrow), [xsr] "v"(xsr), [dto] "v"(dto),
                    [ob0] "v"(ob0), [ob1] "v"(ob1), [ob2] "v"(ob2), [ob3] "v"(ob3), [oc0] "v"(oc0), [oc1] "v"(oc1), [oc2] "v"(oc2), [oc3] "v"(oc3),
                    [ox0] "v"(ox0), [ox1] "v"(ox1), [ox2] "v"(ox2), [ox3] "v"(ox3), [oxl] "v"(oxl),
                    [at] "v"(sa_t), [as] "v"(sa_s), [alc] "v"(sa_lc), [as15] "v"(sa_s15), [d0] "v"(sd0),
-                   [sbc] "s"(sbc), [sxs] "s"(sxs), [flags] "s"(flags), [sh] "s"(sh), [dh] "s"(Dh), [pcb] "s"(pcb), [py] "s"(py), [y32] "s"(y32),
-                   [pdt] "s"(pdt), [pb] "s"(pb), [pc] "s"(pc), [px] "s"(px), [xg4] "s"(xg4), [lb] "s"(lb), [lc] "s"(lcc), [lx] "s"(lx),
-                   [m01] "s"(m01), [m23] "s"(m23)
+                   [sbc] "s"(sbc), [sxs] "s"(sxs), [flags] "s"(flags), [sh] "s"(sh), [dh] "s"(Dh), [pcb] "s"(pcb), [py] "s"(py), [y6] "s"(y6), [rem] "s"(rem),
+                   [pdt] "s"(pdt), [pb] "s"(pb), [pc] "s"(pc), [px] "s"(px), [xg4] "s"(xg4), [lb] "s"(lb), [lc] "s"(lcc), [lx] "s"(lx)
                  : TV_HEAD_STEP_CLOBBERS);
     if (more && !copy) {       // the next chunk is the sequence's last, partial one
       issue_bc_tail(c + 1, 0);
@@ -1098,9 +1103,10 @@ __global__ __launch_bounds__(256) void ssd_head_asm_kernel(HeadArgs a) {
       mode = prep(c + 1, dt_next, f_step);
       reset_cur = __builtin_amdgcn_readfirstlane((int)reset_next) != 0;
       std_cur = __builtin_amdgcn_readfirstlane((int)std_next) != 0;
+      dead_cur = dead_next;
     }
     dt_next = dt_new;
-    if (copy) HEAD_BARRIER(2 * PT);
+    if (copy) HEAD_BARRIER(11);       // (the step's eleven row stores may stay in flight)
     else HEAD_BARRIER(0);
   }
 #ifdef TV_HEAD_STAMP

@@ -20,6 +20,7 @@ The arithmetic and its order per accumulator are those of ssd_head.hip's C++ ste
 
     python timeviper_amd/devtools/gen_head_step.py  > timeviper_amd/csrc/ssd_head_step.inc
 """
+import os
 import sys
 
 PT = 5
@@ -32,7 +33,7 @@ def A_STATE(ct, i): return 32 * ct + 4 * i           # a[..+3]
 def A_YO(ct, ti): return 160 + 16 * ct + 4 * ti
 def A_RING(k): return 240 + 4 * (k % 4)
 
-V0 = 86
+V0 = 76
 _v = [V0]
 def valloc(n):
     b = _v[0]
@@ -48,7 +49,11 @@ CA = [valloc(1) for q in range(4)]
 BA = [valloc(1) for m in range(4)]
 XT = valloc(1)
 XV = valloc(1)
-XRP = [valloc(4) for k in range(2)]       # epilogue: x of two tiles, two sets
+XS = valloc(1)                            # the x / y tile as 16-byte pieces (lane = piece): the row stores of y
+_pad = valloc(1)
+XRP = [valloc(4) for k in range(2)]       # epilogue: x of tiles in flight; store data
+SD = [valloc(4) for k in range(2)]        # store data, two sets
+WQ2 = [[XRP[0], XRP[1]], [SD[0], SD[1]]]   # reset steps, phase A: the second set of weights (registers of phase B)
 T8 = [valloc(8) for k in range(1)][0]     # accumulator reads (snap / epilogue)
 U8 = valloc(8)                            # unpacked halves
 OUT = [valloc(4) for k in range(2)]
@@ -94,6 +99,7 @@ class Emitter:
         self.lds_seq, self.lds_done, self.lds_idx = 0, 0, {}
         self.vm_seq, self.vm_done, self.vm_idx = 0, 0, {}
         self.vm_guarded = False
+        self.uid = ""
         self.stats = {}
 
     def raw(self, text, states=1):
@@ -122,9 +128,9 @@ class Emitter:
                 if n > 0 and not self.vm_guarded:
                     # the counts assume the copies of chunk c + 1 were issued; without them (FLAG_COPY clear) wait for everything
                     self.raw(f"s_bitcmp1_b32 %[flags], {FLAG_COPY}")
-                    self.raw("s_cbranch_scc1 .Lhs_cbw_%=")
+                    self.raw(f"s_cbranch_scc1 .Lhs_cbw{self.uid}_%=")
                     self.raw("s_waitcnt vmcnt(0)")
-                    self.raw(".Lhs_cbw_%=:", 0)
+                    self.raw(f".Lhs_cbw{self.uid}_%=:", 0)
                     self.vm_guarded = True
                 self.raw(f"s_waitcnt vmcnt({n})")
                 self.vm_done = self.vm_seq - n
@@ -179,103 +185,95 @@ def stamp(em, k):
 
 # offsets of HeadVec's fields (bytes)
 VEC_CS, VEC_DTV, VEC_UT, VEC_WTS, VEC_WTD, VEC_ECS, VEC_WS, VEC_ONE = 0, 256, 512, 768, 1024, 1536, 1792, 2304
-N_VM_BEFORE_STD = 7 + 19         # C.B^T, dt, the copies: all issued before the block
+FLAG_DEAD0 = 4                   # flags bit 4 + ti: a standard step's row factors of t-tile ti are all zero
 
 
-def gen_std_block(em):
-    """Standard step (a chunk that decays by more than 2^-199: no single frame holds its weights), between Yoff and
-    Ydiag, as in ssd_head.hip's `ustd_step`: (1) the accumulators get their row factor 2^(cs_t + E) now; (2) the
-    per-head mask M = CB .* 2^(cs_t - cs_s) dt_s [s <= t] replaces C.B^T in its registers (diagonal 16x16 blocks one
-    exponential per element, the others separable around the first token of their t-tile: ut[t] ws[s]).  x~ of such a
-    step is x itself (weights 1), the epilogue's row factors are 1."""
-    assert em.vm_seq == N_VM_BEFORE_STD, em.vm_seq
-    em.raw(f"s_bitcmp1_b32 %[flags], {FLAG_STD}")
-    em.raw("s_cbranch_scc0 .Lhs_nostd_%=")
-    sub = Emitter()
-    sub.pos = 100
-    R = sub.raw
-    E_D, E_S = T8, U8
-    CV, DV = XRP[0], XRP[1]
-    CST, UU, TA, TB = OUT[0], OUT[0] + 1, OUT[0] + 2, OUT[0] + 3
-    UN = OUT[1]
-    R("s_nop 15")
-    R("s_nop 3")                                    # the last Yoff MFMAs have written their tiles
-    # (1) row factors
-    for ti in range(4):
-        sub.emit(Op(f"ds_read_b32 {vr(UU)}, %[alc] offset:{VEC_ECS + 64 * ti}", "lds", w=regs("v", UU), lds_def=f"sev{ti}"))
-        for ct in range(PT):
-            y = A_YO(ct, ti)
-            for r in range(4): sub.emit(Op(f"v_accvgpr_read_b32 {vr(T8 + r)}, {ar(y + r)}", "valu", w=regs("v", T8 + r)))
-            for r in range(4): sub.emit(Op(f"v_mul_f32 {vr(T8 + r)}, {vr(UU)}, {vr(T8 + r)}", "valu", r=regs("v", T8 + r) + regs("v", UU), w=regs("v", T8 + r),
-                                           lds_use=[f"sev{ti}"]))
-            for r in range(4): sub.emit(Op(f"v_accvgpr_write_b32 {ar(y + r)}, {vr(T8 + r)}", "valu", r=regs("v", T8 + r)))
-        sub.drain_lds()
-    # (2) the mask.  s[88:89] = lanes 32..63 (hi = kq >> 1)
-    R("s_mov_b32 s88, 0")
-    R("s_mov_b32 s89, -1")
-    R(f"s_bitcmp1_b32 %[flags], {FLAG_COPY}")
-    R("s_cbranch_scc1 .Lhs_stdw_%=")
-    R("s_waitcnt vmcnt(0)")
-    R(".Lhs_stdw_%=:", 0)
-    R(f"s_waitcnt vmcnt({N_VM_BEFORE_STD - 6})")      # C.B^T has landed (dt and the copies may stay in flight)
+def std_scale_ops(ti):
+    """standard step: the accumulators of t-tile ti get their row factor 2^(cs_t + E) (one glued group; a t-tile whose
+    factors have all underflowed is zeroed instead)"""
+    F = T8 + 4
+    ops = [Op(f"ds_read_b32 {vr(F)}, %[alc] offset:{VEC_ECS + 64 * ti}", "lds", w=regs("v", F), lds_def=f"sev{ti}"),
+           Op(f"s_bitcmp1_b32 %[flags], {FLAG_DEAD0 + ti}", "salu"),
+           Op(f"s_cbranch_scc1 .Lhs_dead{ti}_%=", "salu")]
+    for ct in range(PT):
+        y = A_YO(ct, ti)
+        for r in range(4): ops.append(Op(f"v_accvgpr_read_b32 {vr(T8 + r)}, {ar(y + r)}", "valu", r=regs("a", y + r), w=regs("v", T8 + r)))
+        for r in range(4): ops.append(Op(f"v_mul_f32 {vr(T8 + r)}, {vr(F)}, {vr(T8 + r)}", "valu", r=regs("v", T8 + r) + regs("v", F), w=regs("v", T8 + r),
+                                         lds_use=[f"sev{ti}"]))
+        for r in range(4): ops.append(Op(f"v_accvgpr_write_b32 {ar(y + r)}, {vr(T8 + r)}", "valu", r=regs("v", T8 + r), w=regs("a", y + r)))
+    ops.append(Op(f"s_branch .Lhs_scaled{ti}_%=", "salu"))
+    ops.append(Op(f".Lhs_dead{ti}_%=:", "label", cost=0))
+    ops.append(Op("s_nop 15", "salu"))          # (the other path's wait states for the MFMAs' results are not known to have passed here)
+    ops.append(Op("s_nop 3", "salu"))
+    for ct in range(PT):
+        y = A_YO(ct, ti)
+        for r in range(4): ops.append(Op(f"v_accvgpr_write_b32 {ar(y + r)}, 0", "valu", w=regs("a", y + r)))
+    ops.append(Op(f".Lhs_scaled{ti}_%=:", "label", cost=0))
+    for o in ops[:-1]: o.glue = True
+    return ops
+
+
+def std_mask_ops():
+    """Standard step (a chunk that decays by more than 2^-199: no single frame holds its weights), as in ssd_head.hip's
+    `ustd_step`: the per-head mask M = CB .* 2^(cs_t - cs_s) dt_s [s <= t] replaces C.B^T in its registers (diagonal
+    16x16 blocks one exponential per element, the others separable around the first token of their t-tile: ut[t] ws[s]).
+    Temporaries: registers of phase B."""
+    ops = []
+    E_D, E_S = XRP[0], SD[0]
+    CV, DV = OUT[0], OUT[1]
+    CST, UU, TA, TB, UN = EV[0], EV[0] + 1, EV[1], EV[1] + 1, EV[2]
+    ops.append(Op("s_mov_b32 s88, 0", "salu"))          # s[88:89] = lanes 32..63 (hi = kq >> 1)
+    ops.append(Op("s_mov_b32 s89, -1", "salu"))
+    ops.append(Op(f"v_mov_b32 {vr(TA)}, 0xff800000", "valu", w=regs("v", TA)))      # -inf
+    ops.append(Op(f"v_mov_b32 {vr(TB)}, 0", "valu", w=regs("v", TB)))
     tagn = [0]
 
     def diag(t_off, s_off, e):
         """e[j] = 2^(cs_t - cs_(s0 + j)) dt_(s0 + j) for s0 + j <= t, else 0;  t = t_off + 16 hi + lc, s0 = s_off + 8 kq"""
         tagn[0] += 1
         tg = f"d{tagn[0]}"
-        sub.emit(Op(f"ds_read_b32 {vr(CST)}, %[at] offset:{VEC_CS + 4 * t_off}", "lds", w=regs("v", CST), lds_def=tg + "c"))
+        ops.append(Op(f"ds_read_b32 {vr(CST)}, %[at] offset:{VEC_CS + 4 * t_off}", "lds", w=regs("v", CST), lds_def=tg + "c"))
         for hh in range(2):
-            sub.emit(Op(f"ds_read_b128 {vr(CV, 4)}, %[as] offset:{VEC_CS + 4 * s_off + 16 * hh}", "lds", w=regs("v", CV, 4), lds_def=tg + f"v{hh}"))
-            sub.emit(Op(f"ds_read_b128 {vr(DV, 4)}, %[as] offset:{VEC_DTV + 4 * s_off + 16 * hh}", "lds", w=regs("v", DV, 4), lds_def=tg + f"w{hh}"))
+            ops.append(Op(f"ds_read_b128 {vr(CV, 4)}, %[as] offset:{VEC_CS + 4 * s_off + 16 * hh}", "lds", w=regs("v", CV, 4), lds_def=tg + f"v{hh}"))
+            ops.append(Op(f"ds_read_b128 {vr(DV, 4)}, %[as] offset:{VEC_DTV + 4 * s_off + 16 * hh}", "lds", w=regs("v", DV, 4), lds_def=tg + f"w{hh}"))
             for j in range(4):
                 d = e + 4 * hh + j
-                sub.emit(Op(f"v_sub_f32 {vr(d)}, {vr(CST)}, {vr(CV + j)}", "valu", r=regs("v", CST) + regs("v", CV + j), w=regs("v", d),
-                            lds_use=[tg + "c", tg + f"v{hh}"]))
-                sub.emit(Op(f"v_cmp_ge_i32 vcc, %[d0], {4 * hh + j}", "valu"))
-                sub.emit(Op("s_nop 1", "salu"))
-                sub.emit(Op(f"v_cndmask_b32 {vr(d)}, {vr(TA)}, {vr(d)}, vcc", "valu", r=regs("v", d) + regs("v", TA), w=regs("v", d)))
-                sub.emit(Op(f"v_exp_f32 {vr(d)}, {vr(d)}", "valu", r=regs("v", d), w=regs("v", d)))
-                sub.emit(Op("s_nop 0", "salu"))
-                sub.emit(Op(f"v_mul_f32 {vr(d)}, {vr(d)}, {vr(DV + j)}", "valu", r=regs("v", d) + regs("v", DV + j), w=regs("v", d), lds_use=[tg + f"w{hh}"]))
-            sub.drain_lds()
+                ops.append(Op(f"v_sub_f32 {vr(d)}, {vr(CST)}, {vr(CV + j)}", "valu", r=regs("v", CST) + regs("v", CV + j), w=regs("v", d),
+                              lds_use=[tg + "c", tg + f"v{hh}"]))
+                ops.append(Op(f"v_cmp_ge_i32 vcc, %[d0], {4 * hh + j}", "valu", glue=True))
+                ops.append(Op("s_nop 1", "salu", glue=True))
+                ops.append(Op(f"v_cndmask_b32 {vr(d)}, {vr(TA)}, {vr(d)}, vcc", "valu", r=regs("v", d) + regs("v", TA), w=regs("v", d)))
+                ops.append(Op(f"v_exp_f32 {vr(d)}, {vr(d)}", "valu", r=regs("v", d), w=regs("v", d), cost=8, glue=True))
+                ops.append(Op("s_nop 0", "salu", glue=True))
+                ops.append(Op(f"v_mul_f32 {vr(d)}, {vr(d)}, {vr(DV + j)}", "valu", r=regs("v", d) + regs("v", DV + j), w=regs("v", d), lds_use=[tg + f"w{hh}"]))
 
     def sepf(t_off, w_operand, w_off, e):
         """e[j] = ut[t_off + lc] ws[w_off + j]"""
         tagn[0] += 1
         tg = f"s{tagn[0]}"
-        sub.emit(Op(f"ds_read_b32 {vr(UU)}, %[alc] offset:{VEC_UT + 4 * t_off}", "lds", w=regs("v", UU), lds_def=tg + "u"))
+        ops.append(Op(f"ds_read_b32 {vr(UU)}, %[alc] offset:{VEC_UT + 4 * t_off}", "lds", w=regs("v", UU), lds_def=tg + "u"))
         for hh in range(2):
-            sub.emit(Op(f"ds_read_b128 {vr(CV, 4)}, %[{w_operand}] offset:{VEC_WS + 4 * w_off + 16 * hh}", "lds", w=regs("v", CV, 4), lds_def=tg + f"v{hh}"))
+            ops.append(Op(f"ds_read_b128 {vr(CV, 4)}, %[{w_operand}] offset:{VEC_WS + 4 * w_off + 16 * hh}", "lds", w=regs("v", CV, 4), lds_def=tg + f"v{hh}"))
             for j in range(4):
                 d = e + 4 * hh + j
-                sub.emit(Op(f"v_mul_f32 {vr(d)}, {vr(UU)}, {vr(CV + j)}", "valu", r=regs("v", UU) + regs("v", CV + j), w=regs("v", d), lds_use=[tg + "u", tg + f"v{hh}"]))
-            sub.drain_lds()
+                ops.append(Op(f"v_mul_f32 {vr(d)}, {vr(UU)}, {vr(CV + j)}", "valu", r=regs("v", UU) + regs("v", CV + j), w=regs("v", d), lds_use=[tg + "u", tg + f"v{hh}"]))
 
     def select(e_lo, e_hi, dst):
-        """dst[j] = hi ? e_hi[j] : e_lo[j]   (None = 0)"""
+        """dst[j] = hi ? e_hi[j] : e_lo[j]   (e_hi None = 0)"""
         for j in range(8):
-            lo = "0" if e_lo is None else vr(e_lo + j)
-            hi_ = "0" if e_hi is None else vr(e_hi + j)
-            if e_lo is None:
-                sub.emit(Op(f"v_cndmask_b32 {vr(dst + j)}, 0, {hi_}, s[88:89]", "valu", w=regs("v", dst + j)))
-            elif e_hi is None:
-                sub.emit(Op(f"v_cndmask_b32 {vr(dst + j)}, {lo}, {vr(TB)}, s[88:89]", "valu", w=regs("v", dst + j)))
-            else:
-                sub.emit(Op(f"v_cndmask_b32 {vr(dst + j)}, {lo}, {hi_}, s[88:89]", "valu", w=regs("v", dst + j)))
+            hi_ = vr(TB) if e_hi is None else vr(e_hi + j)
+            ops.append(Op(f"v_cndmask_b32 {vr(dst + j)}, {vr(e_lo + j)}, {hi_}, s[88:89]", "valu", r=regs("v", e_lo + j), w=regs("v", dst + j)))
 
     def apply(f, fac):
         """cbv[f] <- bf16(CB_f .* fac)"""
         for jp in range(4):
             c = CBV[f] + jp
-            sub.emit(Op(f"v_lshlrev_b32 {vr(UN)}, 16, {vr(c)}", "valu", r=regs("v", c), w=regs("v", UN)))
-            sub.emit(Op(f"v_and_b32 {vr(UN + 1)}, 0xffff0000, {vr(c)}", "valu", r=regs("v", c), w=regs("v", UN + 1)))
-            sub.emit(Op(f"v_mul_f32 {vr(UN)}, {vr(UN)}, {vr(fac + 2 * jp)}", "valu", r=regs("v", UN) + regs("v", fac + 2 * jp), w=regs("v", UN)))
-            sub.emit(Op(f"v_mul_f32 {vr(UN + 1)}, {vr(UN + 1)}, {vr(fac + 2 * jp + 1)}", "valu", r=regs("v", UN + 1) + regs("v", fac + 2 * jp + 1), w=regs("v", UN + 1)))
-            sub.emit(Op(f"v_cvt_pk_bf16_f32 {vr(c)}, {vr(UN)}, {vr(UN + 1)}", "valu", r=regs("v", UN, 2), w=regs("v", c)))
+            ops.append(Op(f"v_lshlrev_b32 {vr(UN)}, 16, {vr(c)}", "valu", r=regs("v", c), w=regs("v", UN), vm_use=[f"cb{f}"]))
+            ops.append(Op(f"v_and_b32 {vr(UN + 1)}, 0xffff0000, {vr(c)}", "valu", r=regs("v", c), w=regs("v", UN + 1)))
+            ops.append(Op(f"v_mul_f32 {vr(UN)}, {vr(UN)}, {vr(fac + 2 * jp)}", "valu", r=regs("v", UN) + regs("v", fac + 2 * jp), w=regs("v", UN)))
+            ops.append(Op(f"v_mul_f32 {vr(UN + 1)}, {vr(UN + 1)}, {vr(fac + 2 * jp + 1)}", "valu", r=regs("v", UN + 1) + regs("v", fac + 2 * jp + 1), w=regs("v", UN + 1)))
+            ops.append(Op(f"v_cvt_pk_bf16_f32 {vr(c)}, {vr(UN)}, {vr(UN + 1)}", "valu", r=regs("v", UN, 2), w=regs("v", c)))
 
-    R(f"v_mov_b32 {vr(TA)}, 0xff800000")           # -inf
-    R(f"v_mov_b32 {vr(TB)}, 0")
     diag(0, 0, E_D)                                 # diagonal blocks of fragments (0,0) [hi = 0] and (1,0) [hi = 1]
     select(E_D, None, E_S)
     apply(0, E_S)
@@ -292,15 +290,7 @@ def gen_std_block(em):
     sepf(48, "as15", 80, E_S)                       # block (3,2)
     select(E_S, E_D, E_S)
     apply(5, E_S)
-    R("s_nop 1")
-    sub.drain_lds()
-    em.lines += sub.lines
-    em.raw(".Lhs_nostd_%=:", 0)
-    for f in range(6):
-        for r in regs("v", CBV[f], 4): em.wr[r] = (em.pos, "valu")
-    for t in (T8, U8, XRP[0], XRP[1], OUT[0], OUT[1]):
-        pass
-    em.vm_done = max(em.vm_done, 0)
+    return ops
 
 
 class Task:
@@ -361,12 +351,34 @@ def xw_comp_ops(ct, ks, tag, wtag):
     return ops
 
 
-def wq_read_ops(vw_operand, wtag):
+def wq_read_ops(vw_operand, wtag, dst=None):
+    dst = WQ if dst is None else dst
     ops = []
     for ks in range(2):
         for h in range(2):
-            ops.append(Op(f"ds_read_b128 {vr(WQ[ks][h], 4)}, %[{vw_operand}] offset:{(32 * ks + 4 * h) * 4}", "lds", w=regs("v", WQ[ks][h], 4),
+            ops.append(Op(f"ds_read_b128 {vr(dst[ks][h], 4)}, %[{vw_operand}] offset:{(32 * ks + 4 * h) * 4}", "lds", w=regs("v", dst[ks][h], 4),
                           lds_def=f"{wtag}{ks}{h}"))
+    return ops
+
+
+def xw_dual_ops(ct, ks, tag, wtag, wtag2, dst2):
+    """fragment (ct, ks) of x times two sets of weights from one unpacking: WQ2 -> v[dst2 ..], WQ -> in place"""
+    d = XW[ct][ks]
+    ops = []
+    for e in range(4):
+        t = U8 + 4 * (e & 1)
+        w, w2 = WQ[ks][e >> 1] + 2 * (e & 1), WQ2[ks][e >> 1] + 2 * (e & 1)
+        use = [f"{tag}{ct}{ks}{'a' if e < 2 else 'b'}"]
+        ops.append(Op(f"v_lshlrev_b32 {vr(t)}, 16, {vr(d + e)}", "valu", r=regs("v", d + e), w=regs("v", t), lds_use=use))
+        ops.append(Op(f"v_and_b32 {vr(t + 1)}, 0xffff0000, {vr(d + e)}", "valu", r=regs("v", d + e), w=regs("v", t + 1)))
+        for k in range(2):
+            ops.append(Op(f"v_mul_f32 {vr(t + 2 + k)}, {vr(w2 + k)}, {vr(t + k)}", "valu", r=regs("v", t + k) + regs("v", w2 + k), w=regs("v", t + 2 + k),
+                          lds_use=[f"{wtag2}{ks}{e >> 1}"]))
+        ops.append(Op(f"v_cvt_pk_bf16_f32 {vr(dst2 + e)}, {vr(t + 2)}, {vr(t + 3)}", "valu", r=regs("v", t + 2, 2), w=regs("v", dst2 + e)))
+        for k in range(2):
+            ops.append(Op(f"v_mul_f32 {vr(t + k)}, {vr(w + k)}, {vr(t + k)}", "valu", r=regs("v", t + k) + regs("v", w + k), w=regs("v", t + k),
+                          lds_use=[f"{wtag}{ks}{e >> 1}"]))
+        ops.append(Op(f"v_cvt_pk_bf16_f32 {vr(d + e)}, {vr(t)}, {vr(t + 1)}", "valu", r=regs("v", t, 2), w=regs("v", d + e)))
     return ops
 
 
@@ -387,8 +399,8 @@ def copy_group_ops(name, base_operand, add_operand, m0_expr_ops, voffs, ioffs):
     return ops
 
 
-def epi_tile_ops(ct, ti, xr, acc_t, unp, out, xtag):
-    """the lane's 8 bytes of y of tile (ct, ti): out[0:1] = bf16(yo * ev + D x)"""
+def epi_tile_ops(ct, ti, xr, acc_t, unp, xtag):
+    """tile (ct, ti): the lane's 8 bytes of y = bf16(yo * ev + D x), written over the x they were made from (LDS)"""
     y = A_YO(ct, ti)
     ops = []
     for r in range(4):
@@ -409,17 +421,13 @@ def epi_tile_ops(ct, ti, xr, acc_t, unp, out, xtag):
             ops.append(Op(f"v_fma_f32 {vr(acc_t + k)}, {vr(acc_t + k)}, {vr(EV[ti])}, {vr(unp + k)}", "valu",
                           r=regs("v", acc_t + k) + regs("v", EV[ti]) + regs("v", unp + k), w=regs("v", acc_t + k), lds_use=[f"ev{ti}"]))
     for h in range(2):
-        ops.append(Op(f"v_cvt_pk_bf16_f32 {vr(out + h)}, {vr(acc_t + 2 * h)}, {vr(acc_t + 2 * h + 1)}", "valu", r=regs("v", acc_t + 2 * h, 2), w=regs("v", out + h)))
+        ops.append(Op(f"v_cvt_pk_bf16_f32 {vr(unp + h)}, {vr(acc_t + 2 * h)}, {vr(acc_t + 2 * h + 1)}", "valu", r=regs("v", acc_t + 2 * h, 2), w=regs("v", unp + h)))
+    ops.append(Op(f"ds_write_b64 {vr(XV)}, {vr(unp, 2)} offset:{32 * ct + ti * 16 * XROW}", "lds", r=regs("v", XV) + regs("v", unp, 2), lds_def=f"yw{ct}{ti}"))
     return ops
 
 
-def epi_xread_ops(ct, tp, xr, tagbase):
-    ops = []
-    for k in range(2):
-        ti = tp + k
-        ops.append(Op(f"ds_read_b64 {vr(xr + 2 * k, 2)}, {vr(XV)} offset:{32 * ct + ti * 16 * XROW}", "lds", r=regs("v", XV), w=regs("v", xr + 2 * k, 2),
-                      lds_def=f"{tagbase}{ct}{ti}"))
-    return ops
+def epi_xread_op(ct, ti, xr):
+    return Op(f"ds_read_b64 {vr(xr, 2)}, {vr(XV)} offset:{32 * ct + ti * 16 * XROW}", "lds", r=regs("v", XV), w=regs("v", xr, 2), lds_def=f"ex{ct}{ti}")
 
 
 # ---------------------------------------------------------------- scheduler
@@ -431,6 +439,8 @@ def schedule(em, mfmas, tasks, budget, first_index=0, stamps=None, blocks=None):
     for k, m in enumerate(mfmas):
         idx = first_index + k
         # complete what is due
+        if cur is not None and cur.ops and any(t.deadline <= idx and t.ops and t is not cur for t in tasks):
+            while cur.ops: em.emit(cur.ops.pop(0))
         while True:
             due = [t for t in tasks if t.deadline <= idx and t.ops]
             if cur is not None and cur.ops and cur.deadline <= idx and cur not in due: due.append(cur)
@@ -487,6 +497,8 @@ def gen_step():
     for q in range(4): em.emit(Op(f"v_add_u32 {vr(CA[q])}, %[sbc], %[ca{q}]", "valu", w=regs("v", CA[q])))
     em.emit(Op(f"v_add_u32 {vr(XT)}, %[sxs], %[xtr]", "valu", w=regs("v", XT)))
     em.emit(Op(f"v_add_u32 {vr(XV)}, %[sxs], %[xvr]", "valu", w=regs("v", XV)))
+    em.emit(Op(f"v_add_u32 {vr(XS)}, %[sxs], %[xsr]", "valu", w=regs("v", XS)))
+    for m in range(4): em.emit(Op(f"v_add_u32 {vr(BA[m])}, %[sbc], %[ba{m}]", "valu", w=regs("v", BA[m])))
     for op in wq_read_ops("vw", "wq"): em.emit(op)
     for k in range(4):       # C fragments of quarter 0
         em.emit(Op(f"ds_read_b128 {ar(A_RING(k), 4)}, {vr(CA[0])} offset:{k * 4096}", "lds", r=regs("v", CA[0]), w=regs("a", A_RING(k), 4), lds_def=f"c{k}"))
@@ -498,50 +510,6 @@ def gen_step():
         for op in snap_ops(0, ct, SB[0][ct], T8): em.emit(op)
 
     stamp(em, 1)
-    # ---------------- phase A: Yoff (80 MFMAs), Ydiag (30)
-    mf = []
-    for q in range(4):
-        for ti in range(4):
-            for ct in range(PT):
-                mf.append(mfma(A_YO(ct, ti), SB[q & 1][ct], A_RING(4 * q + ti), None if q == 0 else A_YO(ct, ti), b_is_acc=True))
-                mf[-1].lds_use = [f"c{4 * q + ti}"]
-    ydiag = [(0, 0, 0), (1, 0, 1), (2, 0, 2), (3, 0, 4), (2, 1, 3), (3, 1, 5)]        # (ti, ks, fragment)
-    for ti, ks, f in ydiag:
-        for ct in range(PT):
-            m = mfma(A_YO(ct, ti), XW[ct][ks], CBV[f], A_YO(ct, ti))
-            m.vm_use = [f"cb{f}"]
-            mf.append(m)
-    tasks = []
-    for k in range(4, 16):       # C fragments of quarters 1..3 through the ring
-        q, ti = k // 4, k % 4
-        tasks.append(Task(f"c{k}", [Op(f"ds_read_b128 {ar(A_RING(k), 4)}, {vr(CA[q])} offset:{ti * 4096}", "lds", r=regs("v", CA[q]),
-                                       w=regs("a", A_RING(k), 4), lds_def=f"c{k}")], after=(k - 4) * 5 + 4, deadline=k * 5 - 6, prio=k * 5 - 40))
-    for q in range(1, 4):
-        for ct in range(PT):
-            after = -1 if q == 1 else (q - 2) * 20 + 15 + ct
-            tasks.append(Task(f"snap{q}{ct}", snap_ops(q, ct, SB[q & 1][ct], T8), after=after, deadline=q * 20 + ct, prio=q * 20 + ct - 2))
-    order = [(ct, 0) for ct in range(PT)] + [(ct, 1) for ct in range(PT)]
-    for n, (ct, ks) in enumerate(order):
-        ops = []
-        if n + 1 < len(order): ops += xw_read_ops(order[n + 1][0], order[n + 1][1], "x")
-        ops += xw_comp_ops(ct, ks, "x", "wq")
-        tasks.append(Task(f"xw{ct}{ks}", ops, after=-1, deadline=80 + (0 if ks == 0 else 20) + ct, prio=8 * n + 3))
-    # copies of chunk c + 1 (B, C, three groups of x)
-    m0b = [Op("s_mov_b32 m0, %[lb]", "salu")]
-    m0c = [Op("s_mov_b32 m0, %[lc]", "salu")]
-    tasks.append(Task("cpB", copy_group_ops("cpb", "pb", ("z", 0), m0b, ["ob0", "ob1", "ob2", "ob3"], [0, 1024, 2048, 3072]), after=4, deadline=100, prio=10))
-    tasks.append(Task("cpC", copy_group_ops("cpc", "pc", ("z", 0), m0c, ["oc0", "oc1", "oc2", "oc3"], [0, 1024, 2048, 3072]), after=18, deadline=100, prio=24))
-    for g in range(3):
-        n = min(4, NXI - 4 * g)
-        vo = ["ox0", "ox1", "ox2", "ox3"][:n]
-        if 4 * g + n == NXI: vo[-1] = "oxl"
-        m0x = [Op(f"s_add_u32 m0, %[lx], {RPI * 4 * g * XROW}" if g else "s_mov_b32 m0, %[lx]", "salu")]
-        tasks.append(Task(f"cpX{g}", copy_group_ops(f"cpx{g}", "px", ("xg4", g), m0x, vo, [j * RPI * XROW for j in range(n)]),
-                          after=32 + 14 * g, deadline=100, prio=38 + 14 * g))
-    # phase B operands that may already be fetched: addresses, ev, the first B fragments (ring slots free after the last C use)
-    pre_b = [Op(f"v_add_u32 {vr(BA[m])}, %[sbc], %[ba{m}]", "valu", w=regs("v", BA[m])) for m in range(4)]
-    pre_b += [Op(f"ds_read_b32 {vr(EV[ti])}, %[vev] offset:{64 * ti}", "lds", w=regs("v", EV[ti]), lds_def=f"ev{ti}") for ti in range(4)]
-    tasks.append(Task("preB", pre_b, after=70, deadline=108, prio=95))
 
     def b_read_ops(m):
         i, ks = m // 2, m % 2
@@ -550,32 +518,121 @@ def gen_step():
         d = A_RING(m)
         return [Op(f"ds_read_b64_tr_b16 {ar(d, 2)}, {vr(base)} offset:{off}", "lds", r=regs("v", base), w=regs("a", d, 2), lds_def=f"b{m}a"),
                 Op(f"ds_read_b64_tr_b16 {ar(d + 2, 2)}, {vr(base)} offset:{off + 1024}", "lds", r=regs("v", base), w=regs("a", d + 2, 2), lds_def=f"b{m}b")]
-    for m in range(4):
-        tasks.append(Task(f"b{m}", b_read_ops(m), after=(12 + m) * 5 + 4, deadline=110 + m * 5 - 4, prio=100 + m))
-    va = sum(op.cost for t in tasks for op in t.ops)
-    schedule(em, mf, tasks, budget=va / len(mf) + 1.0, stamps={20: 2, 40: 3, 60: 4, 80: 5}, blocks={80: gen_std_block})
-    stamp(em, 6)
 
-    # ---------------- reset steps: x~ again with the new frame's weights (the state update builds the new state)
+    # ---------------- phase A: Yoff (80 MFMAs), Ydiag (30), in three variants
+    #   F  floating step: x~ = wts x serves Ydiag and the state update
+    #   R  reset step: Ydiag takes x~ in the old frame (wtd), the state update x~ in the new one (wts): both from one
+    #      unpacking of x, the first into the registers of the state's bf16 copy once those are free
+    #   S  standard step: Ydiag takes x itself (read into the same registers) and the per-head mask built into the C.B^T
+    #      registers beside the Yoff MFMAs; the accumulators get their row factor between Yoff and Ydiag
+    def phase_a(em, var):
+        YA = (lambda ct, ks: XW[ct][ks]) if var == "F" else (lambda ct, ks: SB[ks][ct])        # Ydiag's A operand
+        mf = []
+        for q in range(4):
+            for ti in range(4):
+                for ct in range(PT):
+                    mf.append(mfma(A_YO(ct, ti), SB[q & 1][ct], A_RING(4 * q + ti), None if q == 0 else A_YO(ct, ti), b_is_acc=True))
+                    mf[-1].lds_use = [f"c{4 * q + ti}"]
+        ydiag = [(0, 0, 0), (1, 0, 1), (2, 0, 2), (3, 0, 4), (2, 1, 3), (3, 1, 5)]        # (ti, ks, fragment)
+        for ti, ks, f in ydiag:
+            for ct in range(PT):
+                m = mfma(A_YO(ct, ti), YA(ct, ks), CBV[f], A_YO(ct, ti))
+                m.vm_use = [f"cb{f}"]
+                if var == "S": m.lds_use = [f"xr{ct}{ks}a", f"xr{ct}{ks}b"]
+                mf.append(m)
+        tasks = []
+        for k in range(4, 16):       # C fragments of quarters 1..3 through the ring
+            q, ti = k // 4, k % 4
+            tasks.append(Task(f"c{k}", [Op(f"ds_read_b128 {ar(A_RING(k), 4)}, {vr(CA[q])} offset:{ti * 4096}", "lds", r=regs("v", CA[q]),
+                                           w=regs("a", A_RING(k), 4), lds_def=f"c{k}")], after=(k - 4) * 5 + 4, deadline=k * 5 - 6, prio=k * 5 - 40))
+        for q in range(1, 4):
+            for ct in range(PT):
+                after = -1 if q == 1 else (q - 2) * 20 + 15 + ct
+                tasks.append(Task(f"snap{q}{ct}", snap_ops(q, ct, SB[q & 1][ct], T8), after=after, deadline=q * 20 + ct, prio=q * 20 + ct - 2))
+        order = [(ct, 0) for ct in range(PT)] + [(ct, 1) for ct in range(PT)]
+        if var in ("F", "S"):
+            for n, (ct, ks) in enumerate(order):
+                ops = []
+                if n + 1 < len(order): ops += xw_read_ops(order[n + 1][0], order[n + 1][1], "x")
+                ops += xw_comp_ops(ct, ks, "x", "wq")
+                sf = var == "F" or os.environ.get("GEN_SXW")
+                dl = 80 + (0 if ks == 0 else 20) + ct if sf else 109
+                tasks.append(Task(f"xw{ct}{ks}", ops, after=-1, deadline=dl, prio=8 * n + 3 if sf else 60 + 4 * n))
+        if var == "R":
+            # both x~ from one unpacking: old frame (weights WQ2 <- vw2) into SB[ks][ct], new frame (WQ) in place
+            for n, (ct, ks) in enumerate(order):
+                ops = []
+                if n == 0: ops += wq_read_ops("vw2", "w2", WQ2)
+                if n + 1 < len(order): ops += xw_read_ops(order[n + 1][0], order[n + 1][1], "x")
+                ops += xw_dual_ops(ct, ks, "x", "wq", "w2", SB[ks][ct])
+                tasks.append(Task(f"xw{ct}{ks}", ops, after=(55 if ks == 0 else 75) + ct, deadline=80 + (0 if ks == 0 else 20) + ct, prio=56 + 5 * n))
+        if var == "S":
+            # x itself for Ydiag, into the registers of the state's bf16 copy
+            for n, (ct, ks) in enumerate(order):
+                d = SB[ks][ct]
+                off = 32 * ct + ks * 32 * XROW
+                ops = [Op(f"ds_read_b64_tr_b16 {vr(d, 2)}, {vr(XT)} offset:{off}", "lds", r=regs("v", XT), w=regs("v", d, 2), lds_def=f"xr{ct}{ks}a"),
+                       Op(f"ds_read_b64_tr_b16 {vr(d + 2, 2)}, {vr(XT)} offset:{off + 4 * XROW}", "lds", r=regs("v", XT), w=regs("v", d + 2, 2), lds_def=f"xr{ct}{ks}b")]
+                tasks.append(Task(f"xr{ct}{ks}", ops, after=(55 if ks == 0 else 75) + ct, deadline=76 + (0 if ks == 0 else 20) + ct, prio=56 + 5 * n))
+            tasks.append(Task("mask", std_mask_ops(), after=int(os.environ.get("GEN_MASK_AFTER", 20)), deadline=80, prio=30))
+            for ti in range(4):
+                tasks.append(Task(f"scale{ti}", std_scale_ops(ti), after=max(64 + 5 * ti + 4, int(os.environ.get("GEN_SCALE_AFTER", 0))), deadline=80 + 5 * ti, prio=70 + 5 * ti))
+        # copies of chunk c + 1 (B, C, three groups of x)
+        m0b = [Op("s_mov_b32 m0, %[lb]", "salu")]
+        m0c = [Op("s_mov_b32 m0, %[lc]", "salu")]
+        tasks.append(Task("cpB", copy_group_ops("cpb" + var, "pb", ("z", 0), m0b, ["ob0", "ob1", "ob2", "ob3"], [0, 1024, 2048, 3072]), after=4, deadline=100, prio=10))
+        tasks.append(Task("cpC", copy_group_ops("cpc" + var, "pc", ("z", 0), m0c, ["oc0", "oc1", "oc2", "oc3"], [0, 1024, 2048, 3072]), after=18, deadline=100, prio=24))
+        for g in range(3):
+            n = min(4, NXI - 4 * g)
+            vo = ["ox0", "ox1", "ox2", "ox3"][:n]
+            if 4 * g + n == NXI: vo[-1] = "oxl"
+            m0x = [Op(f"s_add_u32 m0, %[lx], {RPI * 4 * g * XROW}" if g else "s_mov_b32 m0, %[lx]", "salu")]
+            tasks.append(Task(f"cpX{g}", copy_group_ops(f"cpx{g}" + var, "px", ("xg4", g), m0x, vo, [j * RPI * XROW for j in range(n)]),
+                              after=32 + 14 * g, deadline=100, prio=38 + 14 * g))
+        # phase B operands that may already be fetched: ev, the first B fragments (ring slots free after the last C use)
+        pre_b = [Op(f"ds_read_b32 {vr(EV[ti])}, %[vev] offset:{64 * ti}", "lds", w=regs("v", EV[ti]), lds_def=f"ev{ti}") for ti in range(4)]
+        tasks.append(Task("preB", pre_b, after=81 if var == "S" else 70, deadline=109, prio=108 if var == "S" else 95))
+        for m in range(4):
+            tasks.append(Task(f"b{m}", b_read_ops(m), after=(12 + m) * 5 + 4, deadline=110 + m * 5 - 4, prio=100 + m))
+        va = sum(op.cost for t in tasks for op in t.ops)
+        schedule(em, mf, tasks, budget=va / len(mf) + 1.0, stamps={20: 2, 40: 3, 60: 4, 80: 5})
+        em.drain_lds()
+
+    import copy
+    def fork(em):
+        e2 = Emitter()
+        e2.__dict__.update(copy.deepcopy({k: v for k, v in em.__dict__.items() if k != "lines"}))
+        e2.lines = []
+        return e2
     em.raw(f"s_bitcmp1_b32 %[flags], {FLAG_RESET}")
-    em.raw("s_cbranch_scc0 .Lhs_noreset_%=")
-    sub = Emitter()
-    sub.pos = 100
-    for op in wq_read_ops("vw2", "wr"): sub.emit(op)
+    em.raw("s_cbranch_scc1 .Lhs_pa_rs_%=")
+    emR, emS = fork(em), fork(em)
+    em.uid, emR.uid, emS.uid = "f", "r", "s"
+    phase_a(em, "F")
+    em.raw("s_branch .Lhs_pa_join_%=")
+    emR.raw(".Lhs_pa_rs_%=:", 0)
+    emR.raw(f"s_bitcmp1_b32 %[flags], {FLAG_STD}")
+    emR.raw("s_cbranch_scc1 .Lhs_pa_s_%=")
+    emS.pos, emS.lines = emR.pos, []
+    phase_a(emR, "R")
+    emR.raw("s_branch .Lhs_pa_join_%=")
+    emS.raw(".Lhs_pa_s_%=:", 0)
+    phase_a(emS, "S")
+    assert em.vm_seq == emR.vm_seq == emS.vm_seq and em.lds_seq == em.lds_done, (em.vm_seq, emR.vm_seq, emS.vm_seq)
+    em.lines += emR.lines + emS.lines
+    em.raw(".Lhs_pa_join_%=:", 0)
+    # after the join: every accumulator tile may have just been written by an MFMA, every vector register by the vector ALU
+    em.pos = max(em.pos, emR.pos, emS.pos) + 1
     for ct in range(PT):
-        for ks in range(2):
-            for op in xw_read_ops(ct, ks, "r"): sub.emit(op)
-    for ct in range(PT):
-        for ks in range(2):
-            for op in xw_comp_ops(ct, ks, "r", "wr"): sub.emit(op)
-    sub.raw("s_nop 1")
-    sub.drain_lds()
-    em.lines += sub.lines
-    em.raw(".Lhs_noreset_%=:", 0)
-    stamp(em, 7)
-    for ct in range(PT):
+        for ti in range(4):
+            for r in regs("a", A_YO(ct, ti), 4): em.wr[r] = (em.pos, "mfma")
         for ks in range(2):
             for r in regs("v", XW[ct][ks], 4): em.wr[r] = (em.pos, "valu")
+    em.vm_done = min(em.vm_done, emR.vm_done, emS.vm_done)
+    em.lds_idx.update(emR.lds_idx)      # (tags defined in every variant: b0 .. b3, ev0 .. ev3; everything has landed)
+    em.lds_done = em.lds_seq = max(em.lds_seq, emR.lds_seq, emS.lds_seq)
+    for t in list(em.lds_idx): em.lds_idx[t] = min(em.lds_idx[t], em.lds_seq - 1)
+    stamp(em, 6)
 
     # ---------------- phase B: state update (80 MFMAs) beside the y epilogue; two copies (reset: first k-step onto zero)
     def phase_b(em, reset):
@@ -589,29 +646,48 @@ def gen_step():
         tasks = []
         for m in range(4, 16):
             tasks.append(Task(f"b{m}", b_read_ops(m), after=110 + (m - 4) * 5 + 4, deadline=110 + m * 5 - 6, prio=110 + m * 5 - 40))
-        seq = [(tp, ct) for tp in (0, 2) for ct in range(PT)]
+        # y epilogue: tiles t-tile by t-tile (x read two tiles ahead), y back into the x tile; the chunk then leaves as whole
+        # 160-byte rows: store k = rows 6 k .. 6 k + 5 (60 lanes x 16 bytes, lane = piece; the last one rows 60 .. 63), rows
+        # past the end of the sequence switched off (row < rem)
+        seq = [(ti, ct) for ti in range(4) for ct in range(PT)]
+        xrs = [XRP[0], XRP[0] + 2, XRP[1], XRP[1] + 2]
         pri = 200
-        for n, (tp, ct) in enumerate(seq):
+        stores_after_tile = {4: [0, 1], 9: [2, 3, 4], 14: [5, 6, 7], 19: [8, 9, 10]}      # rows 6 k + 5 <= 16 ti + 15
+        for n, (ti, ct) in enumerate(seq):
             ops = []
-            if n == 0: ops += epi_xread_ops(ct, tp, XRP[0], "ex")
-            if n + 1 < len(seq): ops += epi_xread_ops(seq[n + 1][1], seq[n + 1][0], XRP[(n + 1) & 1], "ex")
-            if ct == 0:
-                ops.append(Op(f"s_mov_b64 s[{S_Y}:{S_Y + 1}], %[py]", "salu"))
-                if tp == 2:
-                    ops.append(Op(f"s_add_u32 s{S_Y}, s{S_Y}, %[y32]", "salu"))
-                    ops.append(Op(f"s_addc_u32 s{S_Y + 1}, s{S_Y + 1}, 0", "salu"))
-            xr, out = XRP[n & 1], OUT[n & 1]
-            ops += epi_tile_ops(ct, tp, xr, T8, U8, out, f"ex{ct}{tp}")
-            ops += epi_tile_ops(ct, tp + 1, xr + 2, T8 + 4, U8 + 4, out + 2, f"ex{ct}{tp + 1}")
-            ops.append(Op(f"v_permlane16_swap_b32 {vr(out)}, {vr(out + 2)}", "perm", r=regs("v", out) + regs("v", out + 2), w=regs("v", out) + regs("v", out + 2)))
-            ops.append(Op(f"v_permlane16_swap_b32 {vr(out + 1)}, {vr(out + 3)}", "perm", r=regs("v", out + 1) + regs("v", out + 3), w=regs("v", out + 1) + regs("v", out + 3)))
-            ops.append(Op(f"s_mov_b64 exec, %[m{'01' if tp == 0 else '23'}]", "salu", glue=True))
-            ops.append(Op("s_nop 0", "salu", glue=True))
-            if not NOSTORE: ops.append(Op(f"global_store_dwordx4 %[yo16], {vr(out, 4)}, s[{S_Y}:{S_Y + 1}] offset:{32 * ct}", "store", r=regs("v", out, 4), glue=True))
-            ops.append(Op("s_mov_b64 exec, -1", "salu", glue=True))
-            ops.append(Op("s_nop 0", "salu"))
-            tasks.append(Task(f"epi{tp}{ct}", ops, after=111 if tp == 0 else 114, prio=pri))
+            if n == 0:
+                ops.append(epi_xread_op(ct, ti, xrs[0]))
+                ops.append(epi_xread_op(seq[1][1], seq[1][0], xrs[1]))
+            if n + 2 < len(seq): ops.append(epi_xread_op(seq[n + 2][1], seq[n + 2][0], xrs[(n + 2) % 4]))
+            tb = (n & 1) * 4
+            ops += epi_tile_ops(ct, ti, xrs[n % 4], T8 + tb, U8 + tb, f"ex{ct}{ti}")
+            tasks.append(Task(f"epi{ti}{ct}", ops, after=111 if ti < 2 else 114, prio=pri))
             pri += 1
+            grp = stores_after_tile.get(n, [])
+            def sd_read(k):
+                return Op(f"ds_read_b128 {vr(SD[k & 1], 4)}, {vr(XS)} offset:{k * RPI * XROW}", "lds", r=regs("v", XS), w=regs("v", SD[k & 1], 4), lds_def=f"sd{k}")
+            for j, k in enumerate(grp):
+                sops = []
+                if j == 0:
+                    sops.append(sd_read(k))
+                    if len(grp) > 1: sops.append(sd_read(grp[1]))
+                if k == 0:
+                    sops.append(Op(f"s_mov_b64 s[{S_Y}:{S_Y + 1}], %[py]", "salu"))
+                else:
+                    sops.append(Op(f"s_add_u32 s{S_Y}, s{S_Y}, %[y6]", "salu"))
+                    sops.append(Op(f"s_addc_u32 s{S_Y + 1}, s{S_Y + 1}, 0", "salu"))
+                sops.append(Op(f"s_sub_i32 s{S_T}, %[rem], {6 * k}", "salu"))
+                sops.append(Op(f"s_min_i32 s{S_T}, s{S_T}, 6", "salu"))
+                sops.append(Op(f"v_cmp_gt_i32 vcc, s{S_T}, %[lrow]", "valu", glue=True))
+                sops.append(Op("s_nop 1", "salu", glue=True))
+                sops.append(Op("s_mov_b64 exec, vcc", "salu", glue=True, lds_use=[f"sd{k}"]))
+                sops.append(Op("s_nop 0", "salu", glue=True))
+                if not NOSTORE: sops.append(Op(f"global_store_dwordx4 %[yst], {vr(SD[k & 1], 4)}, s[{S_Y}:{S_Y + 1}]", "store", r=regs("v", SD[k & 1], 4), glue=True))
+                sops.append(Op("s_mov_b64 exec, -1", "salu", glue=True))
+                sops.append(Op("s_nop 0", "salu"))
+                if j + 2 < len(grp): sops.append(sd_read(grp[j + 2]))
+                tasks.append(Task(f"st{k}", sops, after=114, prio=pri))
+                pri += 1
         va = sum(op.cost for t in tasks for op in t.ops)
         schedule(em, mf, tasks, budget=va / len(mf) + 1.0, first_index=110, stamps={150: 8})
         stamp(em, 9)
@@ -637,7 +713,7 @@ def gen_step():
     em.raw("s_cbranch_scc1 .Lhs_endw_%=")
     em.raw("s_waitcnt vmcnt(0)")
     em.raw(".Lhs_endw_%=:", 0)
-    em.raw(f"s_waitcnt vmcnt({0 if NOSTORE else 10}) lgkmcnt(0)")
+    em.raw(f"s_waitcnt vmcnt({0 if NOSTORE else 11}) lgkmcnt(0)")
     stamp(em, 10)
     em.raw(f"s_mov_b32 m0, s{S_M0}")
     return em
