@@ -71,6 +71,49 @@ def test_head_scan_fast_kernels_spill_nothing(tmp_path):
 
 
 @needs_tools
+def test_head_scan_asm_kernel_spills_nothing_and_keeps_out_of_the_body_s_registers(tmp_path):
+    """ssd_head_asm_kernel (head_dim 80 x 4 heads: the 9B model's scan) keeps its state in a0..a159 and the step body's
+    values in v76..v255 ACROSS statements the compiler cannot see into (csrc/ssd_head_step.inc).  That holds only while
+    the compiler itself never touches those registers between the statements: no scratch, no v_accvgpr_* / AGPR operand
+    and no VGPR >= TV_HEAD_STEP_V0 outside ;;#ASMSTART .. ;;#ASMEND."""
+    md = kernel_metadata("ssd_head.hip", tmp_path)
+    k = [v for n, v in md.items() if "ssd_head_asm_kernel" in n]
+    assert len(k) == 1, list(md)
+    assert k[0].get("private_segment_fixed_size") == 0 and k[0].get("vgpr_spill_count", 0) == 0, k[0]
+    inc = (build.CSRC / "ssd_head_step.inc").read_text()
+    v0 = int(re.search(r"#define TV_HEAD_STEP_V0 (\d+)", inc).group(1))
+    asm = tmp_path / "ssd_head.s"
+    subprocess.run([build.HIPCC, *build.FLAGS, f"-I{build.CSRC}", "-x", "hip", "-S", "--cuda-device-only",
+                    str(build.CSRC / "ssd_head.hip"), "-o", str(asm)], check=True, capture_output=True)
+    text = asm.read_text()
+    body = text[text.index("ssd_head_asm_kernel"):]
+    body = body[body.index(": ; @"):body.index(".amdhsa_kernel")]
+    inside, bad = False, []
+    for line in body.splitlines():
+        if "#ASMSTART" in line:
+            inside = True
+        elif "#ASMEND" in line:
+            inside = False
+        elif not inside:
+            t = line.strip()
+            if not t or t.startswith((";", ".")):
+                continue
+            regs = [int(a or c) for a, b, c in re.findall(r"\bv(\d+)\b|v\[(\d+):(\d+)\]", t)]
+            if "accvgpr" in t or re.search(r"\ba\[?\d", t) or "scratch_" in t or any(r >= v0 for r in regs):
+                bad.append(t)
+    assert not bad, bad[:5]
+
+
+def test_head_step_include_is_what_the_generator_writes():
+    """csrc/ssd_head_step.inc is generated (devtools/gen_head_step.py --scalar): the committed file must be the generator's
+    output, so that the schedule, the register map and the wait counts can be read (and changed) in one place."""
+    import sys
+    out = subprocess.run([sys.executable, str(build.ROOT / "devtools" / "gen_head_step.py"), "--scalar"], check=True,
+                         capture_output=True, text=True).stdout
+    assert out == (build.CSRC / "ssd_head_step.inc").read_text()
+
+
+@needs_tools
 def test_attention_kernels_with_untracked_q_loads_spill_nothing(tmp_path):
     """flash_fwd_kernel / flash_fwd_stream_kernel load their Q fragments with ssdk::gload16_async."""
     for src in ("attention.hip", "attention_fp8.hip"):

@@ -120,7 +120,7 @@ struct HeadArgs {
 // -DTV_HEAD_STAMP: wave 0 of work-group 0 sums the cycles (s_memtime) of eight phases of its steps;
 // tv_ssd_head_debug_stamps() returns them
 #ifdef TV_HEAD_STAMP
-__device__ unsigned long long g_head_phases[32];
+__device__ unsigned long long g_head_phases[64];
 #define HSTAMP(slot) do { unsigned long long n__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(n__) :: "memory"); ph_acc[slot] += n__ - ph_last; ph_last = n__; } while (0)
 #else
 #define HSTAMP(slot) do {} while (0)
@@ -1061,58 +1061,79 @@ __global__ __launch_bounds__(256) void ssd_head_asm_kernel(HeadArgs a) {
   HEAD_BARRIER(0);
 
 #ifdef TV_HEAD_STAMP
-  unsigned st_last = (unsigned)clock64(), st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, st5 = 0, st6 = 0, st7 = 0, st8 = 0, st9 = 0, st10 = 0;
+  unsigned st_last = (unsigned)clock64(), st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, st5 = 0, st6 = 0, st7 = 0, st8 = 0, st9 = 0, st10 = 0, st11 = 0, st12 = 0;
 #endif
+  // The vectors of chunk c + 1 are made inside step c (beside the MFMAs of its state update); what the next step's set-up needs
+  // comes back in scalar registers: its flags (re-base / reset / standard / dead t-tiles), the re-basing shift, E, the decay total.
+  unsigned nflags = (mode == 1 ? 1u : 0u) | (reset_cur ? 2u : 0u) | (std_cur ? 4u : 0u) | (dead_cur << 4);
+  int nsh = mode == 1 ? (int)f_step : 0;
+  const unsigned vvec = lds_vec + 4 * lane;
+  const unsigned vw2_0 = lds_vec + (unsigned)offsetof(HeadVec, wtd) + 32 * kq;
+  const unsigned lb0 = lds_bt + KP * wave * 1024, lc0 = lds_ct + KP * wave * 1024;
+  const unsigned fl_const = a.softplus ? (1u << 8) : 0u;
+  // running scalar pointers (bytes): C.B^T and y of chunk c, dt of chunk min(c + 2, last), B / C / x of chunk c + 1
+  const char* pcb_r = (const char*)uniform_ptr(cbg + 1024);              // (the step's offsets are -2048 .. 3072)
+  const char* py_r = (const char*)uniform_ptr(ygs);
+  const char* pdt_r = (const char*)uniform_ptr(dtg + (int64_t)min(2, nchunks - 1) * HQ);
+  const char* pb_r = (const char*)uniform_ptr(Bg + (int64_t)HQ * a.bsl);
+  const char* pc_r = (const char*)uniform_ptr(Cg + (int64_t)HQ * a.csl);
+  const char* px_r = (const char*)uniform_ptr(xg + (int64_t)HQ * a.xsl);
+  const int64_t y_step = (int64_t)HQ * a.ysl * 2, b_step = (int64_t)HQ * a.bsl * 2, c_step = (int64_t)HQ * a.csl * 2, x_step = (int64_t)HQ * a.xsl * 2;
+  unsigned sbc = 0, sxs = 0;
   for (int c = 0; c < nchunks; ++c) {
     const bool more = c + 1 < nchunks;
     const bool copy = more && (c + 2) * HQ <= L;
     const int rem = min(L - c * HQ, HQ);
-    const unsigned flags = __builtin_amdgcn_readfirstlane((mode == 1 ? 1u : 0u) | (reset_cur ? 2u : 0u) | (std_cur ? 4u : 0u) | (copy ? 8u : 0u) | (dead_cur << 4));
-    const int sh = __builtin_amdgcn_readfirstlane(mode == 1 ? (int)f_step : 0);
-    const unsigned sbc = (unsigned)(c % NB) * (HQ * HN * 2), sxs = (unsigned)(c & 1) * XSLOT;
-    // row factors of the epilogue (a standard step's accumulators already carry theirs)
-    const unsigned vw2 = lds_vec + (unsigned)offsetof(HeadVec, wtd) + (c & 1) * 256 + 32 * kq;       // (reset steps: Ydiag's weights, the old frame's)
-    const unsigned vev = std_cur ? vev_one : vev_ecs;
-    const void* pcb = uniform_ptr(cbg + (int64_t)c * CBE + 1024);       // (the step's offsets are -2048 .. 3072)
-    const void* py = uniform_ptr(ygs + (int64_t)c * HQ * a.ysl);
-    const void* pdt = uniform_ptr(dtg + (int64_t)min(c + 2, nchunks - 1) * HQ);
-    const int cn = more ? c + 1 : c;
-    const void* pb = uniform_ptr(Bg + (int64_t)cn * HQ * a.bsl);
-    const void* pc = uniform_ptr(Cg + (int64_t)cn * HQ * a.csl);
-    const void* px = uniform_ptr(xg + (int64_t)cn * HQ * a.xsl);
-    const unsigned lb = lds_bt + ((c + 1) % NB) * (HQ * HN * 2) + KP * wave * 1024;
-    const unsigned lcc = lds_ct + ((c + 1) % NB) * (HQ * HN * 2) + KP * wave * 1024;
-    const unsigned lx = lds_xr + ((c + 1) & 1) * XSLOT;
-    unsigned dt_new;
+    const unsigned flags = __builtin_amdgcn_readfirstlane(nflags | (copy ? 8u : 0u) | fl_const);
+    const int sh = __builtin_amdgcn_readfirstlane(nsh);
+    const unsigned vw2 = vw2_0 + (c & 1) * 256;       // (reset steps: Ydiag's weights, the old frame's)
+    const unsigned vev = (flags & 4u) ? vev_one : vev_ecs;
+    const void* pcb = pcb_r; const void* py = py_r; const void* pdt = pdt_r;
+    const void* pb = pb_r; const void* pc = pc_r; const void* px = px_r;
+    pcb_r += CBE * 2; py_r += y_step; pb_r += b_step; pc_r += c_step; px_r += x_step;
+    if (c + 3 < nchunks) pdt_r += HQ * 2;
+    const unsigned lb = lb0 + (sbc ^ (HQ * HN * 2)), lcc = lc0 + (sbc ^ (HQ * HN * 2)), lx = lds_xr + (sxs ^ XSLOT);
+    const int lrem1 = L - (c + 1) * HQ;
+    const unsigned par1 = (unsigned)(c + 1) & 1u;
+    unsigned dt_new, o_flags, o_e, o_dtot, o_cl2;
+    int o_sh;
     asm volatile(TV_HEAD_STEP_ASM
-                 : [dtout] "=&v"(dt_new) TV_STEP_STAMP_OPS
+                 : [dtout] "=&v"(dt_new), [oflags] "=&s"(o_flags), [osh] "=&s"(o_sh), [oe] "=&s"(o_e), [odtot] "=&s"(o_dtot), [ocl2] "=&s"(o_cl2) TV_STEP_STAMP_OPS
                  : [ca0] "v"(ca0), [ca1] "v"(ca1), [ca2] "v"(ca2), [ca3] "v"(ca3), [ba0] "v"(ba0), [ba1] "v"(ba1), [ba2] "v"(ba2), [ba3] "v"(ba3),
                    [xtr] "v"(xtr), [xvr] "v"(xvr), [vw] "v"(vw_wts), [vw2] "v"(vw2), [vev] "v"(vev), [cbo] "v"(cbo), [yst] "v"(yst), [lrow] "v"(lrow), [xsr] "v"(xsr), [dto] "v"(dto),
                    [ob0] "v"(ob0), [ob1] "v"(ob1), [ob2] "v"(ob2), [ob3] "v"(ob3), [oc0] "v"(oc0), [oc1] "v"(oc1), [oc2] "v"(oc2), [oc3] "v"(oc3),
                    [ox0] "v"(ox0), [ox1] "v"(ox1), [ox2] "v"(ox2), [ox3] "v"(ox3), [oxl] "v"(oxl),
                    [at] "v"(sa_t), [as] "v"(sa_s), [alc] "v"(sa_lc), [as15] "v"(sa_s15), [d0] "v"(sd0),
+                   [dtin] "v"(dt_next), [lane] "v"(lane), [vvec] "v"(vvec),
                    [sbc] "s"(sbc), [sxs] "s"(sxs), [flags] "s"(flags), [sh] "s"(sh), [dh] "s"(Dh), [pcb] "s"(pcb), [py] "s"(py), [y6] "s"(y6), [rem] "s"(rem),
-                   [pdt] "s"(pdt), [pb] "s"(pb), [pc] "s"(pc), [px] "s"(px), [xg4] "s"(xg4), [lb] "s"(lb), [lc] "s"(lcc), [lx] "s"(lx)
+                   [pdt] "s"(pdt), [pb] "s"(pb), [pc] "s"(pc), [px] "s"(px), [xg4] "s"(xg4), [lb] "s"(lb), [lc] "s"(lcc), [lx] "s"(lx),
+                   [lrem1] "s"(lrem1), [par1] "s"(par1), [bias] "s"(bias), [ah] "s"(Ah), [dtmin] "s"(a.dt_min), [dtmax] "s"(a.dt_max), [ein] "s"(E), [dtot] "s"(decay_total)
                  : TV_HEAD_STEP_CLOBBERS);
     if (more && !copy) {       // the next chunk is the sequence's last, partial one
       issue_bc_tail(c + 1, 0);
       issue_bc_tail(c + 1, 1);
       issue_x_tail(c + 1);
     }
-    if (more) {
-      mode = prep(c + 1, dt_next, f_step);
-      reset_cur = __builtin_amdgcn_readfirstlane((int)reset_next) != 0;
-      std_cur = __builtin_amdgcn_readfirstlane((int)std_next) != 0;
-      dead_cur = dead_next;
+    if (more) {       // the step has prepared chunk c + 1
+      nflags = o_flags; nsh = o_sh;
+      E = __uint_as_float(o_e); decay_total = __uint_as_float(o_dtot);
+      if (a.chunk_tot && lane == 0) a.chunk_tot[((int64_t)b * a.H + h) * a.nchunks + c_first + c + 1] = __uint_as_float(o_cl2);
     }
     dt_next = dt_new;
+    sbc ^= HQ * HN * 2; sxs ^= XSLOT;
+#ifdef TV_HEAD_STAMP
+    { unsigned long long n__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(n__) :: "memory"); st11 += (unsigned)n__ - st_last; st_last = (unsigned)n__; }
+#endif
     if (copy) HEAD_BARRIER(11);       // (the step's eleven row stores may stay in flight)
     else HEAD_BARRIER(0);
+#ifdef TV_HEAD_STAMP
+    { unsigned long long n__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(n__) :: "memory"); st12 += (unsigned)n__ - st_last; st_last = (unsigned)n__; }
+#endif
   }
 #ifdef TV_HEAD_STAMP
-  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0 && wave < 2) {
-    const unsigned sv[11] = {st0, st1, st2, st3, st4, st5, st6, st7, st8, st9, st10};
-    for (int i = 0; i < 11; ++i) g_head_phases[16 * wave + i] = sv[i];
+  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0) {
+    const unsigned sv[13] = {st0, st1, st2, st3, st4, st5, st6, st7, st8, st9, st10, st11, st12};
+    for (int i = 0; i < 13; ++i) g_head_phases[16 * wave + i] = sv[i];
   }
 #endif
   // ---- final state of this segment, X = 2^E X'

@@ -62,6 +62,7 @@ assert _v[0] == 256, _v[0]
 S_M0, S_CP, S_Y, S_D, S_T = 80, 82, 84, 86, 88      # s80 saved m0, s[82:83] copy base, s[84:85] y rows, s[86:87] D, s[88:89] temp
 
 FLAG_REBASE, FLAG_RESET, FLAG_STD, FLAG_COPY = 0, 1, 2, 3
+FLAG_SOFTPLUS = 8
 
 
 def vr(b, n=1): return f"v{b}" if n == 1 else f"v[{b}:{b + n - 1}]"
@@ -156,7 +157,7 @@ class Emitter:
         if ck == "store":
             for reg in op.r: self.rd_store[reg] = self.pos
         self.pos += 1
-        if op.lds_def is not None or ck in ("lds",):
+        if op.lds_def is not None or ck in ("lds",):      # ("lds_nc": an LDS write inside an optional region, not counted: waits stay safe)
             if op.lds_def is not None: self.lds_idx[op.lds_def] = self.lds_seq
             self.lds_seq += 1
         if op.vm_def is not None or ck in ("vmem", "dma", "store"):
@@ -291,6 +292,196 @@ def std_mask_ops():
     select(E_S, E_D, E_S)
     apply(5, E_S)
     return ops
+
+
+def prep_ops(uid):
+    """The vectors of chunk c + 1 (what ssd_head.hip's `prep` lambda does, in its compiled order of operations): dt -> softplus ->
+    clamp, inclusive scan of dt A over the wave (DPP), the mode decision, row factors, weights, and a standard step's separable
+    factors — written into the wave's vectors in LDS (every reader of chunk c's has finished before phase B).  Results that the
+    next step's scalar set-up needs come back in SGPR outputs.  Temporaries: the registers of the state's bf16 copy."""
+    ops = []
+    P = [SB[0][0] + i for i in range(40)]
+    X, T1, T2, T3, T4, T5, D_, CS, CS2, EE, CL2, ECL, ROW, A0, A1, A2, ARG, PV, K32, MSH = P[:20]
+    VALID, MA, MB, MC = 72, 74, 76, 78          # SGPR pairs
+    SC, SCL, SMODE, SDEAD = 94, 95, 96, 97
+
+    def V(text, w=(), r=(), **kw): ops.append(Op(text, "valu", r=[f"v{x}" for x in r], w=[f"v{x}" for x in w], **kw))
+    def S(text, **kw): ops.append(Op(text, "salu", **kw))
+    def G(n):           # glue the last n ops to their successors (a compare and its consumer, a transcendental and its wait state)
+        for o in ops[-n:]: o.glue = True
+
+    V(f"v_cmp_gt_i32 vcc, %[lrem1], %[lane]"); G(1)
+    S(f"s_mov_b64 s[{VALID}:{VALID + 1}], vcc")
+    V(f"v_lshlrev_b32 {vr(X)}, 16, %[dtin]", w=[X])
+    V(f"v_add_f32 {vr(X)}, %[bias], {vr(X)}", w=[X], r=[X])
+    V(f"v_mul_f32 {vr(T1)}, 0x3fb8aa3b, {vr(X)}", w=[T1], r=[X])
+    V(f"v_exp_f32 {vr(T2)}, {vr(T1)}", w=[T2], r=[T1], cost=8); G(1)
+    S("s_nop 0")
+    V(f"v_add_f32 {vr(T1)}, 1.0, {vr(T2)}", w=[T1], r=[T2])
+    S(f"s_mov_b32 s{SC}, 0x800000")
+    V(f"v_cmp_gt_f32 vcc, s{SC}, {vr(T1)}", r=[T1]); G(1)
+    V(f"v_cndmask_b32 {vr(T3)}, 0, 32, vcc", w=[T3]); G(1)
+    V(f"v_mov_b32 {vr(K32)}, 0x41b17218", w=[K32]); G(1)
+    V(f"v_cndmask_b32 {vr(K32)}, 0, {vr(K32)}, vcc", w=[K32], r=[K32])
+    V(f"v_ldexp_f32 {vr(T1)}, {vr(T1)}, {vr(T3)}", w=[T1], r=[T1, T3])
+    V(f"v_log_f32 {vr(T1)}, {vr(T1)}", w=[T1], r=[T1], cost=8); G(1)
+    S("s_nop 0")
+    V(f"v_mul_f32 {vr(T4)}, 0x3f317217, {vr(T1)}", w=[T4], r=[T1])
+    S(f"s_mov_b32 s{SC}, 0x3f317217")
+    V(f"v_fma_f32 {vr(T5)}, {vr(T1)}, s{SC}, -{vr(T4)}", w=[T5], r=[T1, T4])
+    V(f"v_fmac_f32 {vr(T5)}, 0x3377d1cf, {vr(T1)}", w=[T5], r=[T5, T1])
+    V(f"v_add_f32 {vr(T4)}, {vr(T4)}, {vr(T5)}", w=[T4], r=[T4, T5])
+    S(f"s_mov_b32 s{SC}, 0x7f800000")
+    V(f"v_cmp_lt_f32 s[{MA}:{MA + 1}], |{vr(T1)}|, s{SC}", r=[T1]); G(1)
+    S("s_nop 1"); G(1)
+    V(f"v_cndmask_b32 {vr(T1)}, {vr(T1)}, {vr(T4)}, s[{MA}:{MA + 1}]", w=[T1], r=[T1, T4])
+    V(f"v_sub_f32 {vr(T1)}, {vr(T1)}, {vr(K32)}", w=[T1], r=[T1, K32])             # log(1 + e)
+    V(f"v_mul_f32 {vr(T4)}, -0.5, {vr(T2)}", w=[T4], r=[T2])
+    V(f"v_mul_f32 {vr(T4)}, {vr(T2)}, {vr(T4)}", w=[T4], r=[T2, T4])
+    V(f"v_add_f32 {vr(T4)}, {vr(T2)}, {vr(T4)}", w=[T4], r=[T2, T4])               # e - e^2 / 2
+    S(f"s_mov_b32 s{SC}, 0x3a83126f")
+    V(f"v_cmp_ngt_f32 vcc, s{SC}, {vr(T2)}", r=[T2]); G(1)
+    V(f"v_cndmask_b32 {vr(T1)}, {vr(T4)}, {vr(T1)}, vcc", w=[T1], r=[T1, T4])
+    S(f"s_mov_b32 s{SC}, 0x41a00000")
+    V(f"v_cmp_lt_f32 vcc, s{SC}, {vr(X)}", r=[X]); G(1)
+    V(f"v_cndmask_b32 {vr(T1)}, {vr(T1)}, {vr(X)}, vcc", w=[T1], r=[T1, X])        # softplus(x)
+    S(f"s_bitcmp1_b32 %[flags], {FLAG_SOFTPLUS}"); G(1)
+    S(f"s_cselect_b64 s[{MA}:{MA + 1}], -1, 0")
+    V(f"v_cndmask_b32 {vr(X)}, {vr(X)}, {vr(T1)}, s[{MA}:{MA + 1}]", w=[X], r=[X, T1])
+    V(f"v_max_f32 {vr(X)}, {vr(X)}, {vr(X)}", w=[X], r=[X])
+    V(f"v_max_f32 {vr(X)}, %[dtmin], {vr(X)}", w=[X], r=[X])
+    V(f"v_min_f32 {vr(X)}, %[dtmax], {vr(X)}", w=[X], r=[X])
+    V(f"v_cndmask_b32 {vr(D_)}, 0, {vr(X)}, s[{VALID}:{VALID + 1}]", w=[D_], r=[X])        # d (0 past the end of the sequence)
+    # inclusive scan of d A over the 64 lanes
+    V(f"v_mul_f32 {vr(CS)}, %[ah], {vr(D_)}", w=[CS], r=[D_])
+    for sh in (1, 2, 4, 8):
+        S("s_nop 1"); G(1)
+        V(f"v_add_f32_dpp {vr(CS)}, {vr(CS)}, {vr(CS)} row_shr:{sh} row_mask:0xf bank_mask:0xf bound_ctrl:1", w=[CS], r=[CS])
+    V(f"v_mov_b32 {vr(T1)}, 0", w=[T1])
+    S("s_nop 1"); G(2)
+    V(f"v_mov_b32_dpp {vr(T1)}, {vr(CS)} row_bcast:15 row_mask:0xa bank_mask:0xf", w=[T1], r=[CS, T1])
+    V(f"v_add_f32 {vr(CS)}, {vr(CS)}, {vr(T1)}", w=[CS], r=[CS, T1])
+    V(f"v_mov_b32 {vr(T1)}, 0", w=[T1])
+    S("s_nop 1"); G(2)
+    V(f"v_mov_b32_dpp {vr(T1)}, {vr(CS)} row_bcast:31 row_mask:0xc bank_mask:0xf", w=[T1], r=[CS, T1])
+    V(f"v_add_f32 {vr(CS)}, {vr(CS)}, {vr(T1)}", w=[CS], r=[CS, T1])
+    V(f"v_mul_f32 {vr(CS2)}, 0x3fb8aa3b, {vr(CS)}", w=[CS2], r=[CS])
+    S("s_nop 0"); G(1)
+    V(f"v_readlane_b32 s{SCL}, {vr(CS)}, 63", r=[CS])
+    V(f"v_mov_b32 {vr(EE)}, %[ein]", w=[EE])
+    V(f"v_sub_f32 {vr(T3)}, 0x42c80000, {vr(EE)}", w=[T3], r=[EE])
+    V(f"v_floor_f32 {vr(T3)}, {vr(T3)}", w=[T3], r=[T3])
+    V(f"v_mov_b32 {vr(T1)}, 0x3fb8aa3b", w=[T1])
+    V(f"v_mul_f32 {vr(CL2)}, s{SCL}, {vr(T1)}", w=[CL2], r=[T1])                    # log2 decay of the chunk
+    V(f"v_add_f32 {vr(ECL)}, {vr(EE)}, {vr(CL2)}", w=[ECL], r=[EE, CL2])
+    # mode: 0 floating (-(E + cl2) <= RMAX), 1 re-base first (-cl2 <= 2 RMAX - 1), 2 standard step
+    S(f"s_mov_b32 s{SC}, 0xc3470000")
+    V(f"v_cmp_le_f32 s[{MA}:{MA + 1}], s{SC}, {vr(CL2)}", r=[CL2])
+    S(f"s_mov_b32 s{SC}, 0xc2c80000")
+    V(f"v_cmp_nle_f32 vcc, s{SC}, {vr(ECL)}", r=[ECL]); G(1)
+    S("s_nop 1"); G(1)
+    S(f"s_and_b64 s[{MB}:{MB + 1}], s[{MA}:{MA + 1}], vcc"); G(1)          # mode 1
+    S(f"s_andn2_b64 s[{MC}:{MC + 1}], exec, vcc")                        # mode 0 = not (mode != 0)
+    S(f"s_or_b64 s[{MC}:{MC + 1}], s[{MC}:{MC + 1}], s[{MA}:{MA + 1}]")    # mode != 2 = mode 0 or (-cl2 <= 199)
+    V(f"v_cndmask_b32 {vr(MSH)}, 0, {vr(T3)}, s[{MB}:{MB + 1}]", w=[MSH], r=[T3])   # m = floor(RMAX - E) when re-basing, else 0
+    V(f"v_add_f32 {vr(EE)}, {vr(EE)}, {vr(MSH)}", w=[EE], r=[EE, MSH])                # the frame in which this chunk reads the state
+    V(f"v_add_f32 {vr(ROW)}, {vr(CS2)}, {vr(EE)}", w=[ROW], r=[CS2, EE])
+    V(f"v_exp_f32 {vr(ROW)}, {vr(ROW)}", w=[ROW], r=[ROW], cost=8); G(1)
+    S("s_nop 0")
+    ops.append(Op(f"ds_write2st64_b32 %[vvec], {vr(CS2)}, {vr(D_)} offset1:1", "lds", r=[f"v{CS2}", f"v{D_}"]))
+    ops.append(Op(f"ds_write_b32 %[vvec], {vr(ROW)} offset:{VEC_ECS}", "lds", r=[f"v{ROW}"]))
+    # reset: the chunk decays by more than 2^-64 and is not a standard step
+    S(f"s_mov_b32 s{SC}, 0xc2800000")
+    V(f"v_cmp_ge_f32 s[{MA}:{MA + 1}], s{SC}, {vr(CL2)}", r=[CL2]); G(1)
+    S("s_nop 1"); G(1)
+    S(f"s_and_b64 s[{MA}:{MA + 1}], s[{MA}:{MA + 1}], s[{MC}:{MC + 1}]")          # rst
+    # weights of the state update: 2^arg d, arg = standard: cl2 - cs2; reset: cl2 - cs2 - RMAX; else -cs2 - E
+    V(f"v_sub_f32 {vr(A0)}, -{vr(CS2)}, {vr(EE)}", w=[A0], r=[CS2, EE])
+    V(f"v_sub_f32 {vr(A1)}, {vr(CL2)}, {vr(CS2)}", w=[A1], r=[CL2, CS2])
+    V(f"v_add_f32 {vr(A2)}, 0xc2c80000, {vr(A1)}", w=[A2], r=[A1])
+    V(f"v_cndmask_b32 {vr(ARG)}, {vr(A0)}, {vr(A2)}, s[{MA}:{MA + 1}]", w=[ARG], r=[A0, A2])
+    V(f"v_cndmask_b32 {vr(ARG)}, {vr(A1)}, {vr(ARG)}, s[{MC}:{MC + 1}]", w=[ARG], r=[A1, ARG])
+    V(f"v_exp_f32 {vr(ARG)}, {vr(ARG)}", w=[ARG], r=[ARG], cost=8); G(1)
+    S("s_nop 0")
+    V(f"v_mul_f32 {vr(ARG)}, {vr(D_)}, {vr(ARG)}", w=[ARG], r=[D_, ARG])
+    ops.append(Op(f"ds_write_b32 %[vvec], {vr(ARG)} offset:{VEC_WTS}", "lds", r=[f"v{ARG}"]))
+    V(f"v_exp_f32 {vr(A0)}, {vr(A0)}", w=[A0], r=[A0], cost=8); G(1)              # reset steps: Ydiag's weights (the old frame's)
+    S("s_nop 0")
+    V(f"v_mul_f32 {vr(A0)}, {vr(D_)}, {vr(A0)}", w=[A0], r=[D_, A0])
+    V(f"v_lshl_add_u32 {vr(T1)}, %[par1], 8, %[vvec]", w=[T1])
+    ops.append(Op(f"ds_write_b32 {vr(T1)}, {vr(A0)} offset:{VEC_WTD}", "lds", r=[f"v{T1}", f"v{A0}"]))
+    # frame after this chunk: standard 0, reset RMAX, else E + cl2;  decay total
+    V(f"v_add_f32 {vr(T2)}, {vr(CL2)}, {vr(EE)}", w=[T2], r=[CL2, EE])
+    V(f"v_mov_b32 {vr(T3)}, 0x42c80000", w=[T3])
+    V(f"v_cndmask_b32 {vr(T2)}, {vr(T2)}, {vr(T3)}, s[{MA}:{MA + 1}]", w=[T2], r=[T2, T3])
+    V(f"v_cndmask_b32 {vr(T2)}, 0, {vr(T2)}, s[{MC}:{MC + 1}]", w=[T2], r=[T2])
+    V(f"v_mov_b32 {vr(T4)}, %[dtot]", w=[T4])
+    V(f"v_add_f32 {vr(T4)}, s{SCL}, {vr(T4)}", w=[T4], r=[T4])
+    # dead t-tiles (every row factor zero), mode bits
+    V(f"v_cmp_neq_f32 vcc, 0, {vr(ROW)}", r=[ROW]); G(1)
+    S("s_nop 1"); G(1)
+    S(f"s_and_b32 s{SC}, vcc_lo, 0xffff"); G(1)
+    S(f"s_cmp_eq_u32 s{SC}, 0"); G(1)
+    S(f"s_cselect_b32 s{SDEAD}, 16, 0"); G(1)
+    S(f"s_lshr_b32 s{SC}, vcc_lo, 16"); G(1)
+    S(f"s_cmp_eq_u32 s{SC}, 0"); G(1)
+    S(f"s_cselect_b32 s{SC}, 32, 0"); G(1)
+    S(f"s_or_b32 s{SDEAD}, s{SDEAD}, s{SC}"); G(1)
+    S(f"s_and_b32 s{SC}, vcc_hi, 0xffff"); G(1)
+    S(f"s_cmp_eq_u32 s{SC}, 0"); G(1)
+    S(f"s_cselect_b32 s{SC}, 64, 0"); G(1)
+    S(f"s_or_b32 s{SDEAD}, s{SDEAD}, s{SC}"); G(1)
+    S(f"s_lshr_b32 s{SC}, vcc_hi, 16"); G(1)
+    S(f"s_cmp_eq_u32 s{SC}, 0"); G(1)
+    S(f"s_cselect_b32 s{SC}, 128, 0"); G(1)
+    S(f"s_or_b32 s{SDEAD}, s{SDEAD}, s{SC}")
+    S(f"s_cmp_lg_u64 s[{MB}:{MB + 1}], 0"); G(1)
+    S(f"s_cselect_b32 s{SMODE}, 1, 0")                                     # bit 0: re-base
+    S(f"s_cmp_lg_u64 s[{MA}:{MA + 1}], 0"); G(1)
+    S(f"s_cselect_b32 s{SC}, 2, 0"); G(1)
+    S(f"s_or_b32 s{SMODE}, s{SMODE}, s{SC}")                               # bit 1: reset
+    S(f"s_cmp_lg_u64 s[{MC}:{MC + 1}], 0"); G(1)
+    S(f"s_cselect_b32 s{SC}, 0, 6"); G(1)
+    S(f"s_or_b32 s{SMODE}, s{SMODE}, s{SC}"); G(1)                          # standard: bits 1 and 2
+    S(f"s_or_b32 %[oflags], s{SMODE}, s{SDEAD}")
+    V(f"v_cvt_i32_f32 {vr(T3)}, -{vr(MSH)}", w=[T3], r=[MSH])
+    S("s_nop 0"); G(1)
+    V(f"v_readfirstlane_b32 %[osh], {vr(T3)}", r=[T3])
+    V(f"v_readfirstlane_b32 %[oe], {vr(T2)}", r=[T2])
+    V(f"v_readfirstlane_b32 %[odtot], {vr(T4)}", r=[T4])
+    V(f"v_readfirstlane_b32 %[ocl2], {vr(CL2)}", r=[CL2])
+    # standard steps: separable factors of the off-diagonal mask blocks (pivot = first token of a t-tile); LDS writes not counted
+    S(f"s_cmp_lg_u64 s[{MC}:{MC + 1}], 0")
+    S(f"s_cbranch_scc1 .Lhs_prep_nostd{uid}_%=")
+    k0 = len(ops) - 2
+    for j, ln in enumerate((0, 16, 32, 48)):
+        V(f"v_readlane_b32 s{90 + j}, {vr(CS2)}, {ln}", r=[CS2])
+    V(f"v_mov_b32 {vr(PV)}, s93", w=[PV])
+    for j, bound in ((2, 48), (1, 32), (0, 16)):
+        V(f"v_cmp_gt_i32 vcc, {bound}, %[lane]")
+        V(f"v_mov_b32 {vr(T1)}, s{90 + j}", w=[T1])
+        V(f"v_cndmask_b32 {vr(PV)}, {vr(PV)}, {vr(T1)}, vcc", w=[PV], r=[PV, T1])
+    V(f"v_sub_f32 {vr(T1)}, {vr(CS2)}, {vr(PV)}", w=[T1], r=[CS2, PV])
+    V(f"v_min_f32 {vr(T1)}, 0, {vr(T1)}", w=[T1], r=[T1])
+    V(f"v_exp_f32 {vr(T1)}, {vr(T1)}", w=[T1], r=[T1])
+    S("s_nop 0")
+    ops.append(Op(f"ds_write_b32 %[vvec], {vr(T1)} offset:{VEC_UT}", "lds_nc", r=[f"v{T1}"]))
+    for j, (bound, woff) in enumerate(((16, 0), (32, 16), (48, 48))):
+        V(f"v_sub_f32 {vr(T1)}, s{91 + j}, {vr(CS2)}", w=[T1], r=[CS2])
+        V(f"v_min_f32 {vr(T1)}, 0, {vr(T1)}", w=[T1], r=[T1])
+        V(f"v_exp_f32 {vr(T1)}, {vr(T1)}", w=[T1], r=[T1])
+        S("s_nop 0")
+        V(f"v_mul_f32 {vr(T1)}, {vr(D_)}, {vr(T1)}", w=[T1], r=[D_, T1])
+        V(f"v_cmp_gt_i32 vcc, {bound}, %[lane]")
+        S("s_nop 1")
+        S("s_mov_b64 exec, vcc")
+        S("s_nop 0")
+        ops.append(Op(f"ds_write_b32 %[vvec], {vr(T1)} offset:{VEC_WS + 4 * woff}", "lds_nc", r=[f"v{T1}"]))
+        S("s_mov_b64 exec, -1")
+    ops.append(Op(f".Lhs_prep_nostd{uid}_%=:", "label", cost=0))
+    for o in ops[k0:-1]: o.glue = True
+    return ops
+
 
 
 class Task:
@@ -688,6 +879,7 @@ def gen_step():
                 if j + 2 < len(grp): sops.append(sd_read(grp[j + 2]))
                 tasks.append(Task(f"st{k}", sops, after=114, prio=pri))
                 pri += 1
+        tasks.append(Task("prep", prep_ops("r" if reset else "n"), after=111, prio=150))
         va = sum(op.cost for t in tasks for op in t.ops)
         schedule(em, mf, tasks, budget=va / len(mf) + 1.0, first_index=110, stamps={150: 8})
         stamp(em, 9)
@@ -721,7 +913,7 @@ def gen_step():
 
 def clobbers():
     c = ["memory", "vcc", "scc"]
-    c += [f"s{i}" for i in range(80, 94)]
+    c += [f"s{i}" for i in range(72, 100)]
     c += [f"v{i}" for i in range(V0, 256)]
     c += [f"a{i}" for i in range(256)]
     return c
