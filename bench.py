@@ -40,7 +40,7 @@ HBM_PEAK_GBS = 8000.0                                      # MI355X_MICROARCH.md
 
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0                             # dense bf16, MI355X_MICROARCH.md
-SCAN_SOURCES = ("ssd_head.hip", "ssd_slice.hip", "ssd_correct.hip", "ssd_scan.hip", "ssd_common.hpp", "conv1d.hip")
+SCAN_SOURCES = ("ssd_head.hip", "ssd_head_step.inc", "ssd_slice.hip", "ssd_correct.hip", "ssd_scan.hip", "ssd_common.hpp", "conv1d.hip")
 
 
 def scan_bytes_per_token(cfg) -> int:
@@ -169,9 +169,10 @@ class OpTimers:
             else:
                 src = (f"profiles/{files[-1].name} was taken on other scan kernels (source id "
                        f"{tf.get('scan_source_id')}, tree {scan_source_id()}): re-run devtools/pmc_scan.sh")
-        return {"bound": "hbm", "kernel": "ssd_scan (tv_ssd_scan_cb_fwd: ssd_head_kernel<5,4,2> head-per-wave march x 8-16 "
-                                          "sequence segments (floating, reset and standard steps in the one kernel) + "
-                                          "ssd_seg_chain + ssd_decay_prefix + ssd_correct kernels)",
+        return {"bound": "hbm", "kernel": "ssd_scan (tv_ssd_scan_cb_fwd: ssd_head_asm_kernel — head-per-wave march, the 64-token step one "
+                                          "generated, hand-scheduled instruction stream (csrc/ssd_head_step.inc) — x 8-16 sequence "
+                                          "segments (floating, reset and standard steps) + ssd_dt_transpose + ssd_seg_chain + "
+                                          "ssd_decay_prefix + ssd_correct kernels)",
                 "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "traffic_source": src, "launches": len(r),
                 "avg_launch_us": round(ms * 1e3 / len(r), 1), "bytes_per_token": bytes_per_token}

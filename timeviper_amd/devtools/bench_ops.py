@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--token-major", action="store_true", help="B/C as column slices of the conv rows")
     ap.add_argument("--model-dt", action="store_true", help="dt_bias / dt as in the 9B model's init (slowly forgetting heads)")
     ap.add_argument("--dt-std", type=float, default=0.02, help="with --model-dt: standard deviation of the raw dt (the synthetic 9B model: ~1.3)")
+    ap.add_argument("--model-A", action="store_true", help="A = -(1 .. H) as the 9B model's A_log init (modeling_nano.py): fast-forgetting heads, standard steps")
     ap.add_argument("--no-cb", action="store_true", help="scan recomputes C.B^T in its pre-pass (round 2)")
     a = ap.parse_args()
     L = a.tokens
@@ -65,6 +66,8 @@ def main():
             print(f"conv1d xbc  {ms*1e3:9.1f} us  {by/ms/1e6:8.1f} GB/s  ({by/ms/1e6/8000:.1%} of 8 TB/s)"
                   f"  {'+ C.B^T fragments' if cb is not None else ''}")
         A = -(torch.rand(H, device=dev, generator=g) * 15 + 1)
+        if a.model_A:
+            A = -torch.arange(1, H + 1, device=dev, dtype=torch.float32)
         D = torch.ones(H, device=dev)
         if a.model_dt:      # the 9B model's initialisation (modeling_nano.py:1345-1357): dt in [1e-3, 0.1], slow heads exist
             dtv = torch.exp(torch.rand(H, device=dev, generator=g) * (math.log(0.1) - math.log(1e-3)) + math.log(1e-3))

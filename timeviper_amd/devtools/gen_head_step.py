@@ -675,6 +675,9 @@ def gen_rebase(em):
     em.raw(".Lhs_norebase_%=:", 0)
 
 
+REGION_STATS = {}
+
+
 def gen_step():
     em = Emitter()
     em.raw("s_nop 4", 5)
@@ -700,6 +703,7 @@ def gen_step():
     for ct in range(PT):
         for op in snap_ops(0, ct, SB[0][ct], T8): em.emit(op)
 
+    REGION_STATS["preamble"] = dict(em.stats)
     stamp(em, 1)
 
     def b_read_ops(m):
@@ -799,16 +803,20 @@ def gen_step():
     em.raw("s_cbranch_scc1 .Lhs_pa_rs_%=")
     emR, emS = fork(em), fork(em)
     em.uid, emR.uid, emS.uid = "f", "r", "s"
+    base = dict(em.stats)
     phase_a(em, "F")
+    REGION_STATS["phase A, floating step"] = {k: v - base.get(k, 0) for k, v in em.stats.items()}
     em.raw("s_branch .Lhs_pa_join_%=")
     emR.raw(".Lhs_pa_rs_%=:", 0)
     emR.raw(f"s_bitcmp1_b32 %[flags], {FLAG_STD}")
     emR.raw("s_cbranch_scc1 .Lhs_pa_s_%=")
     emS.pos, emS.lines = emR.pos, []
     phase_a(emR, "R")
+    REGION_STATS["phase A, reset step"] = {k: v - base.get(k, 0) for k, v in emR.stats.items()}
     emR.raw("s_branch .Lhs_pa_join_%=")
     emS.raw(".Lhs_pa_s_%=:", 0)
     phase_a(emS, "S")
+    REGION_STATS["phase A, standard step (both paths of the four row-factor groups counted: 60 + 20 each)"] = {k: v - base.get(k, 0) for k, v in emS.stats.items()}
     assert em.vm_seq == emR.vm_seq == emS.vm_seq and em.lds_seq == em.lds_done, (em.vm_seq, emR.vm_seq, emS.vm_seq)
     em.lines += emR.lines + emS.lines
     em.raw(".Lhs_pa_join_%=:", 0)
@@ -888,7 +896,9 @@ def gen_step():
     em.raw(f"s_bitcmp1_b32 %[flags], {FLAG_RESET}")
     em.raw("s_cbranch_scc1 .Lhs_pb_reset_%=")
     base_state = copy.deepcopy({k: v for k, v in em.__dict__.items() if k != "lines"})
+    base_b = dict(em.stats)
     phase_b(em, False)
+    REGION_STATS["phase B (state update + y epilogue + the next chunk's vectors; a standard chunk's 42 extra counted)"] = {k: v - base_b.get(k, 0) for k, v in em.stats.items()}
     em.raw("s_branch .Lhs_pb_join_%=")
     end_state = {k: v for k, v in em.__dict__.items() if k != "lines"}
     em2 = Emitter()
@@ -919,6 +929,16 @@ def clobbers():
     return c
 
 
+def summary():
+    """static instruction counts per region of the generated body (`--summary`; profiles/r05_ssd_head_isa.md)"""
+    rows = []
+    for name, st in REGION_STATS.items():
+        valu = st.get("valu", 0) + st.get("perm", 0)
+        rows.append(f"| {name} | {st.get('mfma', 0)} | {valu} | {st.get('lds', 0) + st.get('lds_nc', 0)} | {st.get('vmem', 0) + st.get('dma', 0) + st.get('store', 0)} | "
+                    f"{st.get('salu', 0)} | {st.get('nop', 0)} |")
+    return "\n".join(["| region | MFMA | vector ALU | LDS | vector memory | scalar | inserted wait states |", "|---|---:|---:|---:|---:|---:|---:|"] + rows)
+
+
 def main():
     global STAMPS
     STAMPS = "--stamps" in sys.argv
@@ -927,6 +947,9 @@ def main():
     global NOSTORE
     NOSTORE = "--nostore" in sys.argv
     em = gen_step()
+    if "--summary" in sys.argv:
+        print(summary())
+        return
     lines = em.lines
     print("// generated by timeviper_amd/devtools/gen_head_step.py — do not edit")
     print(f"// {sum(1 for l in lines if l.startswith('v_mfma'))} MFMA lines (phase B twice), {len(lines)} lines; emitter stats {em.stats}")
