@@ -116,12 +116,11 @@ class Emitter:
 
     def emit(self, op):
         # memory waits
-        for t in op.lds_use:
-            i = self.lds_idx[t]
-            if self.lds_done <= i:
-                n = min(self.lds_seq - 1 - i, 15)
-                self.raw(f"s_waitcnt lgkmcnt({n})")
-                self.lds_done = self.lds_seq - n
+        pend = [self.lds_idx[t] for t in op.lds_use if self.lds_done <= self.lds_idx[t]]
+        if pend:                       # one wait for the youngest of the operations this instruction needs
+            n = min(self.lds_seq - 1 - max(pend), 15)
+            self.raw(f"s_waitcnt lgkmcnt({n})")
+            self.lds_done = self.lds_seq - n
         for t in op.vm_use:
             i = self.vm_idx[t]
             if self.vm_done <= i:
@@ -877,13 +876,9 @@ def gen_step():
                     sops.append(Op(f"s_addc_u32 s{S_Y + 1}, s{S_Y + 1}, 0", "salu"))
                 sops.append(Op(f"s_sub_i32 s{S_T}, %[rem], {6 * k}", "salu"))
                 sops.append(Op(f"s_min_i32 s{S_T}, s{S_T}, 6", "salu"))
-                sops.append(Op(f"v_cmp_gt_i32 vcc, s{S_T}, %[lrow]", "valu", glue=True))
-                sops.append(Op("s_nop 1", "salu", glue=True))
-                sops.append(Op("s_mov_b64 exec, vcc", "salu", glue=True, lds_use=[f"sd{k}"]))
-                sops.append(Op("s_nop 0", "salu", glue=True))
+                sops.append(Op(f"v_cmpx_gt_i32 vcc, s{S_T}, %[lrow]", "valu", glue=True, lds_use=[f"sd{k}"]))      # EXEC = rows of this store inside the sequence
                 if not NOSTORE: sops.append(Op(f"global_store_dwordx4 %[yst], {vr(SD[k & 1], 4)}, s[{S_Y}:{S_Y + 1}]", "store", r=regs("v", SD[k & 1], 4), glue=True))
-                sops.append(Op("s_mov_b64 exec, -1", "salu", glue=True))
-                sops.append(Op("s_nop 0", "salu"))
+                sops.append(Op("s_mov_b64 exec, -1", "salu"))
                 if j + 2 < len(grp): sops.append(sd_read(grp[j + 2]))
                 tasks.append(Task(f"st{k}", sops, after=114, prio=pri))
                 pri += 1
