@@ -17,7 +17,10 @@
 // correction itself: work-groups (slot k of 64, head, batch) walk the chunks k, k+64, ... of their
 // head until the prefix underflows; per 64-token chunk C . S_in^T on MFMA 16x16x32 (S_in as bf16
 // B fragments in registers for the whole walk, like the march's state snapshot), scaled rows
-// through LDS, 16-byte read-modify-write of y.
+// through LDS, 16-byte read-modify-write of y.  The all-segments pass of the segmented march (tv_ssd_correct_all_launch)
+// does not launch that grid: its prefix kernel lists one walker per CPW chunks of each (head, boundary)'s horizon and
+// persistent work-groups take them off the list (ssd_correct_list_kernel) — no work-group is launched to find nothing
+// to do, and a head that forgets slowly gets up to 32 walkers instead of 6.
 #include <stdlib.h>
 #include "ssd_common.hpp"
 
@@ -26,6 +29,8 @@ using namespace ssdk;
 
 constexpr int CQ = 64;            // tokens per chunk
 constexpr int CN = 128;           // d_state
+constexpr int MAXW = 32;          // walkers per (head, range) of the all-segments pass, at most
+constexpr int CPW = 4;            // chunks of its horizon per walker (the 20 KB of S_in a walker loads: 14 % of what it moves)
 constexpr int CSLOTS = 64;        // work-groups per (batch, head): a head that never forgets is walked by all of them
                                   // (measured with 8: the slowest heads set the launch time, 808 us in the 9B model)
 // The walk of a head ends where the factor 2^(cs_t log2 e) has fallen below 2^-32: the term is then < 2.5e-10 of
@@ -48,6 +53,10 @@ struct CorrArgs {
   int64_t ysb, ysl, dsb, dsl, dsh, csb, csl, csg;      // dsh: elements between the heads of dt (1: token-major rows)
   int softplus, group_map;
   float dt_min, dt_max;
+  // the all-segments pass: a list of walkers (one per CPW chunks of a (head, range)'s horizon) built by the prefix kernel and
+  // taken from a counter by persistent work-groups; NULL: one work-group per (slot, head, range) of the grid
+  unsigned* items;
+  unsigned* counters;              // [0] items written, [1] items taken
 };
 
 __device__ __forceinline__ float disc_dt(const CorrArgs& a, float raw, int h) {
@@ -76,23 +85,29 @@ __global__ __launch_bounds__(64) void ssd_decay_prefix_kernel(CorrArgs a) {
   const float* t = a.tot + ((int64_t)b * a.H + h) * a.tot_stride + cbeg;
   float* p = a.pre + ((int64_t)b * a.H + h) * a.nchunks + cbeg;
   float carry = 0.f;
+  int hor = 0;                      // chunks whose factor has not underflowed (the prefix only decreases)
   for (int c0 = 0; c0 < nch; c0 += 64) {
     const float v = c0 + lane < nch ? t[c0 + lane] : 0.f;
     const float inc = wave_incl_scan_dpp(v);
-    if (c0 + lane < nch) p[c0 + lane] = carry + inc - v;
+    const float pv = carry + inc - v;
+    if (c0 + lane < nch) p[c0 + lane] = pv;
+    hor += __popcll(__ballot(c0 + lane < nch && !(pv < C_UNDERFLOW)));
     carry += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inc), 63));
+  }
+  if (a.items && nch > 0) {         // this (head, range)'s walkers onto the list: (range 11 bits | head 10 | walker 5 | walkers - 1 5)
+    const int nwalk = min(MAXW, max(1, (hor + CPW - 1) / CPW));
+    unsigned base = 0;
+    if (lane == 0) base = atomicAdd(&a.counters[0], (unsigned)nwalk);
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (lane < nwalk) a.items[base + lane] = ((unsigned)blockIdx.y << 20) | ((unsigned)h << 10) | ((unsigned)lane << 5) | (unsigned)(nwalk - 1);
   }
 }
 
-// grid (slots, H, B * nsegc), 256 threads.  PT = ceil(P / 16) column tiles.  Work-group `slot` of a (head, range)
-// walks the chunks slot, slot + gridDim.x, ... of its range.
+// One walker: chunks w, w + nwalk, ... of range (b, si) of head h, until the factor underflows.
 template <int PT>
-__global__ __launch_bounds__(256) void ssd_correct_kernel(CorrArgs a) {
+__device__ __forceinline__ void correct_walk(const CorrArgs& a, const int h, const int b, const int si, const int nbatch,
+                                             const int w, const int nslots, float* ef, float* tile) {
   constexpr int LDW = PT * 16 + 4;                  // padded fp32 row of the staging tile
-  __shared__ float ef[CQ];
-  __shared__ __attribute__((aligned(16))) float tile[CQ * LDW];
-  const int h = blockIdx.y, b = blockIdx.z / a.nsegc, si = blockIdx.z % a.nsegc;
-  const int nslots = gridDim.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lc = lane & 15, kq = lane >> 4;
   const int hpg = a.H / a.G;
@@ -100,14 +115,14 @@ __global__ __launch_bounds__(256) void ssd_correct_kernel(CorrArgs a) {
   const int cbeg = (si + a.first_seg) * a.seg_chunks;          // first chunk / token of the range
   const int tbeg = cbeg * CQ;
   const int nch = min(a.seg_chunks, a.nchunks - cbeg);
-  if (nch <= 0 || (int)blockIdx.x >= nch) return;
+  if (nch <= 0 || w >= nch) return;
   const int L = min(a.L - tbeg, nch * CQ);
   const float* pre = a.pre + ((int64_t)b * a.H + h) * a.nchunks + cbeg;
-  if (pre[blockIdx.x] < C_UNDERFLOW) return;
+  if (pre[w] < C_UNDERFLOW) return;
 
   // S_in as B operand: lane (col lc, kq) of tile ct, k-step ks holds S[p = 16 ct + lc][n = 32 ks + 8 kq + 0..7]
   bf16x8 sf[PT][4];
-  const int64_t sbase = (((int64_t)si * (gridDim.z / a.nsegc) + b) * a.H + h) * a.P * CN;
+  const int64_t sbase = (((int64_t)si * nbatch + b) * a.H + h) * a.P * CN;
 #pragma unroll
   for (int ct = 0; ct < PT; ++ct) {
     const int p = 16 * ct + lc;
@@ -150,8 +165,8 @@ __global__ __launch_bounds__(256) void ssd_correct_kernel(CorrArgs a) {
   };
   bf16x8 cf[4], cfn[4];
   float draw, drawn = 0.f, p0, p0n = 0.f;
-  fetch(blockIdx.x, cf, draw, p0);
-  for (int c = blockIdx.x; c < nch; c += nslots) {
+  fetch(w, cf, draw, p0);
+  for (int c = w; c < nch; c += nslots) {
     if (p0 < C_UNDERFLOW) break;                     // the prefix only decreases: nothing left for this head
     const int t0 = c * CQ;
     const bool more = c + nslots < nch;
@@ -205,6 +220,37 @@ __global__ __launch_bounds__(256) void ssd_correct_kernel(CorrArgs a) {
   }
 }
 
+// grid (slots, H, B * nsegc), 256 threads.  PT = ceil(P / 16) column tiles.  Work-group `slot` of a (head, range)
+// walks the chunks slot, slot + gridDim.x, ... of its range.
+template <int PT>
+__global__ __launch_bounds__(256) void ssd_correct_kernel(CorrArgs a) {
+  __shared__ float ef[CQ];
+  __shared__ __attribute__((aligned(16))) float tile[CQ * (PT * 16 + 4)];
+  correct_walk<PT>(a, blockIdx.y, blockIdx.z / a.nsegc, blockIdx.z % a.nsegc, gridDim.z / a.nsegc, blockIdx.x, gridDim.x, ef, tile);
+}
+
+// The all-segments pass: persistent work-groups take walkers off the list the prefix kernel wrote.  A grid of
+// (slots, heads, boundaries) work-groups paid ~10 ns per work-group that found nothing to do — 5 376 of them at 6 slots,
+// 55 us a call where every head forgets within a chunk — and left a head that forgets slowly to 6 walkers of 50 chunks
+// each while the rest of the chip idled (202 us a launch inside the 9B forward, whose tokens are correlated).
+template <int PT>
+__global__ __launch_bounds__(256) void ssd_correct_list_kernel(CorrArgs a, int nbatch) {
+  __shared__ float ef[CQ];
+  __shared__ __attribute__((aligned(16))) float tile[CQ * (PT * 16 + 4)];
+  __shared__ unsigned next;
+  const unsigned nitems = a.counters[0];
+  for (;;) {
+    __syncthreads();                                 // the previous walker's LDS reads are done
+    if (threadIdx.x == 0) next = atomicAdd(&a.counters[1], 1u);
+    __syncthreads();
+    const unsigned i = next;
+    if (i >= nitems) return;
+    const unsigned it = a.items[i];
+    const int z = (int)(it >> 20), h = (int)((it >> 10) & 1023u), w = (int)((it >> 5) & 31u), nwalk = (int)(it & 31u) + 1;
+    correct_walk<PT>(a, h, z / a.nsegc, z % a.nsegc, nbatch, w, nwalk, ef, tile);
+  }
+}
+
 // Chain of the per-segment results of a segmented march (segments > 0 marched from a zero state):
 //   run = seg_state[0];  for s >= 1:  S_in(s) = run (stored as bf16: the correction's MFMA operand);
 //   run = exp(decay[s]) run + seg_state[s];  final state = run;  total decay = sum of the segments'
@@ -212,8 +258,9 @@ __global__ __launch_bounds__(256) void ssd_seg_chain_kernel(const float* __restr
                                                             const float* __restrict__ seg_decay,
                                                             bf16_t* __restrict__ sin16, float* __restrict__ final_state,
                                                             float* __restrict__ total_decay, int nseg,
-                                                            int64_t bh, int64_t per_head) {
+                                                            int64_t bh, int64_t per_head, unsigned* __restrict__ counters) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;      // float4 index
+  if (counters && i < 2) counters[i] = 0;                         // the walker list of the correction pass (filled by the next launch)
   const int64_t n4 = bh * per_head / 4;
   if (i < n4) {
     const int64_t head = (i * 4) / per_head;
@@ -236,6 +283,21 @@ __global__ __launch_bounds__(256) void ssd_seg_chain_kernel(const float* __restr
 
 template <int PT> void launch_correct(const CorrArgs& a, dim3 grid, hipStream_t st) {
   ssd_correct_kernel<PT><<<grid, 256, 0, st>>>(a);
+}
+template <int PT> void launch_correct_list(const CorrArgs& a, int nwg, int nbatch, hipStream_t st) {
+  ssd_correct_list_kernel<PT><<<dim3(nwg), 256, 0, st>>>(a, nbatch);
+}
+void launch_correct_list_pt(const CorrArgs& a, int nwg, int nbatch, int headdim, hipStream_t st) {
+  switch ((headdim + 15) / 16) {
+    case 1: launch_correct_list<1>(a, nwg, nbatch, st); break;
+    case 2: launch_correct_list<2>(a, nwg, nbatch, st); break;
+    case 3: launch_correct_list<3>(a, nwg, nbatch, st); break;
+    case 4: launch_correct_list<4>(a, nwg, nbatch, st); break;
+    case 5: launch_correct_list<5>(a, nwg, nbatch, st); break;
+    case 6: launch_correct_list<6>(a, nwg, nbatch, st); break;
+    case 7: launch_correct_list<7>(a, nwg, nbatch, st); break;
+    default: launch_correct_list<8>(a, nwg, nbatch, st); break;
+  }
 }
 void launch_correct_pt(const CorrArgs& a, dim3 grid, int headdim, hipStream_t st) {
   switch ((headdim + 15) / 16) {
@@ -280,6 +342,7 @@ int tv_ssd_correct_launch(void* y, const void* dt, const void* A, const void* Cm
   a.softplus = dt_softplus; a.group_map = group_map; a.dt_min = dt_min; a.dt_max = dt_max;
   a.tot_stride = a.nchunks;
   a.state16 = nullptr;
+  a.items = nullptr; a.counters = nullptr;
   a.nsegc = 1; a.first_seg = 0; a.seg_chunks = a.nchunks;
   if (chunk_tot) {
     a.tot = const_cast<float*>(chunk_tot);
@@ -296,9 +359,11 @@ int tv_ssd_correct_launch(void* y, const void* dt, const void* A, const void* Cm
 // (ssd_head.hip) cuts a sequence into up to 16 segments; one launch per boundary cost a fixed ~140 us each
 // (every one of 64 x heads work-groups loading the 40 KB fp32 state before looking at its first chunk).
 size_t tv_ssd_correct_all_workspace_bytes(int batch, int nheads, int nchunks, int nseg, int headdim) {
-  // pre (B, H, nchunks) fp32 + S_in of the nseg - 1 boundaries as bf16
+  // pre (B, H, nchunks) fp32 + S_in of the nseg - 1 boundaries as bf16 + the walker list (MAXW per head and boundary) + its counters
+  const size_t nb = (size_t)(nseg > 1 ? nseg - 1 : 0);
   return ((size_t)batch * nheads * nchunks * sizeof(float) + 255) / 256 * 256 +
-         (size_t)(nseg > 1 ? nseg - 1 : 0) * batch * nheads * headdim * CN * sizeof(bf16_t);
+         (nb * batch * nheads * headdim * CN * sizeof(bf16_t) + 255) / 256 * 256 +
+         nb * batch * nheads * MAXW * sizeof(unsigned) + 256;
 }
 
 int tv_ssd_correct_all_launch(void* y, const void* dt, const void* A, const void* Cm, const void* dt_bias,
@@ -315,6 +380,12 @@ int tv_ssd_correct_all_launch(void* y, const void* dt, const void* A, const void
   a.pre = (float*)workspace;
   bf16_t* sin16 = (bf16_t*)((unsigned char*)workspace + ((size_t)batch * nheads * a.nchunks * sizeof(float) + 255) / 256 * 256);
   a.state16 = sin16;
+  {
+    const size_t nb = (size_t)(nseg > 1 ? nseg - 1 : 0);
+    unsigned char* after = (unsigned char*)sin16 + (nb * batch * nheads * headdim * CN * sizeof(bf16_t) + 255) / 256 * 256;
+    a.items = (unsigned*)after;
+    a.counters = (unsigned*)(after + nb * batch * nheads * MAXW * sizeof(unsigned));
+  }
   a.tot = const_cast<float*>(chunk_tot);
   a.tot_stride = a.nchunks;
   a.ysb = ysb; a.ysl = ysl; a.dsb = dsb; a.dsl = dsl; a.dsh = dsh; a.csb = csb; a.csl = csl; a.csg = csg;
@@ -325,15 +396,23 @@ int tv_ssd_correct_all_launch(void* y, const void* dt, const void* A, const void
   const int64_t bh = (int64_t)batch * nheads, per_head = (int64_t)headdim * CN;
   const int64_t n4 = bh * per_head / 4;
   ssd_seg_chain_kernel<<<dim3((unsigned)((n4 + 255) / 256)), 256, 0, st>>>(seg_state, seg_decay, sin16, final_state,
-                                                                         total_decay, nseg, bh, per_head);
+                                                                         total_decay, nseg, bh, per_head, a.counters);
   if (nsegc > 0) {
     ssd_decay_prefix_kernel<<<dim3(nheads, batch * nsegc), 64, 0, st>>>(a);
-    // work-groups per (head, boundary): every one of them loads the 20 KB of S_in, most leave at once (the carried-in
-    // term has underflowed).  Whole scan at 163 940 / 32 868 tokens, bench-like dt: 1: 2 560 / 754 us, 2: 2 507 / 706,
-    // 4: 2 454 / 694, 6: 2 458 / 681, 8: 2 499 / 699, 16: 2 613 / 785, 32: 2 827 / 961; slowly decaying dt: 6 is best
-    int slots = seg_chunks < 6 ? seg_chunks : 6;
-    if (const char* e = getenv("TV_CORR_SLOTS")) slots = atoi(e) > 0 ? atoi(e) : slots;      // dev tool
-    launch_correct_pt(a, dim3(slots, nheads, batch * nsegc), headdim, st);
+    // walkers: one per CPW chunks of a (head, boundary)'s horizon (at most MAXW), listed by the prefix kernel, taken off the list by
+    // persistent work-groups (4 per CU).  TV_CORR_SLOTS = n (dev tool): the round-3 grid of n work-groups per (head, boundary)
+    // instead (whole scan at 163 940 / 32 868 tokens, bench-like dt, on that grid: 1: 2 560 / 754 us, 4: 2 454 / 694, 6: 2 458 / 681,
+    // 8: 2 499 / 699, 16: 2 613 / 785, 32: 2 827 / 961).
+    int slots = 0;
+    if (const char* e = getenv("TV_CORR_SLOTS")) slots = atoi(e);
+    if (slots > 0) {
+      CorrArgs g = a;
+      g.items = nullptr;
+      launch_correct_pt(g, dim3(slots < seg_chunks ? slots : seg_chunks, nheads, batch * nsegc), headdim, st);
+    } else {
+      const int64_t maxitems = (int64_t)batch * nsegc * nheads * MAXW;
+      launch_correct_list_pt(a, (int)(maxitems < 1024 ? maxitems : 1024), batch, headdim, st);
+    }
   }
   TV_LAUNCH_CHECK();
 }
