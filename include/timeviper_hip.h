@@ -249,6 +249,10 @@ int tv_ssd_state_correction(void* y, const void* dt, const void* A, const void* 
 void tv_ssd_scan_set_impl(int impl);
 /* kernel family (same numbers) the most recent scan call of this process ran on; 0 before the first call */
 int tv_ssd_scan_last_impl(void);
+/* Implementation 6 at head_dim 80 with 4 heads per work-group (the Nano-9B shape): 1 = the 64-token step as the
+ * generated instruction stream (csrc/ssd_head_step.inc; default), 0 = the C++ step, -1 = back to the default /
+ * the environment's TV_HEAD_ASM.  Same results bit for bit (tests/test_ops_gpu.py); process-global, for A/B runs. */
+void tv_ssd_head_set_asm(int on);
 
 /* Single-token decode step, replaces selective_state_update (:528-539) with
  * the head-broadcast arguments the reference passes (A,D,dt_bias per head). */

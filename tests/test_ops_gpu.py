@@ -267,6 +267,46 @@ def test_ssd_scan_decay_regimes(K, impl, regime, a_lo, a_hi, dt_mean, dt_std):
     close(dec, dec_ref, 1e-4, 1e-4 * max(1.0, float(dec_ref.abs().max())), "total decay")
 
 
+@pytest.mark.parametrize("regime,a_lo,a_hi,dt_mean,dt_std,L", [
+    ("slow", 0.05, 0.3, -1.0, 0.5, 2600),                  # floating steps, re-basing
+    ("at the reset threshold", 0.9, 1.1, 0.0, 0.05, 2600),
+    ("at the standard threshold", 2.9, 3.2, 0.0, 0.05, 2600),
+    ("model-like, wide", 1.0, 16.0, 0.0, 1.3, 4133),        # every step kind mixed inside a work-group; ragged last chunk
+    ("violent", 50.0, 200.0, 1.0, 2.0, 1999),               # standard steps only, t-tiles whose row factors underflow
+    ("token spikes", 0.01, 0.05, -2.0, 4.0, 2600),
+])
+def test_ssd_head_generated_step_is_bit_identical_to_the_cpp_step(K, regime, a_lo, a_hi, dt_mean, dt_std, L):
+    """The 64-token step of the head-per-wave march at head_dim 80 x 4 heads per work-group runs as one generated instruction
+    stream (csrc/ssd_head_step.inc); `ssd_head_kernel<5,4,2>` is the same arithmetic in the same order per accumulator written
+    in C++.  y, the final state and the decay total must agree bit for bit in every step kind (tv_ssd_head_set_asm)."""
+    B, H, P, G, N = 1, 16, 80, 2, 128
+    g = torch.Generator().manual_seed(7 + len(regime))
+    x = torch.randn(B, L, H, P, generator=g).to(torch.bfloat16)
+    dt = (torch.randn(B, L, H, generator=g) * dt_std + dt_mean).to(torch.bfloat16)
+    A = -(torch.rand(H, generator=g) * (a_hi - a_lo) + a_lo)
+    Bm = (torch.randn(B, L, G, N, generator=g) * 0.5).to(torch.bfloat16)
+    Cm = (torch.randn(B, L, G, N, generator=g) * 0.5).to(torch.bfloat16)
+    D = torch.rand(H, generator=g) + 0.5
+    ins = (x, dt, A, Bm, Cm, D, torch.zeros(H))
+    init = torch.randn(B, H, P, N, generator=g).to(DEV)
+    outs = []
+    K.ssd_scan_set_impl(6)
+    try:
+        for on in (1, 0):
+            K.ssd_head_set_asm(on)
+            y, fin, dec = run_scan(K, *ins, initial_states=init)
+            assert K.ssd_scan_last_impl() == 6
+            outs.append((y.clone(), fin.clone(), dec.clone()))
+    finally:
+        K.ssd_head_set_asm(-1)
+        K.ssd_scan_set_impl(0)
+    (y1, f1, d1), (y0, f0, d0) = outs
+    assert torch.isfinite(y1.float()).all()
+    assert torch.equal(y1, y0), (regime, (y1.float() - y0.float()).abs().max().item())
+    assert torch.equal(f1, f0), (regime, (f1 - f0).abs().max().item())
+    assert torch.equal(d1, d0), regime
+
+
 def test_ssd_scan_golden_and_group_maps(K):
     for tag, gmap in [("g1", "block"), ("g2_tile", "tile"), ("g4_tile", "tile")]:
         g = load_golden(f"mixer_{tag}")

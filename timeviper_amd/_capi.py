@@ -40,6 +40,7 @@ SIGNATURES = {
     "tv_ssd_state_correction": (_i, [_p] * 6 + [_i] * 6 + [_l] * 7 + [_i, _i, _f, _f, _i, _p, _z, _p]),
     "tv_ssd_scan_set_impl": (None, [_i]),
     "tv_ssd_scan_last_impl": (_i, []),
+    "tv_ssd_head_set_asm": (None, [_i]),
     "tv_selective_state_update": (_i, [_p] * 9 + [_i] * 7 + [_p]),
     "tv_gemm_bf16_fwd": (_i, [_p, _p, _p, _p, _l, _i, _i, _l, _l, _l, _i, _i, _p]),
     "tv_gemm_set_persist": (None, [_i, _i]),
@@ -73,7 +74,7 @@ class TimeViperHipError(RuntimeError):
     pass
 
 
-ABI_VERSION = 11      # tv_abi_version() of the library these SIGNATURES describe (csrc/capi.cpp)
+ABI_VERSION = 12      # tv_abi_version() of the library these SIGNATURES describe (csrc/capi.cpp)
 
 
 def lib_path() -> Path:

@@ -12,7 +12,7 @@ void tv_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int tv_abi_version(void) { return 11; }
+extern "C" int tv_abi_version(void) { return 12; }
 extern "C" const char* tv_last_error(void) { return g_err; }
 #ifndef TV_BUILD_ID
 #define TV_BUILD_ID "unknown"

@@ -154,7 +154,7 @@ __device__ __forceinline__ void correct_walk(const CorrArgs& a, const int h, con
   // round trip to memory instead of three in a row (C -> MFMA -> y read -> y write; round 2: 80 % of the
   // wave-cycles of this kernel were parked).
   constexpr int NY = (CQ * 2 * PT + 255) / 256;      // y pieces per thread (rows of at most 16 PT columns)
-  auto fetch = [&](int c, bf16x8 (&cf)[4], float& draw, float& p0) {
+  auto fetch = [&](int c, bf16x8 (&cf)[4], bf16x8 (&yv)[NY], float& draw, float& p0) {
     const int t0 = c * CQ;
     const int trow = min(t0 + 16 * wave + lc, L - 1);         // rows past the end repeat the last row: finite
 #pragma unroll
@@ -162,21 +162,20 @@ __device__ __forceinline__ void correct_walk(const CorrArgs& a, const int h, con
     const int t = t0 + lane;
     draw = (wave == 0 && t < L) ? (float)dp[(int64_t)t * a.dsl] : 0.f;
     p0 = pre[c];
+#pragma unroll
+    for (int k = 0; k < NY; ++k) {       // the y rows this chunk's term is added to (requested a chunk ahead, like C)
+      const int i = tid + 256 * k, row = i / nvec, ch = i % nvec;
+      if (i < CQ * nvec && t0 + row < L) yv[k] = *(const bf16x8*)(yp + (int64_t)(t0 + row) * a.ysl + 8 * ch);
+    }
   };
-  bf16x8 cf[4], cfn[4];
+  bf16x8 cf[4], cfn[4], yv[NY], yvn[NY];
   float draw, drawn = 0.f, p0, p0n = 0.f;
-  fetch(w, cf, draw, p0);
+  fetch(w, cf, yv, draw, p0);
   for (int c = w; c < nch; c += nslots) {
     if (p0 < C_UNDERFLOW) break;                     // the prefix only decreases: nothing left for this head
     const int t0 = c * CQ;
     const bool more = c + nslots < nch;
-    if (more) fetch(c + nslots, cfn, drawn, p0n);
-    bf16x8 yv[NY];
-#pragma unroll
-    for (int k = 0; k < NY; ++k) {
-      const int i = tid + 256 * k, row = i / nvec, ch = i % nvec;
-      if (i < CQ * nvec && t0 + row < L) yv[k] = *(const bf16x8*)(yp + (int64_t)(t0 + row) * a.ysl + 8 * ch);
-    }
+    if (more) fetch(c + nslots, cfn, yvn, drawn, p0n);
     if (wave == 0) {
       const float d = t0 + lane < L ? disc_dt(a, draw, h) : 0.f;
       const float cs = wave_incl_scan_dpp(d * Ah);
@@ -215,6 +214,8 @@ __device__ __forceinline__ void correct_walk(const CorrArgs& a, const int h, con
     }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) cf[ks] = cfn[ks];
+#pragma unroll
+    for (int k = 0; k < NY; ++k) yv[k] = yvn[k];
     draw = drawn;
     p0 = p0n;
   }

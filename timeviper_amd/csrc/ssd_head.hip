@@ -33,6 +33,7 @@
 // 192 bytes with the 32-byte pieces of rows 8..15 mod 16 swapped pairwise: conflict-free).
 // Reference semantics: mamba_chunk_scan_combined call modeling_nano.py:639-653; arithmetic :775-851.
 #include <stdlib.h>
+#include <atomic>
 #include <type_traits>
 #include "ssd_common.hpp"
 
@@ -1199,8 +1200,11 @@ __global__ __launch_bounds__(256) void ssd_dt_transpose_kernel(const bf16_t* __r
   }
 }
 
-// TV_HEAD_ASM=0 sends head_dim 80 x 4 heads back to the C++ step (A/B runs, dev only)
+// tv_ssd_head_set_asm(0) / TV_HEAD_ASM=0 sends head_dim 80 x 4 heads back to the C++ step (A/B runs, the bit-identity test)
+std::atomic<int> g_head_asm{-1};
 bool head_asm_enabled() {
+  const int f = g_head_asm.load(std::memory_order_relaxed);
+  if (f >= 0) return f != 0;
   static const bool on = [] { const char* e = getenv("TV_HEAD_ASM"); return !e || atoi(e) != 0; }();
   return on;
 }
@@ -1268,6 +1272,8 @@ extern "C" int tv_ssd_head_debug_stamps(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_head_phases), sizeof(g_head_phases));
 }
 #endif
+
+extern "C" void tv_ssd_head_set_asm(int on) { g_head_asm.store(on, std::memory_order_relaxed); }
 
 bool tv_ssd_head_supported(int seqlen, int nheads, int headdim, int ngroups, int dstate, int dtype,
                            int64_t xsl, int64_t bsl, int64_t bsg, int64_t csl, int64_t csg, int64_t ysl,

@@ -445,6 +445,12 @@ def ssd_scan_set_impl(impl: int) -> None:
     _capi.lib().tv_ssd_scan_set_impl(int(impl))
 
 
+def ssd_head_set_asm(on: int) -> None:
+    """Head-per-wave march at head_dim 80 x 4 heads per work-group: 1 the generated step (default), 0 the C++ step, -1 default /
+    TV_HEAD_ASM.  Process-global (A/B runs and the bit-identity test)."""
+    _capi.lib().tv_ssd_head_set_asm(int(on))
+
+
 def ssd_scan_last_impl() -> int:
     """Kernel family (the numbers of `ssd_scan_set_impl`) the most recent scan call of this process ran on."""
     return int(_capi.lib().tv_ssd_scan_last_impl())
