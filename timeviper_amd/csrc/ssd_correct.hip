@@ -77,9 +77,10 @@ __global__ __launch_bounds__(256) void ssd_chunk_decay_kernel(CorrArgs a) {
   if (lane == 0) a.tot[((int64_t)b * a.H + h) * a.nchunks + c] = s * a.A[h] * 1.4426950408889634f;
 }
 
-// grid (H, B * nsegc), one wave: pre[b][h][c] = sum_{first chunk of c's range <= c' < c} tot[b][h][c']
-__global__ __launch_bounds__(64) void ssd_decay_prefix_kernel(CorrArgs a) {
-  const int h = blockIdx.x, b = blockIdx.y / a.nsegc, si = blockIdx.y % a.nsegc, lane = threadIdx.x;
+// one wave per (head h, range z = b * nsegc + si): pre[b][h][c] = sum_{first chunk of c's range <= c' < c} tot[b][h][c'], and
+// (all-segments pass) this (head, range)'s walkers onto the list
+__device__ __forceinline__ void decay_prefix_wave(const CorrArgs& a, const int h, const int z, const int lane) {
+  const int b = z / a.nsegc, si = z % a.nsegc;
   const int cbeg = (si + a.first_seg) * a.seg_chunks;
   const int nch = min(a.seg_chunks, a.nchunks - cbeg);
   const float* t = a.tot + ((int64_t)b * a.H + h) * a.tot_stride + cbeg;
@@ -94,13 +95,17 @@ __global__ __launch_bounds__(64) void ssd_decay_prefix_kernel(CorrArgs a) {
     hor += __popcll(__ballot(c0 + lane < nch && !(pv < C_UNDERFLOW)));
     carry += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inc), 63));
   }
-  if (a.items && nch > 0) {         // this (head, range)'s walkers onto the list: (range 11 bits | head 10 | walker 5 | walkers - 1 5)
+  if (a.items && nch > 0) {         // (range 11 bits | head 10 | walker 5 | walkers - 1 5)
     const int nwalk = min(MAXW, max(1, (hor + CPW - 1) / CPW));
     unsigned base = 0;
     if (lane == 0) base = atomicAdd(&a.counters[0], (unsigned)nwalk);
     base = __builtin_amdgcn_readfirstlane(base);
-    if (lane < nwalk) a.items[base + lane] = ((unsigned)blockIdx.y << 20) | ((unsigned)h << 10) | ((unsigned)lane << 5) | (unsigned)(nwalk - 1);
+    if (lane < nwalk) a.items[base + lane] = ((unsigned)z << 20) | ((unsigned)h << 10) | ((unsigned)lane << 5) | (unsigned)(nwalk - 1);
   }
+}
+// grid (H, B * nsegc), one wave (the stand-alone operator)
+__global__ __launch_bounds__(64) void ssd_decay_prefix_kernel(CorrArgs a) {
+  decay_prefix_wave(a, blockIdx.x, blockIdx.y, threadIdx.x);
 }
 
 // One walker: chunks w, w + nwalk, ... of range (b, si) of head h, until the factor underflows.
@@ -255,13 +260,10 @@ __global__ __launch_bounds__(256) void ssd_correct_list_kernel(CorrArgs a, int n
 // Chain of the per-segment results of a segmented march (segments > 0 marched from a zero state):
 //   run = seg_state[0];  for s >= 1:  S_in(s) = run (stored as bf16: the correction's MFMA operand);
 //   run = exp(decay[s]) run + seg_state[s];  final state = run;  total decay = sum of the segments'
-__global__ __launch_bounds__(256) void ssd_seg_chain_kernel(const float* __restrict__ seg_state,
-                                                            const float* __restrict__ seg_decay,
-                                                            bf16_t* __restrict__ sin16, float* __restrict__ final_state,
-                                                            float* __restrict__ total_decay, int nseg,
-                                                            int64_t bh, int64_t per_head, unsigned* __restrict__ counters) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;      // float4 index
-  if (counters && i < 2) counters[i] = 0;                         // the walker list of the correction pass (filled by the next launch)
+__device__ __forceinline__ void seg_chain_block(const float* __restrict__ seg_state, const float* __restrict__ seg_decay,
+                                                bf16_t* __restrict__ sin16, float* __restrict__ final_state,
+                                                float* __restrict__ total_decay, int nseg, int64_t bh, int64_t per_head,
+                                                const int64_t i) {             // i: float4 index
   const int64_t n4 = bh * per_head / 4;
   if (i < n4) {
     const int64_t head = (i * 4) / per_head;
@@ -279,6 +281,20 @@ __global__ __launch_bounds__(256) void ssd_seg_chain_kernel(const float* __restr
     float t = 0.f;
     for (int s = 0; s < nseg; ++s) t += seg_decay[(int64_t)s * bh + i];
     total_decay[i] = t;
+  }
+}
+// One launch for the two small passes between the march and the correction: blocks [0, nb_chain) chain the segment states, the
+// rest take four (head, range) pairs each and write their decay prefixes and walkers (a launch less per call: ~12 us of ~1 360
+// inside the 9B forward, of ~420 at 33 k tokens).  The list's counters are zeroed by the caller's FIRST launch (the dt transpose).
+__global__ __launch_bounds__(256) void ssd_chain_prefix_kernel(const float* __restrict__ seg_state, const float* __restrict__ seg_decay,
+                                                               bf16_t* __restrict__ sin16, float* __restrict__ final_state,
+                                                               float* __restrict__ total_decay, int nseg, int64_t bh,
+                                                               int64_t per_head, int nb_chain, CorrArgs a, int npairs) {
+  if ((int)blockIdx.x < nb_chain) {
+    seg_chain_block(seg_state, seg_decay, sin16, final_state, total_decay, nseg, bh, per_head, (int64_t)blockIdx.x * 256 + threadIdx.x);
+  } else {
+    const int pair = ((int)blockIdx.x - nb_chain) * 4 + (int)(threadIdx.x >> 6);
+    if (pair < npairs) decay_prefix_wave(a, pair % a.H, pair / a.H, threadIdx.x & 63);
   }
 }
 
@@ -367,6 +383,14 @@ size_t tv_ssd_correct_all_workspace_bytes(int batch, int nheads, int nchunks, in
          nb * batch * nheads * MAXW * sizeof(unsigned) + 256;
 }
 
+// the walker list's two counters inside `workspace` (zeroed by the caller before tv_ssd_correct_all_launch)
+unsigned* tv_ssd_correct_all_counters(void* workspace, int batch, int nheads, int nchunks, int nseg, int headdim) {
+  const size_t nb = (size_t)(nseg > 1 ? nseg - 1 : 0);
+  unsigned char* sin16 = (unsigned char*)workspace + ((size_t)batch * nheads * nchunks * sizeof(float) + 255) / 256 * 256;
+  unsigned char* after = sin16 + (nb * batch * nheads * headdim * CN * sizeof(bf16_t) + 255) / 256 * 256;
+  return (unsigned*)(after + nb * batch * nheads * MAXW * sizeof(unsigned));
+}
+
 int tv_ssd_correct_all_launch(void* y, const void* dt, const void* A, const void* Cm, const void* dt_bias,
                               const float* seg_state, const float* seg_decay, float* final_state,
                               float* total_decay, const float* chunk_tot, int batch, int seqlen, int nheads,
@@ -396,10 +420,11 @@ int tv_ssd_correct_all_launch(void* y, const void* dt, const void* A, const void
   a.nsegc = nsegc > 0 ? nsegc : 1; a.first_seg = 1; a.seg_chunks = seg_chunks;
   const int64_t bh = (int64_t)batch * nheads, per_head = (int64_t)headdim * CN;
   const int64_t n4 = bh * per_head / 4;
-  ssd_seg_chain_kernel<<<dim3((unsigned)((n4 + 255) / 256)), 256, 0, st>>>(seg_state, seg_decay, sin16, final_state,
-                                                                         total_decay, nseg, bh, per_head, a.counters);
+  const int nb_chain = (int)((n4 + 255) / 256);
+  const int npairs = nsegc > 0 ? nheads * batch * nsegc : 0;
+  ssd_chain_prefix_kernel<<<dim3((unsigned)(nb_chain + (npairs + 3) / 4)), 256, 0, st>>>(seg_state, seg_decay, sin16, final_state, total_decay,
+                                                                                      nseg, bh, per_head, nb_chain, a, npairs);
   if (nsegc > 0) {
-    ssd_decay_prefix_kernel<<<dim3(nheads, batch * nsegc), 64, 0, st>>>(a);
     // walkers: one per CPW chunks of a (head, boundary)'s horizon (at most MAXW), listed by the prefix kernel, taken off the list by
     // persistent work-groups (4 per CU).  TV_CORR_SLOTS = n (dev tool): the round-3 grid of n work-groups per (head, boundary)
     // instead (whole scan at 163 940 / 32 868 tokens, bench-like dt, on that grid: 1: 2 560 / 754 us, 4: 2 454 / 694, 6: 2 458 / 681,

@@ -43,6 +43,7 @@ int tv_ssd_cb_prepass_launch(const void* Bm, const void* Cm, void* cb, int batch
                              hipStream_t st);
 // ssd_correct.hip
 size_t tv_ssd_correct_all_workspace_bytes(int batch, int nheads, int nchunks, int nseg, int headdim);
+unsigned* tv_ssd_correct_all_counters(void* workspace, int batch, int nheads, int nchunks, int nseg, int headdim);
 int tv_ssd_correct_all_launch(void* y, const void* dt, const void* A, const void* Cm, const void* dt_bias,
                               const float* seg_state, const float* seg_decay, float* final_state,
                               float* total_decay, const float* chunk_tot, int batch, int seqlen, int nheads,
@@ -1165,7 +1166,9 @@ __global__ __launch_bounds__(256) void ssd_head_asm_kernel(HeadArgs a) {
 // the visits of the work-groups that want them and came from HBM 11 times over (profiles/r04_ssd_scan_read_attribution.json:
 // 0.48 GB of reads for 0.04 GB of dt at 164 k tokens).  grid (nchunks, B), 256 threads; tokens past L are written as zeros.
 __global__ __launch_bounds__(256) void ssd_dt_transpose_kernel(const bf16_t* __restrict__ dt, bf16_t* __restrict__ out, int L, int H,
-                                                               int64_t dsb, int64_t dsl, int64_t lp, int vec) {
+                                                               int64_t dsb, int64_t dsl, int64_t lp, int vec, unsigned* __restrict__ zero2) {
+  // (the first launch of a scan call also clears the two counters of the correction pass's walker list)
+  if (zero2 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 2) zero2[threadIdx.x] = 0;
   __shared__ __attribute__((aligned(16))) unsigned short tile[HQ][136];       // [token][head], rows of 272 bytes (16-byte multiple)
   const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const unsigned short* src = (const unsigned short*)dt + (int64_t)b * dsb;
@@ -1260,11 +1263,11 @@ hipError_t launch_head(const HeadArgs& a, dim3 grid, hipStream_t st) {
 
 // dt (B, L, H) -> head-major (B, H, 64 nchunks) for the march kernels of this file and of ssd_pair.hip
 void tv_ssd_dt_transpose_launch(const void* dt, void* out, int batch, int seqlen, int nheads, int64_t dsb, int64_t dsl,
-                                hipStream_t st) {
+                                unsigned* zero2, hipStream_t st) {
   const int nchunks = (seqlen + HQ - 1) / HQ;
   const int vec = (((uintptr_t)dt) & 15) == 0 && dsl % 8 == 0 && dsb % 8 == 0 && nheads % 8 == 0;
   ssd_dt_transpose_kernel<<<dim3(nchunks, batch), 256, 0, st>>>((const bf16_t*)dt, (bf16_t*)out, seqlen, nheads, dsb, dsl,
-                                                               (int64_t)nchunks * HQ, vec);
+                                                               (int64_t)nchunks * HQ, vec, zero2);
 }
 
 #ifdef TV_HEAD_STAMP
@@ -1320,7 +1323,8 @@ int tv_ssd_head_launch(const void* x, const void* dt, const void* A, const void*
   {
     const int64_t lp = (int64_t)a.nchunks * HQ;
     bf16_t* dtt = (bf16_t*)(wsb + lay.dtt);
-    tv_ssd_dt_transpose_launch(dt, dtt, batch, seqlen, nheads, dsb, dsl, st);
+    unsigned* counters = lay.nseg > 1 ? tv_ssd_correct_all_counters(wsb + lay.corr, batch, nheads, a.nchunks, lay.nseg, headdim) : nullptr;
+    tv_ssd_dt_transpose_launch(dt, dtt, batch, seqlen, nheads, dsb, dsl, counters, st);
     a.dt = dtt; dt = dtt;
     dsb = (int64_t)nheads * lp; dsl = 1; a.dsh = lp;
   }
