@@ -51,9 +51,6 @@ int tv_ssd_correct_all_launch(void* y, const void* dt, const void* A, const void
                               int64_t dsb, int64_t dsl, int64_t dsh, int64_t csb, int64_t csl, int64_t csg, int dt_softplus,
                               float dt_min, float dt_max, int group_map, void* workspace, hipStream_t st);
 
-#ifndef TV_HEAD_ASM_DEFAULT
-#define TV_HEAD_ASM_DEFAULT 1
-#endif
 #ifndef TV_HEAD_PIN
 #define TV_HEAD_PIN 0
 #endif
@@ -862,7 +859,6 @@ __global__ __launch_bounds__(NW * 64) void ssd_head_kernel(HeadArgs a) {
 #include "ssd_head_step.inc"
 #define TV_STEP_STAMP_OPS
 #endif
-#include "ssd_head_loop.inc"       // the same body inside the chunk loop: python devtools/gen_head_step.py --scalar --loop
 
 struct __attribute__((aligned(16))) HeadVecA {
   HeadVec v;
@@ -1093,6 +1089,7 @@ __global__ __launch_bounds__(256) void ssd_head_asm_kernel(HeadArgs a) {
     const unsigned flags = __builtin_amdgcn_readfirstlane(nflags | (copy ? 8u : 0u) | fl_const);
     const int sh = __builtin_amdgcn_readfirstlane(nsh);
     const unsigned vw2 = vw2_0 + (c & 1) * 256;       // (reset steps: Ydiag's weights, the old frame's)
+    const unsigned vev = (flags & 4u) ? vev_one : vev_ecs;
     const void* pcb = pcb_r; const void* py = py_r; const void* pdt = pdt_r;
     const void* pb = pb_r; const void* pc = pc_r; const void* px = px_r;
     pcb_r += CBE * 2; py_r += y_step; pb_r += b_step; pc_r += c_step; px_r += x_step;
@@ -1105,7 +1102,7 @@ __global__ __launch_bounds__(256) void ssd_head_asm_kernel(HeadArgs a) {
     asm volatile(TV_HEAD_STEP_ASM
                  : [dtout] "=&v"(dt_new), [oflags] "=&s"(o_flags), [osh] "=&s"(o_sh), [oe] "=&s"(o_e), [odtot] "=&s"(o_dtot), [ocl2] "=&s"(o_cl2) TV_STEP_STAMP_OPS
                  : [ca0] "v"(ca0), [ca1] "v"(ca1), [ca2] "v"(ca2), [ca3] "v"(ca3), [ba0] "v"(ba0), [ba1] "v"(ba1), [ba2] "v"(ba2), [ba3] "v"(ba3),
-                   [xtr] "v"(xtr), [xvr] "v"(xvr), [vw] "v"(vw_wts), [vw2] "v"(vw2), [veve] "v"(vev_ecs), [vevo] "v"(vev_one), [cbo] "v"(cbo), [yst] "v"(yst), [lrow] "v"(lrow), [xsr] "v"(xsr), [dto] "v"(dto),
+                   [xtr] "v"(xtr), [xvr] "v"(xvr), [vw] "v"(vw_wts), [vw2] "v"(vw2), [vev] "v"(vev), [cbo] "v"(cbo), [yst] "v"(yst), [lrow] "v"(lrow), [xsr] "v"(xsr), [dto] "v"(dto),
                    [ob0] "v"(ob0), [ob1] "v"(ob1), [ob2] "v"(ob2), [ob3] "v"(ob3), [oc0] "v"(oc0), [oc1] "v"(oc1), [oc2] "v"(oc2), [oc3] "v"(oc3),
                    [ox0] "v"(ox0), [ox1] "v"(ox1), [ox2] "v"(ox2), [ox3] "v"(ox3), [oxl] "v"(oxl),
                    [at] "v"(sa_t), [as] "v"(sa_s), [alc] "v"(sa_lc), [as15] "v"(sa_s15), [d0] "v"(sd0),
@@ -1164,271 +1161,6 @@ __global__ __launch_bounds__(256) void ssd_head_asm_kernel(HeadArgs a) {
   }
 }
 
-__global__ __launch_bounds__(256) void ssd_head_loop_kernel(HeadArgs a) {
-  typedef HeadSmemA Smem;
-  constexpr int PT = 5, NW = 4, NB = 2, P = 80, KP = 4;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  Smem& sm = *reinterpret_cast<Smem*>(smem_raw);
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lc = lane & 15, kq = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
-  const int b = blockIdx.y;
-  const int hpg = a.H / a.G;
-  const int g = blockIdx.x % a.G;
-  const int hig = (blockIdx.x / a.G) * NW + wave;
-  const int h = a.group_map ? (hig * a.G + g) : (g * hpg + hig);
-  const int seg = blockIdx.z;
-  const int c_first = seg * a.seg_chunks;
-  const int t_first = c_first * HQ;
-  const int nchunks = min(a.seg_chunks, a.nchunks - c_first);
-  const int L = min(a.L - t_first, nchunks * HQ);
-  HeadVec& vec = sm.v[wave].v;
-  const unsigned lds0 = lds_addr_of(smem_raw);
-  const unsigned lds_bt = lds0 + (unsigned)offsetof(Smem, bt), lds_ct = lds0 + (unsigned)offsetof(Smem, ct);
-  const unsigned lds_xr = lds0 + (unsigned)offsetof(Smem, xr) + wave * (unsigned)sizeof(sm.xr[0]);
-  const unsigned lds_vec = lds0 + (unsigned)offsetof(Smem, v) + wave * (unsigned)sizeof(HeadVecA);
-  constexpr unsigned XSLOT = sizeof(sm.xr[0][0]);
-  {
-    float* vz = reinterpret_cast<float*>(&sm.v[wave]);
-    for (int i = lane; i < (int)(sizeof(HeadVecA) / 4); i += 64) vz[i] = 0.f;
-    sm.v[wave].one[lane] = 1.f;
-  }
-
-  // ---- B / C copies (as in ssd_head_kernel): piece k of this wave = token rows 16 wave + 4 k + (lane >> 4)
-  const bf16_t* Bg = a.Bm + (int64_t)b * a.bsb + (int64_t)g * a.bsg + (int64_t)t_first * a.bsl;
-  const bf16_t* Cg = a.Cm + (int64_t)b * a.csb + (int64_t)g * a.csg + (int64_t)t_first * a.csl;
-  const int bc_row0 = 4 * KP * wave + (lane >> 4);
-  const unsigned off_b0 = (unsigned)((bc_row0 * a.bsl + ((lane & 15) ^ (4 * ((lane >> 4) & 3))) * 8) * 2);
-  const unsigned off_c0 = (unsigned)(bc_row0 * a.csl * 2);
-  const unsigned cgc0 = (unsigned)(((lane & 15) ^ (lane >> 4)) << 4);
-  const unsigned r4b = (unsigned)(4 * a.bsl * 2), r4c = (unsigned)(4 * a.csl * 2);
-  const unsigned ob0 = off_b0, ob1 = off_b0 + r4b - 1024u, ob2 = off_b0 + 2 * r4b - 2048u, ob3 = off_b0 + 3 * r4b - 3072u;
-  const unsigned oc0 = off_c0 + cgc0, oc1 = off_c0 + r4c + (cgc0 ^ 64u) - 1024u, oc2 = off_c0 + 2 * r4c + (cgc0 ^ 128u) - 2048u,
-                 oc3 = off_c0 + 3 * r4c + (cgc0 ^ 192u) - 3072u;
-  auto issue_bc_tail = [&](int c, int which) {       // a chunk with fewer than 64 rows: rows past the end repeat the last row
-    const int slot = c % NB;
-    const int t0 = c * HQ;
-    const bf16_t* Tc = which ? Cg + (int64_t)t0 * a.csl : Bg + (int64_t)t0 * a.bsl;
-    const int64_t rl = which ? a.csl : a.bsl;
-    const unsigned dst = (which ? lds_ct : lds_bt) + slot * (HQ * HN * 2);
-    const void* sp = uniform_ptr(Tc);
-#pragma unroll
-    for (int k = 0; k < KP; ++k) {
-      const int row = 4 * KP * wave + 4 * k + (lane >> 4);
-      const int rr = min(row, L - 1 - t0);
-      const int cg = which ? (lane & 15) ^ (row & 15) : (lane & 15) ^ (4 * (row & 3));
-      glds16(sp, (unsigned)((rr * rl + cg * 8) * 2), dst + (KP * wave + k) * 1024);
-    }
-  };
-  // ---- x copies
-  constexpr int XROW = 2 * P, NPC = P / 8, RPI = 64 / NPC, NXI = (HQ + RPI - 1) / RPI;
-  const bf16_t* xg = a.x + (int64_t)b * a.xsb + (int64_t)t_first * a.xsl + (int64_t)h * P;
-  const int x_lrow = lane / NPC;
-  const unsigned x_off = (unsigned)((x_lrow * a.xsl + (lane % NPC) * 8) * 2);
-  const unsigned x_off_last = (unsigned)((min(x_lrow, HQ - 1 - RPI * (NXI - 1)) * a.xsl + (lane % NPC) * 8) * 2);
-  const unsigned dj = (unsigned)(RPI * a.xsl * 2) - (unsigned)(RPI * XROW);
-  const unsigned ox0 = x_off, ox1 = x_off + dj, ox2 = x_off + 2 * dj, ox3 = x_off + 3 * dj, oxl = x_off_last + 2 * dj;
-  const unsigned xg4 = (unsigned)(RPI * 4 * a.xsl * 2);
-  auto issue_x_tail = [&](int c) {
-    const int t0 = c * HQ;
-    const bf16_t* xc = xg + (int64_t)t0 * a.xsl;
-#pragma unroll
-    for (int k = 0; k < NXI; ++k)
-      glds16(uniform_ptr(xc), (unsigned)((min(RPI * k + x_lrow, L - 1 - t0) * a.xsl + (lane % NPC) * 8) * 2),
-             lds_xr + (c & 1) * XSLOT + RPI * k * XROW);
-  };
-  auto issue_full = [&](int c) {        // a whole chunk from C++ (prologue only)
-    const void* sb = uniform_ptr(Bg + (int64_t)c * HQ * a.bsl);
-    glds16x4(sb, ob0, ob1, ob2, ob3, lds_bt + (c % NB) * (HQ * HN * 2) + KP * wave * 1024);
-    const void* sc = uniform_ptr(Cg + (int64_t)c * HQ * a.csl);
-    glds16x4(sc, oc0, oc1, oc2, oc3, lds_ct + (c % NB) * (HQ * HN * 2) + KP * wave * 1024);
-#pragma unroll
-    for (int k = 0; k < NXI; ++k) {
-      const void* sx = uniform_ptr(xg + (int64_t)(c * HQ + RPI * k) * a.xsl);
-      glds16(sx, k == NXI - 1 ? x_off_last : x_off, lds_xr + (c & 1) * XSLOT + RPI * k * XROW);
-    }
-  };
-  auto issue_chunk = [&](int c) {
-    if ((c + 1) * HQ <= L) issue_full(c);
-    else { issue_bc_tail(c, 0); issue_bc_tail(c, 1); issue_x_tail(c); }
-  };
-
-  // ---- lane parts of the LDS addresses the step reads (slot 0; the step adds the slot offsets)
-  const int xr_lo = (8 * kq + q4) * XROW + 8 * p4, xv_lo = lc * XROW + 8 * kq;
-  const int c_lo = lc * 256, c_z = (kq ^ lc) << 4, bsw = q4 << 6, b_lo = (8 * kq + q4) * 256 + p4 * 16;
-  const unsigned ca0 = lds_ct + ((c_z ^ 0) + c_lo), ca1 = lds_ct + ((c_z ^ 64) + c_lo), ca2 = lds_ct + ((c_z ^ 128) + c_lo),
-                 ca3 = lds_ct + ((c_z ^ 192) + c_lo);
-  const unsigned ba0 = lds_bt + ((bsw ^ 0) + b_lo), ba1 = lds_bt + ((bsw ^ 64) + b_lo), ba2 = lds_bt + ((bsw ^ 128) + b_lo),
-                 ba3 = lds_bt + ((bsw ^ 192) + b_lo);
-  const unsigned xtr = lds_xr + xr_lo, xvr = lds_xr + xv_lo;
-  const unsigned vw_wts = lds_vec + (unsigned)offsetof(HeadVec, wts) + 32 * kq;
-  const unsigned vev_ecs = lds_vec + (unsigned)offsetof(HeadVec, ecs) + 4 * lc;
-  const unsigned vev_one = lds_vec + (unsigned)offsetof(HeadVecA, one) + 4 * lc;
-  // standard steps: the mask factors' addresses (token t = 16 (kq >> 1) + lc, columns s = 8 kq + j) and the diagonal test
-  const unsigned sa_t = lds_vec + 4 * (16 * (kq >> 1) + lc), sa_s = lds_vec + 32 * kq, sa_lc = lds_vec + 4 * lc, sa_s15 = lds_vec + 32 * (kq & 1);
-  const int sd0 = 16 * (kq >> 1) + lc - 8 * kq;
-  const unsigned cbo = lane * 16, dto = lane * 2;
-  const unsigned yst = (unsigned)(((lane / 10) * a.ysl + (lane % 10) * 8) * 2);      // row stores: lane = 16-byte piece of 6 rows of 160 bytes
-  const int lrow = lane / 10;
-  const unsigned xsr = lds_xr + 16 * lane;
-  bf16_t* const ygs = a.y + (int64_t)b * a.ysb + (int64_t)t_first * a.ysl + (int64_t)h * P;
-  const bf16_t* cbg = a.cb + (((int64_t)b * a.G + g) * a.nchunks + c_first) * CBE;
-  const unsigned y6 = (unsigned)(12 * a.ysl);      // bytes of 6 rows of y
-
-  // ---- per-chunk vectors (the same decisions and arithmetic as ssd_head_kernel's prep)
-  const float Ah = a.A[h];
-  const float bias = a.dt_bias ? a.dt_bias[h] : 0.f;
-  const float Dh = a.D ? a.D[h] : 0.f;
-  const bf16_t* dtg = a.dt + (int64_t)b * a.dsb + (int64_t)t_first * a.dsl + (int64_t)h * a.dsh;      // head-major: dsl == 1
-  float decay_total = 0.f;
-  float E = 0.f;
-  bool reset_next = false, std_next = false;
-  unsigned dead_next = 0;        // standard steps: bit ti = every row factor of t-tile ti has underflowed to zero
-  auto prep = [&](int c, unsigned raw_bits, float& f_out) __attribute__((always_inline)) {
-    const int t = c * HQ + lane;
-    float d = 0.f;
-    if (t < L) {
-      d = bf16_lo(raw_bits) + bias;
-      if (a.softplus) d = softplus_fast(d);
-      d = fminf(fmaxf(d, a.dt_min), a.dt_max);
-    }
-    const float cs = wave_incl_scan_dpp(d * Ah);
-    const float cl = rdlane(cs, 63);
-    const float cs2 = cs * 1.4426950408889634f, cl2 = cl * 1.4426950408889634f;
-    const int mode = -(E + cl2) <= RMAX ? 0 : -cl2 <= 2.f * RMAX - 1.f ? 1 : 2;
-    const float mshift = mode == 1 ? __builtin_floorf(RMAX - E) : 0.f;
-    const float Euse = E + mshift;
-    f_out = mode == 1 ? -mshift : 1.f;
-    vec.cs[lane] = cs2;
-    vec.dtv[lane] = d;
-    const float rowf = __builtin_amdgcn_exp2f(cs2 + Euse);
-    vec.ecs[lane] = rowf;
-    {
-      const unsigned long long nz = __builtin_amdgcn_ballot_w64(rowf != 0.f);
-      dead_next = ((nz & 0xffffull) == 0 ? 1u : 0u) | (((nz >> 16) & 0xffffull) == 0 ? 2u : 0u) | (((nz >> 32) & 0xffffull) == 0 ? 4u : 0u) |
-                  ((nz >> 48) == 0 ? 8u : 0u);
-    }
-    const bool rst = TV_HEAD_RESET && mode != 2 && cl2 <= -RESET_THR;
-    const bool ustd = mode == 2;
-    reset_next = rst || ustd;
-    std_next = ustd;
-    vec.wts[lane] = __builtin_amdgcn_exp2f(mode == 2 ? cl2 - cs2 : rst ? cl2 - cs2 - RMAX : -cs2 - Euse) * d;
-    if (rst) vec.wtd[c & 1][lane] = __builtin_amdgcn_exp2f(-cs2 - Euse) * d;
-    if (a.chunk_tot && lane == 0) a.chunk_tot[((int64_t)b * a.H + h) * a.nchunks + c_first + c] = cl2;
-    if (__builtin_expect(mode == 2, 0)) {
-      const float p0 = rdlane(cs2, 0), p1 = rdlane(cs2, 16), p2 = rdlane(cs2, 32), p3 = rdlane(cs2, 48);
-      const float pv = lane < 16 ? p0 : lane < 32 ? p1 : lane < 48 ? p2 : p3;
-      vec.ut[lane] = __builtin_amdgcn_exp2f(fminf(cs2 - pv, 0.f));
-      if (lane < 16) vec.ws[lane] = __builtin_amdgcn_exp2f(fminf(p1 - cs2, 0.f)) * d;
-      if (lane < 32) vec.ws[16 + lane] = __builtin_amdgcn_exp2f(fminf(p2 - cs2, 0.f)) * d;
-      if (lane < 48) vec.ws[48 + lane] = __builtin_amdgcn_exp2f(fminf(p3 - cs2, 0.f)) * d;
-    }
-    decay_total += cl;
-    E = mode == 2 ? 0.f : rst ? RMAX : Euse + cl2;
-    return __builtin_amdgcn_readfirstlane(ustd ? 0 : mode);
-  };
-
-  // ---- state: zero, or the caller's initial state (first segment)
-  asm volatile(TV_HEAD_STATE_ZERO ::: TV_HEAD_STATE_CLOBBERS);
-  if (a.init && seg == 0) {
-#pragma unroll
-    for (int ct = 0; ct < PT; ++ct)
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const f32x4 v = *(const f32x4*)(a.init + (((int64_t)b * a.H + h) * P + 16 * ct + lc) * HN + 32 * (i >> 1) + 8 * kq + 4 * (i & 1));
-        asm volatile("v_accvgpr_write_b32 a[%c4], %0\n\tv_accvgpr_write_b32 a[%c5], %1\n\tv_accvgpr_write_b32 a[%c6], %2\n\tv_accvgpr_write_b32 a[%c7], %3"
-                     :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "n"(32 * ct + 4 * i), "n"(32 * ct + 4 * i + 1), "n"(32 * ct + 4 * i + 2), "n"(32 * ct + 4 * i + 3)
-                     : TV_HEAD_STATE_CLOBBERS);
-      }
-  }
-
-  // ---- prologue: chunk 0's copies, its vectors
-  issue_chunk(0);
-  unsigned dt_next = *(const unsigned short*)(dtg + lane);
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(dt_next) :: "memory");
-  float f_step;
-  int mode = prep(0, dt_next, f_step);
-  bool reset_cur = __builtin_amdgcn_readfirstlane((int)reset_next) != 0;
-  bool std_cur = __builtin_amdgcn_readfirstlane((int)std_next) != 0;
-  unsigned dead_cur = dead_next;
-  dt_next = *(const unsigned short*)(dtg + (int64_t)min(1, nchunks - 1) * HQ + lane);
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(dt_next) :: "memory");
-  HEAD_BARRIER(0);
-
-#ifdef TV_HEAD_STAMP
-  unsigned st_last = (unsigned)clock64(), st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, st5 = 0, st6 = 0, st7 = 0, st8 = 0, st9 = 0, st10 = 0, st11 = 0, st12 = 0;
-#endif
-  // The whole march over this segment's chunks is ONE statement (ssd_head_loop.inc): the step body of ssd_head_asm_kernel between
-  // the scalar set-up of a chunk and the hand-over to the next (flags, running pointers, the last chunk's clamped copies,
-  // chunk_tot, the barrier) — what that kernel's C++ loop does between its statements costs 730 cycles a step there.
-  const unsigned nflags0 = __builtin_amdgcn_readfirstlane((mode == 1 ? 1u : 0u) | (reset_cur ? 2u : 0u) | (std_cur ? 4u : 0u) | (dead_cur << 4));
-  const int nsh0 = __builtin_amdgcn_readfirstlane(mode == 1 ? (int)f_step : 0);
-  unsigned e0, dtot0;      // (the compiler folds a readfirstlane of a value it knows to be uniform and then hands the asm a vector register)
-  asm volatile("v_readfirstlane_b32 %0, %2\n\tv_readfirstlane_b32 %1, %3" : "=s"(e0), "=s"(dtot0) : "v"(E), "v"(decay_total));
-  const unsigned vvec = lds_vec + 4 * lane;
-  const unsigned vw20 = lds_vec + (unsigned)offsetof(HeadVec, wtd) + 32 * kq;
-  const unsigned lb0 = lds_bt + KP * wave * 1024, lc0 = lds_ct + KP * wave * 1024;
-  const unsigned fl_const = a.softplus ? (1u << 8) : 0u;
-  const void* pcb0 = uniform_ptr(cbg + 1024);              // (the step's offsets are -2048 .. 3072)
-  const void* py0 = uniform_ptr(ygs);
-  const void* pdt0 = uniform_ptr(dtg + (int64_t)min(2, nchunks - 1) * HQ);
-  const void* pb0 = uniform_ptr(Bg + (int64_t)HQ * a.bsl);
-  const void* pc0 = uniform_ptr(Cg + (int64_t)HQ * a.csl);
-  const void* px0 = uniform_ptr(xg + (int64_t)HQ * a.xsl);
-  // chunk_tot of chunk c + 1 is written at the end of step c (lane 0); without it the stores go to this wave's own total
-  float* sink = (a.nseg > 1 ? a.seg_decay + (int64_t)seg * gridDim.y * a.H : a.total_decay);
-  const void* pct0 = a.chunk_tot ? (const void*)uniform_ptr(a.chunk_tot + ((int64_t)b * a.H + h) * a.nchunks + c_first + 1)
-                                 : (const void*)uniform_ptr(sink + (int64_t)b * a.H + h);
-  const unsigned ctstep = a.chunk_tot ? 4u : 0u;
-  const unsigned ystep = (unsigned)(HQ * a.ysl * 2), bstep = (unsigned)(HQ * a.bsl * 2), cstep = (unsigned)(HQ * a.csl * 2),
-                 xstep = (unsigned)(HQ * a.xsl * 2), cbstep = CBE * 2;
-  const unsigned bsl2 = (unsigned)(a.bsl * 2), csl2 = (unsigned)(a.csl * 2), xsl2 = (unsigned)(a.xsl * 2);
-  // the last, partial chunk's copies (rows past the end repeat the last row): lane parts
-  const int tr0 = 4 * KP * wave + (lane >> 4);
-  const unsigned tcb = (unsigned)(((lane & 15) ^ (4 * ((lane >> 4) & 3))) * 16), tcc = cgc0, txc = (unsigned)((lane % NPC) * 16);
-  unsigned o_e, o_dtot;
-  asm volatile(TV_HEAD_LOOP_ASM
-               : [oe] "=&s"(o_e), [odtot] "=&s"(o_dtot)
-               : [ca0] "v"(ca0), [ca1] "v"(ca1), [ca2] "v"(ca2), [ca3] "v"(ca3), [ba0] "v"(ba0), [ba1] "v"(ba1), [ba2] "v"(ba2), [ba3] "v"(ba3),
-                 [xtr] "v"(xtr), [xvr] "v"(xvr), [xsr] "v"(xsr), [vw] "v"(vw_wts), [vw20] "v"(vw20), [veve] "v"(vev_ecs), [vevo] "v"(vev_one),
-                 [cbo] "v"(cbo), [yst] "v"(yst), [lrow] "v"(lrow), [dto] "v"(dto),
-                 [ob0] "v"(ob0), [ob1] "v"(ob1), [ob2] "v"(ob2), [ob3] "v"(ob3), [oc0] "v"(oc0), [oc1] "v"(oc1), [oc2] "v"(oc2), [oc3] "v"(oc3),
-                 [ox0] "v"(ox0), [ox1] "v"(ox1), [ox2] "v"(ox2), [ox3] "v"(ox3), [oxl] "v"(oxl),
-                 [at] "v"(sa_t), [as] "v"(sa_s), [alc] "v"(sa_lc), [as15] "v"(sa_s15), [d0] "v"(sd0),
-                 [lane] "v"(lane), [vvec] "v"(vvec), [tr0] "v"(tr0), [tcb] "v"(tcb), [tcc] "v"(tcc), [txr] "v"(x_lrow), [txc] "v"(txc), [dt1] "v"(dt_next),
-                 [nflags0] "s"(nflags0), [nsh0] "s"(nsh0), [e0] "s"(e0), [dtot0] "s"(dtot0),
-                 [pcb0] "s"(pcb0), [py0] "s"(py0), [pdt0] "s"(pdt0), [pb0] "s"(pb0), [pc0] "s"(pc0), [px0] "s"(px0), [pct0] "s"(pct0),
-                 [nchunks] "s"(nchunks), [L] "s"(L), [flconst] "s"(fl_const), [ctstep] "s"(ctstep), [cbstep] "s"(cbstep), [ystep] "s"(ystep),
-                 [bstep] "s"(bstep), [cstep] "s"(cstep), [xstep] "s"(xstep), [xg4] "s"(xg4), [y6] "s"(y6), [lb0] "s"(lb0), [lc0] "s"(lc0),
-                 [ldsxr] "s"(lds_xr), [bsl2] "s"(bsl2), [csl2] "s"(csl2), [xsl2] "s"(xsl2),
-                 [bias] "s"(bias), [ah] "s"(Ah), [dtmin] "s"(a.dt_min), [dtmax] "s"(a.dt_max), [dh] "s"(Dh)
-               : TV_HEAD_LOOP_CLOBBERS);
-  E = __uint_as_float(o_e);
-  decay_total = __uint_as_float(o_dtot);
-  // ---- final state of this segment, X = 2^E X'
-  {
-    const float sc = __builtin_amdgcn_exp2f(E);
-    float* fin = a.nseg > 1 ? a.seg_state + (int64_t)seg * gridDim.y * a.H * P * HN : a.final_state;
-    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
-    if (fin) {
-#pragma unroll
-      for (int ct = 0; ct < PT; ++ct)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          float v0, v1, v2, v3;
-          asm volatile("v_accvgpr_read_b32 %0, a[%c4]\n\tv_accvgpr_read_b32 %1, a[%c5]\n\tv_accvgpr_read_b32 %2, a[%c6]\n\tv_accvgpr_read_b32 %3, a[%c7]"
-                       : "=v"(v0), "=v"(v1), "=v"(v2), "=v"(v3)
-                       : "n"(32 * ct + 4 * i), "n"(32 * ct + 4 * i + 1), "n"(32 * ct + 4 * i + 2), "n"(32 * ct + 4 * i + 3));
-          *(f32x4*)(fin + (((int64_t)b * a.H + h) * P + 16 * ct + lc) * HN + 32 * (i >> 1) + 8 * kq + 4 * (i & 1)) =
-              f32x4{v0 * sc, v1 * sc, v2 * sc, v3 * sc};
-        }
-    }
-    float* td = a.nseg > 1 ? a.seg_decay + (int64_t)seg * gridDim.y * a.H : a.total_decay;
-    if (td && lane == 0) td[(int64_t)b * a.H + h] = decay_total;
-  }
-}
-
-
 // dt (B, L, H) -> (B, H, Lp) with Lp = 64 nchunks: a wave (= a head) then reads the 64 tokens of a chunk as ONE 128-byte line.
 // Token-major, the same 64 values are 2 bytes each out of 64 lines that all 128 heads share; the lines are evicted between
 // the visits of the work-groups that want them and came from HBM 11 times over (profiles/r04_ssd_scan_read_attribution.json:
@@ -1473,12 +1205,11 @@ __global__ __launch_bounds__(256) void ssd_dt_transpose_kernel(const bf16_t* __r
 
 // tv_ssd_head_set_asm(0) / TV_HEAD_ASM=0 sends head_dim 80 x 4 heads back to the C++ step (A/B runs, the bit-identity test)
 std::atomic<int> g_head_asm{-1};
-// 0 the C++ step, 1 the generated step as one statement per chunk (C++ loop), 2 the generated chunk loop (default)
-int head_asm_mode() {
+bool head_asm_enabled() {
   const int f = g_head_asm.load(std::memory_order_relaxed);
-  if (f >= 0) return f;
-  static const int mode = [] { const char* e = getenv("TV_HEAD_ASM"); return e ? atoi(e) : TV_HEAD_ASM_DEFAULT; }();
-  return mode;
+  if (f >= 0) return f != 0;
+  static const bool on = [] { const char* e = getenv("TV_HEAD_ASM"); return !e || atoi(e) != 0; }();
+  return on;
 }
 static_assert(sizeof(HeadSmemA) <= 160 * 1024, "LDS budget");
 
@@ -1612,10 +1343,7 @@ int tv_ssd_head_launch(const void* x, const void* dt, const void* A, const void*
   const int key = headdim / 16 * 10 + nw;
   switch (key) {
     case 54:
-      if (head_asm_mode() == 2) {
-        e = hipFuncSetAttribute((const void*)ssd_head_loop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(HeadSmemA));
-        if (e == hipSuccess) ssd_head_loop_kernel<<<grid, 256, sizeof(HeadSmemA), st>>>(a);
-      } else if (head_asm_mode() == 1) {
+      if (head_asm_enabled()) {
         e = hipFuncSetAttribute((const void*)ssd_head_asm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(HeadSmemA));
         if (e == hipSuccess) ssd_head_asm_kernel<<<grid, 256, sizeof(HeadSmemA), st>>>(a);
       } else {

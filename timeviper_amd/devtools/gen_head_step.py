@@ -21,7 +21,6 @@ The arithmetic and its order per accumulator are those of ssd_head.hip's C++ ste
     python timeviper_amd/devtools/gen_head_step.py  > timeviper_amd/csrc/ssd_head_step.inc
 """
 import os
-import re
 import sys
 
 PT = 5
@@ -34,16 +33,13 @@ def A_STATE(ct, i): return 32 * ct + 4 * i           # a[..+3]
 def A_YO(ct, ti): return 160 + 16 * ct + 4 * ti
 def A_RING(k): return 240 + 4 * (k % 4)
 
-LOOP = "--loop" in sys.argv      # the whole chunk loop as one statement (ssd_head_loop.inc): four more registers of the body
-V0 = 72 if LOOP else 76
+V0 = 76
 _v = [V0]
 def valloc(n):
     b = _v[0]
     assert n == 1 or b % 2 == 0
     _v[0] += n
     return b
-if LOOP:
-    DTC, DTL, VW2T, _spare = valloc(1), valloc(1), valloc(1), valloc(1)      # dt of the chunk being prepared / being loaded, a temporary
 SB = [[valloc(4) for ct in range(PT)] for b in range(2)]
 XW = [[valloc(4) for ks in range(2)] for ct in range(PT)]
 CBV = [valloc(4) for f in range(6)]
@@ -307,7 +303,6 @@ def prep_ops(uid):
     X, T1, T2, T3, T4, T5, D_, CS, CS2, EE, CL2, ECL, ROW, A0, A1, A2, ARG, PV, K32, MSH = P[:20]
     VALID, MA, MB, MC = 72, 74, 76, 78          # SGPR pairs
     SC, SCL, SMODE, SDEAD = 94, 95, 96, 97
-    PIV = 72                                    # standard steps: the four pivots (the masks in s72..s75 are dead by then)
 
     def V(text, w=(), r=(), **kw): ops.append(Op(text, "valu", r=[f"v{x}" for x in r], w=[f"v{x}" for x in w], **kw))
     def S(text, **kw): ops.append(Op(text, "salu", **kw))
@@ -459,11 +454,11 @@ def prep_ops(uid):
     S(f"s_cbranch_scc1 .Lhs_prep_nostd{uid}_%=")
     k0 = len(ops) - 2
     for j, ln in enumerate((0, 16, 32, 48)):
-        V(f"v_readlane_b32 s{PIV + j}, {vr(CS2)}, {ln}", r=[CS2])
-    V(f"v_mov_b32 {vr(PV)}, s{PIV + 3}", w=[PV])
+        V(f"v_readlane_b32 s{90 + j}, {vr(CS2)}, {ln}", r=[CS2])
+    V(f"v_mov_b32 {vr(PV)}, s93", w=[PV])
     for j, bound in ((2, 48), (1, 32), (0, 16)):
         V(f"v_cmp_gt_i32 vcc, {bound}, %[lane]")
-        V(f"v_mov_b32 {vr(T1)}, s{PIV + j}", w=[T1])
+        V(f"v_mov_b32 {vr(T1)}, s{90 + j}", w=[T1])
         V(f"v_cndmask_b32 {vr(PV)}, {vr(PV)}, {vr(T1)}, vcc", w=[PV], r=[PV, T1])
     V(f"v_sub_f32 {vr(T1)}, {vr(CS2)}, {vr(PV)}", w=[T1], r=[CS2, PV])
     V(f"v_min_f32 {vr(T1)}, 0, {vr(T1)}", w=[T1], r=[T1])
@@ -471,7 +466,7 @@ def prep_ops(uid):
     S("s_nop 0")
     ops.append(Op(f"ds_write_b32 %[vvec], {vr(T1)} offset:{VEC_UT}", "lds_nc", r=[f"v{T1}"]))
     for j, (bound, woff) in enumerate(((16, 0), (32, 16), (48, 48))):
-        V(f"v_sub_f32 {vr(T1)}, s{PIV + 1 + j}, {vr(CS2)}", w=[T1], r=[CS2])
+        V(f"v_sub_f32 {vr(T1)}, s{91 + j}, {vr(CS2)}", w=[T1], r=[CS2])
         V(f"v_min_f32 {vr(T1)}, 0, {vr(T1)}", w=[T1], r=[T1])
         V(f"v_exp_f32 {vr(T1)}, {vr(T1)}", w=[T1], r=[T1])
         S("s_nop 0")
@@ -789,8 +784,7 @@ def gen_step():
             tasks.append(Task(f"cpX{g}", copy_group_ops(f"cpx{g}" + var, "px", ("xg4", g), m0x, vo, [j * RPI * XROW for j in range(n)]),
                               after=32 + 14 * g, deadline=100, prio=38 + 14 * g))
         # phase B operands that may already be fetched: ev, the first B fragments (ring slots free after the last C use)
-        vev = "vevo" if var == "S" else "veve"      # a standard step's accumulators already carry their row factors: ones
-        pre_b = [Op(f"ds_read_b32 {vr(EV[ti])}, %[{vev}] offset:{64 * ti}", "lds", w=regs("v", EV[ti]), lds_def=f"ev{ti}") for ti in range(4)]
+        pre_b = [Op(f"ds_read_b32 {vr(EV[ti])}, %[vev] offset:{64 * ti}", "lds", w=regs("v", EV[ti]), lds_def=f"ev{ti}") for ti in range(4)]
         tasks.append(Task("preB", pre_b, after=81 if var == "S" else 70, deadline=109, prio=108 if var == "S" else 95))
         for m in range(4):
             tasks.append(Task(f"b{m}", b_read_ops(m), after=(12 + m) * 5 + 4, deadline=110 + m * 5 - 4, prio=100 + m))
@@ -922,116 +916,9 @@ def gen_step():
     return em
 
 
-# ---------------------------------------------------------------- the chunk loop as one statement
-XSLOT = 64 * 80 * 2 + 512
-S_C, S_NFL, S_NSH, S_E, S_DTOT, S_SBC, S_SXS, S_PAR = 50, 51, 52, 53, 54, 55, 56, 57
-S_PCB, S_PY, S_PDT, S_PB, S_PC, S_PX = 58, 60, 62, 64, 66, 68
-S_FLAGS, S_SH, S_REM, S_LREM1, S_TMP, S_CL2, S_PAR1 = 70, 71, 90, 91, 93, 98, 99
-S_PCT = 100            # s[100:101]: where the next chunk's log2 decay goes (chunk_tot)
-FLAG_MORE = 9
-
-
-def gen_loop():
-    """The march over a segment's chunks as ONE statement: the step body between a scalar set-up and the hand-over to the next
-    chunk (what ssd_head_asm_kernel's C++ loop does between its statements: flags, running pointers, the last chunk's clamped
-    copies, chunk_tot, the barrier).  Per-step operands of the body become registers of the statement."""
-    em = gen_step()
-    body = em.lines
-    pair = lambda b: f"s[{b}:{b + 1}]"
-    top = [
-        f"s_mov_b32 s{S_C}, 0", f"s_mov_b32 s{S_NFL}, %[nflags0]", f"s_mov_b32 s{S_NSH}, %[nsh0]", f"s_mov_b32 s{S_E}, %[e0]",
-        f"s_mov_b32 s{S_DTOT}, %[dtot0]", f"s_mov_b32 s{S_SBC}, 0", f"s_mov_b32 s{S_SXS}, 0",
-        f"s_mov_b64 {pair(S_PCB)}, %[pcb0]", f"s_mov_b64 {pair(S_PY)}, %[py0]", f"s_mov_b64 {pair(S_PDT)}, %[pdt0]",
-        f"s_mov_b64 {pair(S_PB)}, %[pb0]", f"s_mov_b64 {pair(S_PC)}, %[pc0]", f"s_mov_b64 {pair(S_PX)}, %[px0]", f"s_mov_b64 {pair(S_PCT)}, %[pct0]",
-        f"v_mov_b32 {vr(DTC)}, %[dt1]",
-        ".Lhs_loop_%=:",
-        # scalar set-up of this chunk: more, copy (the next chunk exists / is a whole one), the rows of this and the next chunk
-        f"s_add_i32 s{S_TMP}, s{S_C}, 1", f"s_and_b32 s{S_PAR1}, s{S_TMP}, 1", f"s_and_b32 s{S_PAR}, s{S_C}, 1",
-        f"s_cmp_lt_i32 s{S_TMP}, %[nchunks]", f"s_cselect_b32 s{S_FLAGS}, {1 << FLAG_MORE}, 0",
-        f"s_lshl_b32 s{S_TMP}, s{S_TMP}, 6", f"s_sub_i32 s{S_LREM1}, %[L], s{S_TMP}",
-        f"s_add_i32 s{S_REM}, s{S_LREM1}, 64", f"s_min_i32 s{S_REM}, s{S_REM}, 64",
-        f"s_cmp_ge_i32 s{S_LREM1}, 64", f"s_cselect_b32 s{S_TMP}, {1 << FLAG_COPY}, 0", f"s_or_b32 s{S_TMP}, s{S_TMP}, {1 << FLAG_MORE}",
-        f"s_cmp_lg_u32 s{S_FLAGS}, 0", f"s_cselect_b32 s{S_FLAGS}, s{S_TMP}, 0",
-        f"s_or_b32 s{S_FLAGS}, s{S_FLAGS}, s{S_NFL}", f"s_or_b32 s{S_FLAGS}, s{S_FLAGS}, %[flconst]", f"s_mov_b32 s{S_SH}, s{S_NSH}",
-    ]
-    # the last, partial chunk's copies: rows past the end repeat the last row (as issue_bc_tail / issue_x_tail in C++)
-    tail = [f"s_bitcmp1_b32 s{S_FLAGS}, {FLAG_MORE}", "s_cbranch_scc0 .Lhs_notail_%=", f"s_bitcmp1_b32 s{S_FLAGS}, {FLAG_COPY}", "s_cbranch_scc1 .Lhs_notail_%=",
-            f"s_sub_i32 s{S_TMP}, s{S_LREM1}, 1"]
-    T = T8
-    def tail_piece(base_pair, row_op, k_rows, stride_op, col_expr, m0_lines):
-        ls = [f"v_add_u32 {vr(T)}, {k_rows}, %[{row_op}]", f"v_min_i32 {vr(T)}, s{S_TMP}, {vr(T)}", f"v_mul_lo_u32 {vr(T)}, {vr(T)}, %[{stride_op}]"]
-        ls += col_expr
-        ls += m0_lines + ["s_nop 0", f"global_load_lds_dwordx4 {vr(T)}, {base_pair}"]
-        return ls
-    for which, (bp, stride, dst0) in enumerate(((S_PB, "bsl2", "lb0"), (S_PC, "csl2", "lc0"))):
-        for k in range(4):
-            col = ([f"v_add_u32 {vr(T)}, {vr(T)}, %[tcb]"] if which == 0 else
-                   [f"v_xor_b32 {vr(T + 1)}, {64 * k}, %[tcc]", f"v_add_u32 {vr(T)}, {vr(T)}, {vr(T + 1)}"])
-            m0 = [f"s_xor_b32 s{S_CP}, s{S_SBC}, 0x4000", f"s_add_u32 s{S_CP}, s{S_CP}, %[{dst0}]", f"s_add_u32 m0, s{S_CP}, {1024 * k}"]
-            tail += tail_piece(pair(bp), "tr0", 4 * k, stride, col, m0)
-    for k in range(NXI):
-        col = [f"v_add_u32 {vr(T)}, {vr(T)}, %[txc]"]
-        m0 = [f"s_xor_b32 s{S_CP}, s{S_SXS}, {XSLOT}", f"s_add_u32 s{S_CP}, s{S_CP}, %[ldsxr]", f"s_add_u32 m0, s{S_CP}, {RPI * k * XROW}"]
-        tail += tail_piece(pair(S_PX), "txr", RPI * k, "xsl2", col, m0)
-    tail += ["s_waitcnt vmcnt(0)", ".Lhs_notail_%=:"]
-    post = tail + [
-        # chunk_tot of the chunk just prepared (lane 0), its dt, the running pointers, the slot toggles
-        f"s_bitcmp1_b32 s{S_FLAGS}, {FLAG_MORE}", "s_cbranch_scc0 .Lhs_nomore_%=",
-        f"v_mov_b32 {vr(T8)}, s{S_CL2}", f"v_mov_b32 {vr(T8 + 1)}, 0", "s_mov_b64 exec, 1",
-        f"global_store_dword {vr(T8 + 1)}, {vr(T8)}, {pair(S_PCT)}", "s_mov_b64 exec, -1",
-        f"s_add_u32 s{S_PCT}, s{S_PCT}, %[ctstep]", f"s_addc_u32 s{S_PCT + 1}, s{S_PCT + 1}, 0",
-        ".Lhs_nomore_%=:",
-        f"v_mov_b32 {vr(DTC)}, {vr(DTL)}",
-        f"s_xor_b32 s{S_SBC}, s{S_SBC}, 0x4000", f"s_xor_b32 s{S_SXS}, s{S_SXS}, {XSLOT}",
-    ]
-    for ptr, step in ((S_PCB, "cbstep"), (S_PY, "ystep"), (S_PB, "bstep"), (S_PC, "cstep"), (S_PX, "xstep")):
-        post += [f"s_add_u32 s{ptr}, s{ptr}, %[{step}]", f"s_addc_u32 s{ptr + 1}, s{ptr + 1}, 0"]
-    post += [f"s_add_i32 s{S_TMP}, s{S_C}, 3", f"s_cmp_lt_i32 s{S_TMP}, %[nchunks]", f"s_cselect_b32 s{S_TMP}, 128, 0",
-             f"s_add_u32 s{S_PDT}, s{S_PDT}, s{S_TMP}", f"s_addc_u32 s{S_PDT + 1}, s{S_PDT + 1}, 0",
-             f"s_add_i32 s{S_C}, s{S_C}, 1",
-             "s_waitcnt lgkmcnt(0)", "s_barrier",
-             f"s_cmp_lt_i32 s{S_C}, %[nchunks]", "s_cbranch_scc1 .Lhs_loop_%=",
-             f"s_mov_b32 %[oe], s{S_E}", f"s_mov_b32 %[odtot], s{S_DTOT}"]
-    # the step's own end (m0 restore) moves behind the loop
-    m0_restore = body.pop()
-    assert m0_restore.startswith("s_mov_b32 m0,"), m0_restore
-    # the body's first lines save m0 / set D: once, before the loop
-    head = []
-    while not body[0].startswith("s_bitcmp1_b32 %[flags]"):
-        head.append(body.pop(0))
-    lines = head + top + body + post + [m0_restore]
-    rep = {"%[flags]": f"s{S_FLAGS}", "%[sh]": f"s{S_SH}", "%[sbc]": f"s{S_SBC}", "%[sxs]": f"s{S_SXS}", "%[rem]": f"s{S_REM}",
-           "%[lrem1]": f"s{S_LREM1}", "%[par1]": f"s{S_PAR1}", "%[ein]": f"s{S_E}", "%[dtot]": f"s{S_DTOT}", "%[oflags]": f"s{S_NFL}",
-           "%[osh]": f"s{S_NSH}", "%[oe]": None, "%[odtot]": None, "%[ocl2]": f"s{S_CL2}", "%[pcb]": pair(S_PCB), "%[py]": pair(S_PY),
-           "%[pdt]": pair(S_PDT), "%[pb]": pair(S_PB), "%[pc]": pair(S_PC), "%[px]": pair(S_PX), "%[dtin]": vr(DTC), "%[dtout]": vr(DTL)}
-    out = []
-    for i, ln in enumerate(lines):
-        inside = len(head) + len(top) <= i < len(head) + len(top) + len(body)
-        if inside:
-            if ln == "s_mov_b32 m0, %[lb]":
-                out += [f"s_xor_b32 s{S_TMP}, s{S_SBC}, 0x4000", f"s_add_u32 m0, s{S_TMP}, %[lb0]"]; continue
-            if ln == "s_mov_b32 m0, %[lc]":
-                out += [f"s_xor_b32 s{S_TMP}, s{S_SBC}, 0x4000", f"s_add_u32 m0, s{S_TMP}, %[lc0]"]; continue
-            if ln == "s_mov_b32 m0, %[lx]":
-                out += [f"s_xor_b32 s{S_TMP}, s{S_SXS}, {XSLOT}", f"s_add_u32 m0, s{S_TMP}, %[ldsxr]"]; continue
-            m = re.match(r"s_add_u32 m0, %\[lx\], (\d+)$", ln)
-            if m:
-                out += [f"s_xor_b32 s{S_TMP}, s{S_SXS}, {XSLOT}", f"s_add_u32 s{S_TMP}, s{S_TMP}, %[ldsxr]", f"s_add_u32 m0, s{S_TMP}, {m.group(1)}"]; continue
-            if "%[vw2]" in ln and "ds_read_b128" in ln and "offset:0" in ln:
-                out.append(f"v_lshl_add_u32 {vr(VW2T)}, s{S_PAR}, 8, %[vw20]")
-            ln = ln.replace("%[vw2]", vr(VW2T))
-            for k_, v_ in rep.items():
-                if v_ is not None: ln = ln.replace(k_, v_)
-            # the step's end: the prepared chunk's E / decay total go straight to the loop's registers
-            ln = ln.replace("%[oe]", f"s{S_E}").replace("%[odtot]", f"s{S_DTOT}")
-        out.append(ln)
-    return out, em
-
-
-
 def clobbers():
     c = ["memory", "vcc", "scc"]
-    c += [f"s{i}" for i in range(50 if LOOP else 72, 102 if LOOP else 100)]
+    c += [f"s{i}" for i in range(72, 100)]
     c += [f"v{i}" for i in range(V0, 256)]
     c += [f"a{i}" for i in range(256)]
     return c
@@ -1054,16 +941,6 @@ def main():
     PK = "--scalar" not in sys.argv
     global NOSTORE
     NOSTORE = "--nostore" in sys.argv
-    if LOOP:
-        lines, em = gen_loop()
-        print("// generated by timeviper_amd/devtools/gen_head_step.py --scalar --loop — do not edit")
-        print("#define TV_HEAD_LOOP_ASM \\")
-        for ln in lines:
-            print(f'  "{ln}\\n\\t" \\')
-        print('  ""')
-        print("#define TV_HEAD_LOOP_CLOBBERS " + ", ".join(f'"{c}"' for c in clobbers()))
-        print(f"#define TV_HEAD_LOOP_V0 {V0}")
-        return
     em = gen_step()
     if "--summary" in sys.argv:
         print(summary())
