@@ -171,6 +171,7 @@ class Emitter:
 
 
 STAMPS = False
+XNT = "--xnt" in sys.argv      # experiment: the x copies (bytes read once, by one wave) with the non-temporal hint
 NOSTORE = False  # timing experiment: no y stores
 PK = True        # packed f32 multiplies / FMAs (False: scalar ones)
 def stamp(em, k):
@@ -583,7 +584,7 @@ def copy_group_ops(name, base_operand, add_operand, m0_expr_ops, voffs, ioffs):
     ops += m0_expr_ops
     ops.append(Op("s_nop 0", "salu"))
     for v, io in zip(voffs, ioffs):
-        ops.append(Op(f"global_load_lds_dwordx4 %[{v}], s[{S_CP}:{S_CP + 1}]" + (f" offset:{io}" if io else ""), "dma"))
+        ops.append(Op(f"global_load_lds_dwordx4 %[{v}], s[{S_CP}:{S_CP + 1}]" + (f" offset:{io}" if io else "") + (" nt" if XNT and name.startswith("cpx") else ""), "dma"))
     ops.append(Op(f".Lhs_{name}_%=:", "label", cost=0))
     for o in ops[:-1]: o.glue = True
     return ops

@@ -16,7 +16,7 @@ from bench import scan_source_id  # noqa: E402
 tag, impl = sys.argv[1], int(sys.argv[2])
 tokens = int(sys.argv[3]) if len(sys.argv) > 3 else 163940
 KERNELS = ["ssd_head_asm_kernel", "ssd_head_kernel<5, 4, 2>", "ssd_slice_kernel", "ssd_cb_kernel",
-           "ssd_correct_list_kernel", "ssd_correct_kernel", "ssd_seg_chain_kernel", "ssd_seg_combine_kernel", "ssd_chunk_decay_kernel",
+           "ssd_correct_list_kernel", "ssd_correct_kernel", "ssd_chain_prefix_kernel", "ssd_seg_chain_kernel", "ssd_seg_combine_kernel", "ssd_chunk_decay_kernel",
            "ssd_decay_prefix_kernel", "ssd_dt_transpose_kernel"]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))     # kernel -> counter -> per-dispatch sums
 names = {}

@@ -26,7 +26,7 @@ def share(pred):
 
 print()
 for pat in ("ssd_head_asm_kernel", "ssd_head_kernel", "ssd_dt_transpose", "ssd_slice_kernel", "ssd_cb_kernel", "ssd_correct_list_kernel", "ssd_correct_kernel", "ssd_seg_chain",
-            "ssd_decay_prefix", "gemm_persist_kernel", "gemm_bf16_kernel", "layernorm_rows", "conv1d_xbc", "conv1d_bc_cb", "rmsnorm_gated"):
+            "ssd_decay_prefix", "ssd_chain_prefix", "gemm_persist_kernel", "gemm_bf16_kernel", "layernorm_rows", "conv1d_xbc", "conv1d_bc_cb", "rmsnorm_gated"):
     for r in rows:
         if pat in r["Name"]:
             print(f"- `{r['Name'][:60]}`: {r['Calls']} calls, avg {float(r['AverageNs']) / 1e3:.1f} µs, "
