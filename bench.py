@@ -43,6 +43,32 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0                             # dense bf16, MI355X_
 SCAN_SOURCES = ("ssd_head.hip", "ssd_head_step.inc", "ssd_slice.hip", "ssd_correct.hip", "ssd_scan.hip", "ssd_common.hpp", "conv1d.hip")
 
 
+def copy_rate(dev, rl) -> dict:
+    """GB/s (bytes read + bytes written) of `y.copy_(x)` on 3.4 GB — the size of the scan's x at 163 940 tokens — timed with events
+    on the current stream after the bench's timed region, and where the scan's HBM traffic rate stands against it."""
+    import torch
+    n = 163940 * 20480 // 4
+    x = torch.empty(n, dtype=torch.int32, device=dev).random_()
+    y = torch.empty_like(x)
+    best = None
+    for _ in range(3):
+        y.copy_(x)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            y.copy_(x)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        best = ms if best is None else min(best, ms)
+    gbs = 2 * n * 4 / (best * 1e-3) / 1e9
+    out = {"copy_rate": round(gbs, 1), "copy_rate_unit": "GB/s (read + write) of torch copy_ on 3.36 GB, this box"}
+    if rl.get("traffic"):
+        out["traffic_over_copy_rate"] = round(rl["traffic"] / gbs, 4)
+    return out
+
+
 def scan_bytes_per_token(cfg) -> int:
     H, P, G, N = cfg.mamba_num_heads, cfg.mamba_head_dim, cfg.n_groups, cfg.ssm_state_size
     return 2 * H * P + 2 * H + 2 * 2 * G * N + 2 * H * P   # x, dt, B+C read; y written (bf16)
@@ -668,6 +694,10 @@ def run(args, env):
             # ... and every kernel with a stated roof, all event-timed inside the timed steps
             "rooflines": st.all_rooflines(scan_bytes_per_token(cfg), cfg),
         }
+        if world == 1 and dev.type == "cuda" and line["roofline"]:
+            # What a plain copy of the same size reaches on THIS box (read + write streams, outside the timed region): the
+            # practical ceiling of an operator that reads x and writes y once — `peak` stays the 8 TB/s of the data sheet.
+            line["roofline"].update(copy_rate(dev, line["roofline"]))
         if world == 1 and not args.no_cpu_baseline and dev.type == "cuda":
             line["cpu_baseline"] = cpu_baseline(cfg)
     # RCCL writes a version banner through C stdio, which is block-buffered on a pipe and would
