@@ -307,6 +307,36 @@ def test_ssd_head_generated_step_is_bit_identical_to_the_cpp_step(K, regime, a_l
     assert torch.equal(d1, d0), regime
 
 
+@pytest.mark.parametrize("a_lo,a_hi,dt_mean,dt_std", [(0.002, 0.02, -3.0, 0.3), (0.05, 0.3, -1.0, 0.5), (1.0, 16.0, 0.0, 1.3)])
+def test_ssd_correction_walker_list_matches_the_grid(K, monkeypatch, a_lo, a_hi, dt_mean, dt_std):
+    """The carried-in correction of the segmented march runs its walkers off a list (one per 4 chunks of a (head, boundary)'s horizon,
+    persistent work-groups: ssd_correct_list_kernel); TV_CORR_SLOTS=n runs the grid of n work-groups per (head, boundary) instead.
+    Every chunk is corrected by exactly one walker either way: y must agree bit for bit — with heads that never forget (whole
+    segments corrected), slow ones, and the bench-like mix."""
+    B, L, H, P, G, N = 1, 5200, 16, 80, 2, 128           # 82 chunks: 4 - 5 segments
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, L, H, P, generator=g).to(torch.bfloat16)
+    dt = (torch.randn(B, L, H, generator=g) * dt_std + dt_mean).to(torch.bfloat16)
+    A = -(torch.rand(H, generator=g) * (a_hi - a_lo) + a_lo)
+    Bm = (torch.randn(B, L, G, N, generator=g) * 0.5).to(torch.bfloat16)
+    Cm = (torch.randn(B, L, G, N, generator=g) * 0.5).to(torch.bfloat16)
+    ins = (x, dt, A, Bm, Cm, torch.ones(H), torch.zeros(H))
+    K.ssd_scan_set_impl(6)
+    try:
+        monkeypatch.delenv("TV_CORR_SLOTS", raising=False)
+        y_list, fin_list, _ = run_scan(K, *ins)
+        monkeypatch.setenv("TV_CORR_SLOTS", "3")
+        y_grid, fin_grid, _ = run_scan(K, *ins)
+    finally:
+        K.ssd_scan_set_impl(0)
+    assert torch.equal(y_list, y_grid), (y_list.float() - y_grid.float()).abs().max().item()
+    assert torch.equal(fin_list, fin_grid)
+    f = [t.float() for t in ins]
+    y_ref = R.ssd_recurrence_ref(*f[:5], D=f[5], dt_bias=f[6])[0]
+    scale = y_ref.abs().amax(dim=-1, keepdim=True).clamp_min(1.0)
+    assert ((y_list.float().cpu() - y_ref).abs() / scale).max().item() < 5e-2
+
+
 def test_ssd_scan_golden_and_group_maps(K):
     for tag, gmap in [("g1", "block"), ("g2_tile", "tile"), ("g4_tile", "tile")]:
         g = load_golden(f"mixer_{tag}")
