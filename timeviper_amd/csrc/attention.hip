@@ -415,7 +415,12 @@ __device__ unsigned long long g_fa_stamps[2 * 16 * 8];
 // the first tile of the next.  Non-causal, >= 2 key tiles.  Grid: 8 x (work-groups per XCD); the
 // work-groups of XCD x walk slots x*... of that XCD's contiguous range of (batch, head) pairs, so the
 // query blocks that share K / V still meet in one L2 at about the same time.
-template <typename T, int KS, int DT, int KT>
+// ONES (head_dim a multiple of 8 and < 32 DT: the ViT's 72): the row sums of P come out of the P.V MFMAs.  The pad chunks
+// of the rings are written ONCE (zeros; V column head_dim = 1.0) and the copy lanes that would land on them are switched
+// off (a constant EXEC mask per wave around each piece: the swizzle depends on row & 15 only), so O^T row head_dim
+// accumulates sum_k bf16(P[q][k]) — rescaled by alpha with the rest of the tile — and the per-tile adds for l go away.
+// l is then the sum of the ROUNDED weights, the ones the output was built from.
+template <typename T, int KS, int DT, int KT, bool ONES>
 __global__ __launch_bounds__(512) void flash_fwd_stream_kernel(AttnArgs a) {
   constexpr int NW = 8;
   constexpr int FA_KB = 32 * KT;
@@ -492,6 +497,23 @@ __global__ __launch_bounds__(512) void flash_fwd_stream_kernel(AttnArgs a) {
     offV[i] = (unsigned)(row * (int)a.vsl * (int)sizeof(T)) + coV[i];
   }
   const unsigned m0_wave = (unsigned)(wave * 1024);
+  // ONES: lanes whose slot is a pad chunk stay out of the copies (same lanes for every piece of a wave)
+  const unsigned long long liveK = __builtin_amdgcn_ballot_w64(((lane & 15) ^ ((4 * wave + (lane >> 4)) & 15)) < dchunks);
+  const unsigned long long liveV = __builtin_amdgcn_ballot_w64(((lane & 15) ^ (4 * ((lane >> 4) & 3))) < dchunks);
+  if constexpr (ONES) {
+    // pad chunks of every ring row: K zeros (they meet Q columns that are zero, but must be finite), V zeros and the
+    // ones column.  16 bytes a chunk; rows are 256 bytes, chunk c of row `row` lives in slot c ^ swizzle(row).
+    const v8 one_first = [] { v8 z = {}; z[0] = from_f32<T>(1.f); return z; }();
+    const v8 zero8 = {};
+    for (int i = tid; i < NS * FA_KB * 16; i += 512) {
+      const int row = i >> 4, c = i & 15;
+      if (c >= dchunks) {
+        *(v8*)(fa_smem + row * ROWB + ((c ^ (row & 15)) << 4)) = zero8;
+        *(v8*)(fa_smem + NS * TILEB + row * ROWB + ((c ^ (4 * (row & 3))) << 4)) = c == dchunks ? one_first : zero8;
+      }
+    }
+    __syncthreads();
+  }
   // tile `kt` of the sequence at kpx / vpx into ring stage `stage`: piece j (0..PPW-1; K first)
   struct TileCopy { const unsigned char *tk, *tv; unsigned mk; int left; };
   auto tile_copy = [&](const T* kpx, const T* vpx, int kt, int stage) {
@@ -510,7 +532,11 @@ __global__ __launch_bounds__(512) void flash_fwd_stream_kernel(AttnArgs a) {
       const int rr = min(p_row[i], c.left - 1);
       off = (unsigned)(rr * (int)(isK ? a.ksl : a.vsl) * (int)sizeof(T)) + (isK ? coK[i] : coV[i]);
     }
-    ssdk::glds16(isK ? c.tk : c.tv, off, c.mk + (unsigned)(i * NW * 1024) + (isK ? 0u : (unsigned)(NS * TILEB)));
+    if constexpr (ONES)
+      ssdk::glds16_lanes(isK ? c.tk : c.tv, off, c.mk + (unsigned)(i * NW * 1024) + (isK ? 0u : (unsigned)(NS * TILEB)),
+                         isK ? liveK : liveV);
+    else
+      ssdk::glds16(isK ? c.tk : c.tv, off, c.mk + (unsigned)(i * NW * 1024) + (isK ? 0u : (unsigned)(NS * TILEB)));
   };
 
   int k_rd[KS];
@@ -639,9 +665,9 @@ __global__ __launch_bounds__(512) void flash_fwd_stream_kernel(AttnArgs a) {
           const f32x2 pp = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
           sacc[t][i] = pp[0];
           sacc[t][i + 1] = pp[1];
-          ps2 += pp;
+          if constexpr (!ONES) ps2 += pp;
         }
-      l_run = l_run * alpha + (ps2[0] + ps2[1]);
+      if constexpr (!ONES) l_run = l_run * alpha + (ps2[0] + ps2[1]);
       if (__builtin_amdgcn_ballot_w64(m_new > m_run)) {
         const f32x2 al2 = {alpha, alpha};
 #pragma unroll
@@ -700,7 +726,19 @@ __global__ __launch_bounds__(512) void flash_fwd_stream_kernel(AttnArgs a) {
     {
       const int h = pair % a.Hq, b = pair / a.Hq;
       const int qrow = qblk * QB + wave * FA_QW + r;
-      const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+      float l_tot;
+      if constexpr (ONES) {
+        // O^T row head_dim of query r: d-tile DT - 1, local row D - 32 (DT - 1) (a multiple of 8: element 4 (row / 8) of
+        // the lane with hh = 0)
+        const int rl8 = (D - 32 * (DT - 1)) >> 3;
+        float lv = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) lv = g == rl8 ? oacc[DT - 1][4 * g] : lv;
+        const float lo = __shfl_xor(lv, 32, 64);
+        l_tot = hh ? lo : lv;
+      } else {
+        l_tot = l_run + __shfl_xor(l_run, 32, 64);
+      }
       const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
       // A lane holds 4 output columns (8 bytes) per (d-tile, group g): columns 32 dt + 8 g + 4 hh .. + 3.  The halves
       // hh = 0 / 1 of a lane pair (r, r + 32) own the two halves of 8 consecutive columns, so one
@@ -819,10 +857,17 @@ int launch_fa_d(const AttnArgs& a, int B, hipStream_t st) {
           flash_fwd_kernel<T, KS, DT, 8, KT><<<dim3((unsigned)(pairs * nqb), 1, 1), 512, lds, st>>>(ax);
         } else if (stream_ && a.Lk > 32 * KT && slots > tv_cu_count() / 8) {
           // one resident work-group per CU streams its share of the query blocks
-          e = hipFuncSetAttribute((const void*)flash_fwd_stream_kernel<T, KS, DT, KT>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-          if (e == hipSuccess)
-            flash_fwd_stream_kernel<T, KS, DT, KT><<<dim3((unsigned)(8 * (tv_cu_count() / 8)), 1, 1), 512, lds, st>>>(ax);
+          static const int ones_ = [] { const char* v = getenv("TV_FA_ONES"); return v ? atoi(v) : 1; }();
+          const dim3 grid_s((unsigned)(8 * (tv_cu_count() / 8)), 1, 1);
+          if (ones_ && a.D % 8 == 0 && a.D < 32 * DT) {
+            e = hipFuncSetAttribute((const void*)flash_fwd_stream_kernel<T, KS, DT, KT, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e == hipSuccess) flash_fwd_stream_kernel<T, KS, DT, KT, true><<<grid_s, 512, lds, st>>>(ax);
+          } else {
+            e = hipFuncSetAttribute((const void*)flash_fwd_stream_kernel<T, KS, DT, KT, false>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e == hipSuccess) flash_fwd_stream_kernel<T, KS, DT, KT, false><<<grid_s, 512, lds, st>>>(ax);
+          }
         } else {
           flash_fwd_kernel<T, KS, DT, 8, KT><<<dim3((unsigned)(pairs * nqb), 1, 1), 512, lds, st>>>(ax);
         }
