@@ -313,6 +313,8 @@ int tv_flash_attn_fwd(const void* q, const void* k, const void* v, void* o,
  * (flash_fwd_w64_kernel), 2 = the same in-wave pipeline on 16-row halves, 8 waves, two per SIMD
  * (flash_fwd_w32_kernel); both bf16, >= 256 keys, row strides >= 128 elements; both slower at head_dim 72 —
  * DESIGN.md §5 — and therefore not the default.  Results agree within the operator's tolerance.
+ * 3 = the streaming kernel with the row sums of P on the vector pipe (the form before round 5's ones column in the V
+ * ring: `l` summed in fp32 before P is rounded) — always built, for A/B runs and tests.
  * Initial value: env TV_FA_W64. */
 void tv_flash_attn_set_variant(int variant);
 /* 1 when the library was built with -DTV_FA_VARIANTS (the two variants above are compiled in), 0 in the

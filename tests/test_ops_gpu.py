@@ -513,6 +513,40 @@ def test_flash_attention_streaming(K, dtype, B, Lq, Lk, Hq, Hkv, D):
     assert torch.equal(o, o2)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,Lq,Lk,Hq,Hkv,D", [
+    (24, 729, 729, 16, 16, 72),      # SigLIP: pad chunks 9..15 of the rings, the ones column is V column 72
+    (11, 257, 257, 16, 16, 88),      # InternVideo2: pad chunks 11..15, ones column 88, ragged last tile
+    (7, 600, 97, 16, 16, 72),        # the second key tile holds ONE key (its other rows repeat it, weight 0)
+])
+def test_flash_attention_streaming_row_sums_on_the_matrix_pipe(K, dtype, B, Lq, Lk, Hq, Hkv, D):
+    """The default streaming kernel takes P's row sums out of the P.V MFMAs (a 1.0 column in the V ring's first pad chunk,
+    copy lanes of the pad chunks switched off); `flash_attn_set_variant(3)` is the same kernel with the sums on the vector
+    pipe.  Same products, `l` summed from the rounded weights instead of the fp32 ones: the outputs differ by rounding
+    only (one step of the output type on a few elements), the log-sum-exp by less than 2e-3."""
+    g = torch.Generator().manual_seed(Lq * 11 + Lk + D)
+    qkv = torch.randn(B, max(Lq, Lk), Hq + 2 * Hkv, D, generator=g).to(dtype).to(DEV)
+    q, k, v = qkv[:, :Lq, :Hq], qkv[:, :Lk, Hq:Hq + Hkv], qkv[:, :Lk, Hq + Hkv:]
+    q = q * 2.0                                                    # sharper rows: few keys carry the weight
+    k[:, Lk - 1] *= 4.0
+    o1, lse1 = K.flash_attn_func(q, k, v, causal=False, return_lse=True)
+    K.flash_attn_set_variant(3)
+    try:
+        o0, lse0 = K.flash_attn_func(q, k, v, causal=False, return_lse=True)
+    finally:
+        K.flash_attn_set_variant(0)
+    assert torch.isfinite(o1.float()).all()
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    d = (o1.float() - o0.float()).abs()
+    assert (d <= 2 * eps * o0.float().abs() + 1e-6).all(), d.max().item()
+    assert (d > 0).float().mean().item() < 0.5                     # most elements round to the same value
+    assert (lse1 - lse0).abs().max().item() < 2e-3
+    o_ref, _ = R.attention_ref(q.float().cpu(), k.float().cpu(), v.float().cpu(), False)
+    e1 = (o1.float().cpu() - o_ref).norm() / o_ref.norm()
+    e0 = (o0.float().cpu() - o_ref).norm() / o_ref.norm()
+    assert e1 < 1.05 * e0 + 1e-5, (e1.item(), e0.item())           # and is no further from the fp32 oracle
+
+
 @pytest.mark.parametrize("B,Lq,Lk,Hq,Hkv,D", [
     (24, 729, 729, 16, 16, 72),      # SigLIP frames: 3 query blocks, 12 key tiles, the last one holds 25 keys
     (13, 300, 300, 13, 13, 72),      # 5 key tiles with a ragged tail, 2 query blocks, the last XCD's range ends early

@@ -80,6 +80,7 @@ struct AttnArgs {
   int nqb, nb;       // nqb > 0: 1-D XCD-aware grid, nqb query blocks per (batch, head), nb batches; 0: 3-D grid
   int ppx;           // streaming kernel: (batch, head) pairs per XCD
   int o16;           // streaming kernel: o rows are 16-byte aligned (wide epilogue stores)
+  int notrim;        // streaming kernel (dev, TV_FA_TRIM=0): the last key tile runs all its sub-tiles
 };
 
 // KS = ceil(D/16) k-steps of QK^T, DT = ceil(D/32) d-tiles of PV, NW waves per workgroup.
@@ -606,18 +607,20 @@ __global__ __launch_bounds__(512) void flash_fwd_stream_kernel(AttnArgs a) {
       const unsigned stage_off = (unsigned)(stage * TILEB);
       const unsigned cK = sK_off + stage_off, cV = sV_off + stage_off;
 
-      f32x16 sacc[KT];
-      v8 kf[KT][KS];
+      auto tile_body = [&](auto nt_c) __attribute__((always_inline)) {
+      constexpr int NT = decltype(nt_c)::value;        // live 32-key sub-tiles of this tile
+      f32x16 sacc[NT];
+      v8 kf[NT][KS];
       unsigned kb[KS];
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) kb[ks] = cK + (unsigned)k_rd[ks];
 #pragma unroll
-      for (int t = 0; t < KT; ++t)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) kf[t][ks] = Frag<T>::row_read(lds_at(kb[ks]) + t * (32 * ROWB));
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int t = 0; t < KT; ++t) {
+      for (int t = 0; t < NT; ++t) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) sacc[t][i] = 0.f;
 #pragma unroll
@@ -625,21 +628,21 @@ __global__ __launch_bounds__(512) void flash_fwd_stream_kernel(AttnArgs a) {
           sacc[t] = Frag<T>::mfma(kf[t][ks], qf[ks], sacc[t]);
           // the copies of tile kt+2 go out between the MFMAs (placing them between the exponentials
           // of the softmax instead measured the same)
-          constexpr int every = (KT * KS) / PPW > 0 ? (KT * KS) / PPW : 1;
+          constexpr int every = (NT * KS) / PPW > 0 ? (NT * KS) / PPW : 1;
           const int idx = t * KS + ks;
           if (ahead && idx % every == 0 && idx / every < PPW) issue_piece(pf, idx / every);
         }
       }
       if (ahead) {
 #pragma unroll
-        for (int i = (KT * KS) / ((KT * KS) / PPW > 0 ? (KT * KS) / PPW : 1); i < PPW; ++i)
+        for (int i = (NT * KS) / ((NT * KS) / PPW > 0 ? (NT * KS) / PPW : 1); i < PPW; ++i)
           issue_piece(pf, i);
       }
       FSTAMP(0);
       typedef float f32x2 __attribute__((ext_vector_type(2)));
       if (kbase + FA_KB > a.Lk) {
 #pragma unroll
-        for (int t = 0; t < KT; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             const int key = kbase + t * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
@@ -648,7 +651,7 @@ __global__ __launch_bounds__(512) void flash_fwd_stream_kernel(AttnArgs a) {
       }
       float tmax = -INFINITY;
 #pragma unroll
-      for (int t = 0; t < KT; ++t)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int i = 0; i < 16; i += 2) tmax = fmaxf(fmaxf(tmax, sacc[t][i]), sacc[t][i + 1]);
       tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
@@ -658,7 +661,7 @@ __global__ __launch_bounds__(512) void flash_fwd_stream_kernel(AttnArgs a) {
       const f32x2 sc2 = {a.scale_log2, a.scale_log2}, nm2 = {-m_use, -m_use};
       f32x2 ps2 = {0.f, 0.f};
 #pragma unroll
-      for (int t = 0; t < KT; ++t)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int i = 0; i < 16; i += 2) {
           const f32x2 e = __builtin_elementwise_fma(f32x2{sacc[t][i], sacc[t][i + 1]}, sc2, nm2);
@@ -695,8 +698,8 @@ __global__ __launch_bounds__(512) void flash_fwd_stream_kernel(AttnArgs a) {
         v4 vlo[2][DT], vhi[2][DT];
         read_v(0, vlo[0], vhi[0]);
 #pragma unroll
-        for (int s_ = 0; s_ < 2 * KT; ++s_) {
-          if (s_ < 2 * KT - 1) read_v(s_ + 1, vlo[(s_ + 1) & 1], vhi[(s_ + 1) & 1]);
+        for (int s_ = 0; s_ < 2 * NT; ++s_) {
+          if (s_ < 2 * NT - 1) read_v(s_ + 1, vlo[(s_ + 1) & 1], vhi[(s_ + 1) & 1]);
           const int t = s_ >> 1, rb = (s_ & 1) * 8;
           v8 pf;
 #pragma unroll
@@ -711,6 +714,14 @@ __global__ __launch_bounds__(512) void flash_fwd_stream_kernel(AttnArgs a) {
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+      };
+      // a frame's last tile is rarely full (729 keys = 7 x 96 + 57): sub-tiles that hold no key at all are left out of
+      // the products, the exponentials and the V reads (the copies still bring the whole tile: the ring's shape is fixed)
+      const int live_keys = a.Lk - kbase;
+      // (not at 6 k-steps: three bodies beside 24 more fragment registers do not fit the 256)
+      if (KT < 3 || KS > 5 || live_keys > 64 || a.notrim) tile_body(std::integral_constant<int, KT>{});
+      else if (live_keys > 32) tile_body(std::integral_constant<int, (KT > 2 ? 2 : KT)>{});
+      else tile_body(std::integral_constant<int, 1>{});
       FSTAMP(2);
       // the next tile (copied an iteration ago) must have landed; this iteration's copies stay in flight
       if (ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
@@ -858,8 +869,10 @@ int launch_fa_d(const AttnArgs& a, int B, hipStream_t st) {
         } else if (stream_ && a.Lk > 32 * KT && slots > tv_cu_count() / 8) {
           // one resident work-group per CU streams its share of the query blocks
           static const int ones_ = [] { const char* v = getenv("TV_FA_ONES"); return v ? atoi(v) : 1; }();
+          static const int trim_ = [] { const char* v = getenv("TV_FA_TRIM"); return v ? atoi(v) : 1; }();
+          ax.notrim = !trim_;
           const dim3 grid_s((unsigned)(8 * (tv_cu_count() / 8)), 1, 1);
-          if (ones_ && a.D % 8 == 0 && a.D < 32 * DT) {
+          if (ones_ && g_fa_variant.load(std::memory_order_relaxed) != 3 && a.D % 8 == 0 && a.D < 32 * DT) {
             e = hipFuncSetAttribute((const void*)flash_fwd_stream_kernel<T, KS, DT, KT, true>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (e == hipSuccess) flash_fwd_stream_kernel<T, KS, DT, KT, true><<<grid_s, 512, lds, st>>>(ax);

@@ -462,6 +462,7 @@ def flash_attn_set_variant(variant: int) -> None:
     two-waves-per-SIMD kernel with 16-row halves, where they apply (non-causal bf16, head_dim 65..80, >= 256 keys;
     include/timeviper_hip.h).  The two variants are measured-slower experiments and only exist in a library built
     with TV_FA_VARIANTS=1 (`flash_attn_variants_built()`); elsewhere the call has no effect.
+    3: the streaming kernel with P's row sums on the vector pipe instead of the ones column (always built; A/B).
     Process-global (dev tools and tests)."""
     _capi.lib().tv_flash_attn_set_variant(int(variant))
 
