@@ -397,6 +397,15 @@ __global__ __launch_bounds__(NW * 64) void flash_fwd_kernel(AttnArgs a) {
 }
 
 
+// ssdk::glds16 for the lanes of `live` only (a wave-uniform mask): the other lanes' 16 LDS bytes keep what they hold.
+__device__ __forceinline__ void glds16_lanes(const void* sbase, unsigned voff, unsigned lds_dst, unsigned long long live) {
+  unsigned keep;
+  unsigned long long ex;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_mov_b64 %1, exec\n\ts_mov_b64 exec, %5\n\t"
+               "global_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep), "=&s"(ex) : "v"(voff), "s"(sbase), "s"(lds_dst), "s"(live) : "memory");
+}
+
 // -DTV_FA_STAMP (dev): waves 0 and 4 of work-group 0 of the streaming kernel sum the cycles of each phase
 // of tile kt (s_memtime): g_fa_stamps[wave/4][kt < 16][phase < 8]; tv_fa_debug_stamps() copies them out.
 #ifdef TV_FA_STAMP
@@ -534,7 +543,7 @@ __global__ __launch_bounds__(512) void flash_fwd_stream_kernel(AttnArgs a) {
       off = (unsigned)(rr * (int)(isK ? a.ksl : a.vsl) * (int)sizeof(T)) + (isK ? coK[i] : coV[i]);
     }
     if constexpr (ONES)
-      ssdk::glds16_lanes(isK ? c.tk : c.tv, off, c.mk + (unsigned)(i * NW * 1024) + (isK ? 0u : (unsigned)(NS * TILEB)),
+      glds16_lanes(isK ? c.tk : c.tv, off, c.mk + (unsigned)(i * NW * 1024) + (isK ? 0u : (unsigned)(NS * TILEB)),
                          isK ? liveK : liveV);
     else
       ssdk::glds16(isK ? c.tk : c.tv, off, c.mk + (unsigned)(i * NW * 1024) + (isK ? 0u : (unsigned)(NS * TILEB)));

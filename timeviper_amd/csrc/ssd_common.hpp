@@ -36,14 +36,6 @@ __device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigne
                "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
-// glds16 for the lanes of `live` only (a wave-uniform mask): the other lanes' 16 LDS bytes keep what they hold.
-__device__ __forceinline__ void glds16_lanes(const void* sbase, unsigned voff, unsigned lds_dst, unsigned long long live) {
-  unsigned keep;
-  unsigned long long ex;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_mov_b64 %1, exec\n\ts_mov_b64 exec, %5\n\t"
-               "global_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep), "=&s"(ex) : "v"(voff), "s"(sbase), "s"(lds_dst), "s"(live) : "memory");
-}
 // Four 1 KiB pieces with ONE M0 set-up: piece j copies *(sbase + vj + 1024 j) to LDS[lds_dst + 1024 j + 16*lane].
 // The instruction offset moves the global and the LDS address alike, so the caller passes vj = (source offset of
 // piece j) - 1024 j (never negative for rows of >= 256 bytes taken in order).
