@@ -388,15 +388,22 @@ def make_qwen2_golden():
     # from a (1,1,L,L) tensor (:560-569) and broadcasts the scores to 4-D, after which the vision
     # slice (:651-653) is empty and torch.cat (:692) raises.  (The nano file keeps the mask 2-D.)
     pd = "uni_1_0.75-uni_3_0.5-uni_4_0.25"
+    # "wc_*": the same three models with well-conditioned projections (q / k weights N(0, 0.08) like the rest) and every
+    # parameter rounded to bf16 before the reference runs in fp32: a bf16 implementation then differs from these logits by
+    # its activations' rounding only, so the GPU test can hold it to 3e-2 (the sharp toys above amplify any bf16 run to
+    # ~ 14 % and only pin the fp32 oracle).
     for tag, kw in [("plain", {}), ("pdrop_nomerge", dict(use_pdrop=True, pdrop_type=pd)),
-                    ("pdrop_transv", dict(use_pdrop=True, pdrop_type=pd, merge_module="CrossAttention"))]:
+                    ("pdrop_transv", dict(use_pdrop=True, pdrop_type=pd, merge_module="CrossAttention")),
+                    ("wc_plain", {}), ("wc_pdrop_nomerge", dict(use_pdrop=True, pdrop_type=pd)),
+                    ("wc_pdrop_transv", dict(use_pdrop=True, pdrop_type=pd, merge_module="CrossAttention"))]:
+        wc = tag.startswith("wc_")
         cfg = q.Qwen2Config(vocab_size=64, hidden_size=64, intermediate_size=96, num_hidden_layers=6,
                             num_attention_heads=4, num_key_value_heads=2, max_position_embeddings=512,
                             rope_theta=10000.0, rms_norm_eps=1e-6, pad_token_id=None, **kw)
         cfg._attn_implementation = "eager"
         torch.manual_seed(31)
         model = q.Qwen2ForCausalLM(cfg).eval().float()
-        g = torch.Generator().manual_seed(32)
+        g = torch.Generator().manual_seed(33 if wc else 32)
         for n, p in model.named_parameters():
             if n.endswith("alpha"):
                 p.fill_(0.7)
@@ -405,7 +412,9 @@ def make_qwen2_golden():
             elif n.endswith("bias"):
                 p.copy_(torch.randn(p.shape, generator=g) * 0.1)
             else:
-                p.copy_(torch.randn(p.shape, generator=g) * (0.4 if ("q_proj" in n or "k_proj" in n) else 0.08))
+                p.copy_(torch.randn(p.shape, generator=g) * (0.4 if ("q_proj" in n or "k_proj" in n) and not wc else 0.08))
+            if wc:
+                p.copy_(p.bfloat16().float())
         ids = torch.randint(0, 64, (1, 43), generator=g)
         args = {}
         if kw:

@@ -113,7 +113,9 @@ def test_internvideo2_mirror_matches_reference(case, is_video):
 
 
 @pytest.mark.parametrize("tag,extra", [("plain", {}), ("pdrop_nomerge", dict(use_pdrop=True)),
-                                       ("pdrop_transv", dict(use_pdrop=True, merge_module="CrossAttention"))])
+                                       ("pdrop_transv", dict(use_pdrop=True, merge_module="CrossAttention")),
+                                       ("wc_plain", {}), ("wc_pdrop_nomerge", dict(use_pdrop=True)),
+                                       ("wc_pdrop_transv", dict(use_pdrop=True, merge_module="CrossAttention"))])
 def test_qwen2_mirror_matches_reference(tag, extra):
     """Qwen2 mirror: reference state dict loads strict; forward (operators replaced by their CPU
     restatements) reproduces the reference logits, including pdrop + TransV."""

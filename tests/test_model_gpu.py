@@ -373,10 +373,14 @@ def test_vlm_dual_encoder_qwen2_matches_parts():
     assert relerr(out[:, -1], ref[:, -1]) < 3e-2
 
 
-@pytest.mark.parametrize("tag,extra", [("plain", {}), ("pdrop_nomerge", dict(use_pdrop=True)),
-                                       ("pdrop_transv", dict(use_pdrop=True, merge_module="CrossAttention"))])
+@pytest.mark.parametrize("tag,extra", [("wc_plain", {}), ("wc_pdrop_nomerge", dict(use_pdrop=True)),
+                                       ("wc_pdrop_transv", dict(use_pdrop=True, merge_module="CrossAttention"))])
 def test_qwen2_bf16_vs_reference_golden(tag, extra):
-    """Qwen2 mirror on the HIP operators (bf16) against the reference's fp32 logits."""
+    """Qwen2 mirror on the HIP operators (bf16) against the REFERENCE's fp32 logits (`oracle/make_golden.py`, fixtures
+    `qwen2_wc_*`: the reference's Qwen2ForCausalLM with well-conditioned projections and bf16-representable parameters, so
+    the two runs differ by the rounding of bf16 activations only).  Bound 3e-2 of the logits' norm, as for the Nano toys.
+    (The sharp `qwen2_{plain,pdrop_*}` fixtures amplify ANY bf16 run to ~ 14 %: they pin the fp32 oracle and the fp32
+    mirror on the CPU — tests/test_oracle_golden.py, tests/test_model_cpu.py — and are not compared in bf16.)"""
     from timeviper_amd.model.llm.qwen2 import Qwen2Config, Qwen2ForCausalLM
     g = load_golden(f"qwen2_{tag}")
     cfg = Qwen2Config(vocab_size=64, hidden_size=64, intermediate_size=96, num_hidden_layers=6,
@@ -390,10 +394,8 @@ def test_qwen2_bf16_vs_reference_golden(tag, extra):
     with torch.no_grad():
         out = model(input_ids=torch.from_numpy(g["ids"]).long().to(DEV), use_cache=False, **args)
     assert out.logits.shape == g["logits"].shape
-    # this toy (sharp attention: q/k weights N(0, 0.4), 6 layers) amplifies bf16 round-off to ~14 %
-    # of the logits' norm on ANY bf16 implementation (the CPU restatement in bf16 included), so the
-    # fp32 reference only bounds it loosely here; the tight check is the well-conditioned model below
-    assert relerr(out.logits, torch.from_numpy(g["logits"])) < 0.25
+    e = relerr(out.logits, torch.from_numpy(g["logits"]))
+    assert e < 3e-2, e
 
 
 @pytest.mark.parametrize("merge", ["no_merge", "CrossAttention"])

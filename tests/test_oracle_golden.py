@@ -214,7 +214,9 @@ QWEN_ARGS = {"first_vision_token_positions": [3], "num_vision_tokens": [24], "te
 
 
 @pytest.mark.parametrize("tag,extra", [("plain", {}), ("pdrop_nomerge", dict(pdrop_type=QWEN_PD)),
-                                       ("pdrop_transv", dict(pdrop_type=QWEN_PD, merge_module="CrossAttention"))])
+                                       ("pdrop_transv", dict(pdrop_type=QWEN_PD, merge_module="CrossAttention")),
+                                       ("wc_plain", {}), ("wc_pdrop_nomerge", dict(pdrop_type=QWEN_PD)),
+                                       ("wc_pdrop_transv", dict(pdrop_type=QWEN_PD, merge_module="CrossAttention"))])
 def test_qwen2_matches_reference(tag, extra):
     """G12: Qwen2ForCausalLM of the reference (eager, fp32): rotary attention, SwiGLU, uniform pdrop
     stages with re-started positions, TransV merge with biased q/k/v."""
