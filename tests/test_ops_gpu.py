@@ -5,6 +5,7 @@ import os
 
 import numpy as np
 import pytest
+from pathlib import Path
 import torch
 
 from conftest import golden_state_dict, load_golden
@@ -305,6 +306,20 @@ def test_ssd_head_generated_step_is_bit_identical_to_the_cpp_step(K, regime, a_l
     assert torch.equal(y1, y0), (regime, (y1.float() - y0.float()).abs().max().item())
     assert torch.equal(f1, f0), (regime, (f1 - f0).abs().max().item())
     assert torch.equal(d1, d0), regime
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_ssd_head_generated_step_fuzz(K, seed):
+    """48 random cases a seed (timeviper_amd/devtools/scan_fuzz.py: shapes, ragged lengths, decay regimes over five decades,
+    softplus / dt_limit / D / dt_bias / initial states / strided packed rows / both group maps): generated step == C++ step,
+    bit for bit."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "scan_fuzz", Path(__file__).resolve().parent.parent / "timeviper_amd" / "devtools" / "scan_fuzz.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bad = mod.run(48, seed)
+    assert not bad, bad[:3]
 
 
 @pytest.mark.parametrize("a_lo,a_hi,dt_mean,dt_std", [(0.002, 0.02, -3.0, 0.3), (0.05, 0.3, -1.0, 0.5), (1.0, 16.0, 0.0, 1.3)])
