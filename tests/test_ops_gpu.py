@@ -508,6 +508,7 @@ def test_flash_attention(K, dtype, B, Lq, Lk, Hq, Hkv, D, causal):
     (11, 257, 257, 16, 16, 88),      # InternVideo2 heads (6 k-steps), 3 ragged key tiles
     (7, 600, 97, 16, 16, 72),        # two key tiles, the second holds ONE key
     (13, 300, 300, 13, 13, 72),      # 169 (batch, head) pairs padded to 176: the last XCD's range ends early
+    (12, 400, 300, 16, 8, 80),       # head_dim 80: K uses all five k-steps, the ones column is V column 80 (chunk 10); GQA
 ])
 def test_flash_attention_streaming(K, dtype, B, Lq, Lk, Hq, Hkv, D):
     """Many short sequences: `flash_fwd_stream_kernel` (one resident work-group per CU walks the query blocks;
@@ -533,6 +534,7 @@ def test_flash_attention_streaming(K, dtype, B, Lq, Lk, Hq, Hkv, D):
     (24, 729, 729, 16, 16, 72),      # SigLIP: pad chunks 9..15 of the rings, the ones column is V column 72
     (11, 257, 257, 16, 16, 88),      # InternVideo2: pad chunks 11..15, ones column 88, ragged last tile
     (7, 600, 97, 16, 16, 72),        # the second key tile holds ONE key (its other rows repeat it, weight 0)
+    (12, 400, 300, 16, 8, 80),       # head_dim 80: no K pad column inside the k-steps, ones column 80
 ])
 def test_flash_attention_streaming_row_sums_on_the_matrix_pipe(K, dtype, B, Lq, Lk, Hq, Hkv, D):
     """The default streaming kernel takes P's row sums out of the P.V MFMAs (a 1.0 column in the V ring's first pad chunk,
