@@ -30,10 +30,7 @@ using namespace ssdk;
 constexpr int CQ = 64;            // tokens per chunk
 constexpr int CN = 128;           // d_state
 constexpr int MAXW = 32;          // walkers per (head, range) of the all-segments pass, at most
-#ifndef TV_CORR_CPW
-#define TV_CORR_CPW 4
-#endif
-constexpr int CPW = TV_CORR_CPW;            // chunks of its horizon per walker (the 20 KB of S_in a walker loads: 14 % of what it moves)
+constexpr int CPW = 4;            // chunks of its horizon per walker (the 20 KB of S_in a walker loads: 14 % of what it moves)
 constexpr int CSLOTS = 64;        // work-groups per (batch, head): a head that never forgets is walked by all of them
                                   // (measured with 8: the slowest heads set the launch time, 808 us in the 9B model)
 // The walk of a head ends where the factor 2^(cs_t log2 e) has fallen below 2^-32: the term is then < 2.5e-10 of
