@@ -283,6 +283,12 @@ int tv_gemm_bf16_fwd(const void* A, const void* W, const void* bias, void* C, in
  * 2 adds the old C in fp32 before the one rounding in both.  mode -1: automatic (default), 0: never, 1:
  * wherever the shape allows (tests); grid: work-groups of the persistent kernel, 0 = one per compute unit. */
 void tv_gemm_set_persist(int mode, int grid);
+/* Of the persistent kernels the first choice is csrc/gemm_drip.hip: 256 x 192 tiles (the ViT's widths 1 152 / 3 456 /
+ * 4 352 are multiples of 192, not of 256) whose finished tile leaves during the NEXT tile's K loop — half of it parked in
+ * LDS, half in accumulator registers, stored one 1 KiB piece per phase with the GELU applied on the way out.  Takes
+ * K >= 640, K % 128 == 0, N % 8 == 0, N >= 192, M >= 256, an fp32 bias for epilogues 0 / 1.  mode -1: automatic (default;
+ * TV_GEMM_DRIP=0 in the environment switches it off), 0: never, 1: wherever the shape allows (tests). */
+void tv_gemm_set_drip(int mode);
 
 /* ------------------------------------------------------------------------
  * A1 / T3 / ViT  fused softmax attention forward (flash-style, no S x S

@@ -11,12 +11,14 @@ fails here instead of producing silently wrong numbers on the GPU."""
 import re
 import shutil
 import subprocess
+import sys
 from pathlib import Path
 
 import pytest
 
 from timeviper_amd import build
 
+ROOT = Path(__file__).resolve().parent.parent
 LLVM = Path("/opt/rocm/lib/llvm/bin")
 needs_tools = pytest.mark.skipif(not (LLVM / "llvm-objdump").exists() or not (LLVM / "llvm-readelf").exists(),
                                  reason="ROCm LLVM tools not found")
@@ -132,9 +134,42 @@ def test_gemm_kernels_spill_nothing(tmp_path):
     """Both GEMM kernels keep five half-tiles of LDS-DMA copies in flight behind hand-counted waits and, at two waves per
     SIMD, live within 256 registers: a spill would put scratch loads — which the compiler waits for with vmcnt(0) — into
     the copy queue and drain the pipeline every K-tile.  (Scalar spills into vector lanes are allowed: no memory.)"""
-    for src, pat, n in (("gemm.hip", "gemm_bf16_kernel", 3), ("gemm_persist.hip", "gemm_persist_kernel", 2)):
+    for src, pat, n in (("gemm.hip", "gemm_bf16_kernel", 3), ("gemm_persist.hip", "gemm_persist_kernel", 2),
+                        ("gemm_drip.hip", "gemm_drip_kernel", 3)):
         md = kernel_metadata(src, tmp_path)
         kernels = {k: v for k, v in md.items() if pat in k}
         assert len(kernels) == n, (src, list(md))
         for k, v in kernels.items():
             assert v.get("private_segment_fixed_size") == 0 and v.get("vgpr_spill_count", 0) == 0, (src, k, v)
+
+
+def test_gemm_drip_register_statements_are_current():
+    """csrc/gemm_drip_regs.inc (the statements of the 256 x 192 GEMM that name accumulator registers) is what
+    devtools/gen_gemm_drip_regs.py emits."""
+    r = subprocess.run([sys.executable, str(ROOT / "timeviper_amd" / "devtools" / "gen_gemm_drip_regs.py"), "--check"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+@needs_tools
+def test_gemm_drip_accumulator_registers_are_left_alone(tmp_path):
+    """gemm_drip.hip keeps its accumulators (a[0:95]) and the parked half of the finished tile (a[96:119]) in registers the
+    compiler does not allocate: outside the hand-written statements the compiled kernel must not touch an accumulator
+    register (it is built with -amdgpu-spill-vgpr-to-agpr=0 for that reason), and it must use no scratch."""
+    src = ROOT / "timeviper_amd" / "csrc" / "gemm_drip.hip"
+    out = tmp_path / "gemm_drip.s"
+    flags = [f for f in build.FLAGS if not f.startswith("-fPIC")] + build.FILE_FLAGS["gemm_drip.hip"]
+    r = subprocess.run([build.HIPCC, *flags, "-x", "hip", "-S", "--cuda-device-only", str(src), "-o", str(out)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    inasm, bad = False, []
+    for ln in out.read_text().splitlines():
+        if "#ASMSTART" in ln:
+            inasm = True
+        elif "#ASMEND" in ln:
+            inasm = False
+        elif not inasm and not ln.lstrip().startswith((";", ".")) and re.search(r"[\s,\[]a\[?\d", ln):
+            bad.append(ln.strip())
+        if "scratch_" in ln:
+            bad.append(ln.strip())
+    assert not bad, bad[:10]

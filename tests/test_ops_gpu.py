@@ -1209,6 +1209,7 @@ def test_gemm_persistent_kernel(K, M, N, Kd, grid, epi):
             return K.linear_fused(a, w, None, epilogue=2, out=c0.clone())
         return K.linear_fused(a, w, b, epilogue=epi)
     try:
+        K.gemm_set_drip(0)                # (the 256 x 192 kernel has its own test below)
         K.gemm_set_persist(1, grid)
         out = run()
         torch.cuda.synchronize()
@@ -1216,6 +1217,7 @@ def test_gemm_persistent_kernel(K, M, N, Kd, grid, epi):
         tile = run()
     finally:
         K.gemm_set_persist(-1, 0)
+        K.gemm_set_drip(-1)
     if epi == 2:
         ref = acc + c0.double().cpu()
     else:
@@ -1238,16 +1240,69 @@ def test_gemm_persistent_repeated_runs_are_identical(K):
     c0 = torch.randn(M, N, generator=g).bfloat16().to(DEV)
     try:
         K.gemm_set_persist(1, 64)
-        for epi in (0, 1, 2):
-            outs = []
-            for _ in range(20):
-                outs.append(K.linear_fused(a, w, None, epilogue=2, out=c0.clone()) if epi == 2
-                            else K.linear_fused(a, w, b, epilogue=epi))
-            torch.cuda.synchronize()
-            for o in outs[1:]:
-                assert torch.equal(o, outs[0]), f"epilogue {epi}: two launches differ"
+        for drip in (0, 1):               # the 256 x 256 persistent kernel, then the 256 x 192 one (csrc/gemm_drip.hip)
+            K.gemm_set_drip(drip)
+            for epi in (0, 1, 2):
+                outs = []
+                for _ in range(20):
+                    outs.append(K.linear_fused(a, w, None, epilogue=2, out=c0.clone()) if epi == 2
+                                else K.linear_fused(a, w, b, epilogue=epi))
+                torch.cuda.synchronize()
+                for o in outs[1:]:
+                    assert torch.equal(o, outs[0]), f"drip {drip} epilogue {epi}: two launches differ"
     finally:
         K.gemm_set_persist(-1, 0)
+        K.gemm_set_drip(-1)
+
+
+@pytest.mark.parametrize("M,N,Kd,grid", [(1024, 1152, 1152, 8), (2187, 4352, 1152, 8), (1500, 1160, 1152, 16),
+                                         (1300, 1152, 4352, 8), (729 * 8, 3456, 1408, 64), (256, 192, 1152, 8),
+                                         (729 * 16, 1152, 1152, 64)])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_gemm_drip_kernel(K, M, N, Kd, grid, epi):
+    """The 256 x 192 persistent GEMM (csrc/gemm_drip.hip: the finished tile leaves during the next tile's K loop, half of
+    it parked in LDS and half in accumulator registers; old C by LDS-DMA into the staging rows; the bias as the
+    accumulators' start value) on small grids so that every work-group walks several tiles, shifted edge tiles in M and N
+    included: against the fp64 product, and against the per-tile kernel — identical for the accumulating epilogue (same
+    order of additions), within one bf16 rounding for the bias epilogues (the bias enters before the products instead of
+    after them: a different fp32 rounding order, which flips the final rounding of a few elements in 10 000)."""
+    g = torch.Generator().manual_seed(M + N + Kd + epi)
+    a = (torch.randn(M, Kd, generator=g) * 0.5).bfloat16().to(DEV)
+    w = (torch.randn(N, Kd, generator=g) * (1.0 / math.sqrt(Kd))).bfloat16().to(DEV)
+    b = torch.randn(N, generator=g).bfloat16().float().to(DEV)
+    c0 = torch.randn(M, N, generator=g).bfloat16().to(DEV)
+    acc = a.double().cpu() @ w.double().cpu().t()
+
+    def run():
+        if epi == 2:
+            return K.linear_fused(a, w, None, epilogue=2, out=c0.clone())
+        return K.linear_fused(a, w, b, epilogue=epi)
+    try:
+        K.gemm_set_persist(1, grid)
+        K.gemm_set_drip(1)
+        out = run()
+        torch.cuda.synchronize()
+        K.gemm_set_drip(0)
+        K.gemm_set_persist(0, 0)
+        tile = run()
+    finally:
+        K.gemm_set_persist(-1, 0)
+        K.gemm_set_drip(-1)
+    if epi == 2:
+        ref = acc + c0.double().cpu()
+    else:
+        pre = acc + b.double().cpu()
+        ref = torch.nn.functional.gelu(pre.float().bfloat16().double()) if epi == 1 else pre
+    close(out, ref, 2.0 ** -8 * (2.2 if epi == 1 else 1.0), 1e-2 if epi == 1 else 2e-3, f"drip gemm epi {epi}")
+    if epi == 2:
+        assert torch.equal(out, tile), "256 x 192 and per-tile kernel differ (accumulating epilogue)"
+    else:
+        diff = (out.float() - tile.float()).abs()
+        frac = float((diff > 0).float().mean())
+        assert frac < 2e-3, f"{frac:.2e} of the elements differ from the per-tile kernel"
+        # one bf16 step of the larger of the two (GELU: of the pre-activation, slope <= 1.13)
+        lim = torch.maximum(out.float().abs(), tile.float().abs()) * 2.0 ** -7 * (1.2 if epi == 1 else 1.0) + 1e-3
+        assert bool((diff <= lim).all()), "more than one bf16 rounding step from the per-tile kernel"
 
 
 # ---------------------------------------------------------------- ragged / padded batches (flash_attention_class.py:59-91)

@@ -44,6 +44,7 @@ SIGNATURES = {
     "tv_selective_state_update": (_i, [_p] * 9 + [_i] * 7 + [_p]),
     "tv_gemm_bf16_fwd": (_i, [_p, _p, _p, _p, _l, _i, _i, _l, _l, _l, _i, _i, _p]),
     "tv_gemm_set_persist": (None, [_i, _i]),
+    "tv_gemm_set_drip": (None, [_i]),
     "tv_flash_attn_fwd": (_i, [_p] * 5 + [_i] * 6 + [_l] * 12 + [_f, _i, _i, _p]),
     "tv_flash_attn_set_variant": (None, [_i]),
     "tv_flash_attn_variants_built": (_i, []),

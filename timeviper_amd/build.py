@@ -33,11 +33,17 @@ if os.environ.get("TV_FA_STAMP"):       # dev only: per-phase stamps in the stre
     FLAGS.append("-DTV_FA_STAMP")
 if os.environ.get("TV_FA_VARIANTS"):    # dev only: the two measured-slower ViT attention kernels (attention_variants.hpp)
     FLAGS.append("-DTV_FA_VARIANTS")
+if os.environ.get("TV_DRIP_STAMP"):     # dev only: per-phase cycle sums in the 256 x 192 GEMM (gemm_drip.hip)
+    FLAGS.append("-DTV_DRIP_STAMP")
 if os.environ.get("TV_SLICE_STAMP"):    # dev only: per-wave barrier-wait stamps in ssd_slice.hip
     FLAGS.append("-DTV_SLICE_STAMP")
 
 
 FLAGS += os.environ.get("TV_EXTRA_HIPCC_FLAGS", "").split()   # dev only
+
+# per-file flags.  gemm_drip.hip names its accumulator registers (a[0:119], csrc/gemm_drip_regs.inc) instead of handing
+# them to the register allocator: the compiler must then never park a spilled vector register in an accumulator register.
+FILE_FLAGS = {"gemm_drip.hip": ["-mllvm", "-amdgpu-spill-vgpr-to-agpr=0"]}
 
 
 def _sources():
@@ -59,13 +65,13 @@ def _hash(paths, extra: str = "") -> str:
 
 def source_id() -> str:
     """Hash of every source, header and compiler flag the library is built from."""
-    return _hash(_sources() + _headers(), " ".join(FLAGS))
+    return _hash(_sources() + _headers(), " ".join(FLAGS) + repr(sorted(FILE_FLAGS.items())))
 
 
 def _compile(src: Path, force: bool, build_id: str) -> Path:
     obj = OBJ / (src.name + ".o")
     tag = OBJ / (src.name + ".hash")
-    flags = list(FLAGS)
+    flags = list(FLAGS) + FILE_FLAGS.get(src.name, [])
     if src.name == "capi.cpp":                    # the one translation unit that carries the id
         flags.append(f'-DTV_BUILD_ID="{build_id}"')
     want = _hash([src] + _headers(), " ".join(flags))

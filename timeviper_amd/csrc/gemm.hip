@@ -368,7 +368,9 @@ extern "C" int tv_gemm_bf16_fwd(const void* A, const void* W, const void* bias, 
   }
   if ((int64_t)a.tiles_m * a.tiles_n >= (1ll << 31)) TV_UNSUPPORTED("gemm: too many tiles");
   hipStream_t st = (hipStream_t)stream;
-  // the ViT's big shapes: persistent work-groups, tile epilogue inside the main loop (gemm_persist.hip)
+  // the ViT's big shapes: persistent work-groups — 256 x 192 tiles that leave during the next tile's K loop (gemm_drip.hip),
+  // else 256 x 256 tiles with the epilogue by quadrants inside the main loop (gemm_persist.hip)
+  if (drip_takes(a, epilogue, persist_grid())) return launch_drip(a, epilogue, persist_grid(), st);
   if (persist_takes(a, epilogue)) return launch_persist(a, epilogue, st);
   switch (epilogue) {
     case EPI_BIAS: return launch_gemm<EPI_BIAS>(a, st);

@@ -48,5 +48,10 @@ __device__ __forceinline__ float gelu_erf_f(float x) {
 // kernel takes; the caller then runs the per-tile kernel.
 bool persist_takes(const GemmArgs& a, int epilogue);
 int launch_persist(const GemmArgs& a, int epilogue, hipStream_t st);
+int persist_grid();        // work-groups of the persistent kernels (one per compute unit unless tv_gemm_set_persist says otherwise)
+
+// gemm_drip.hip: persistent 256 x 192 tiles whose finished tile leaves during the next tile's K loop
+bool drip_takes(const GemmArgs& a, int epilogue, int grid);
+int launch_drip(const GemmArgs& a, int epilogue, int grid, hipStream_t st);
 
 }  // namespace tvgemm

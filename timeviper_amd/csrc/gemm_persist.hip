@@ -435,6 +435,7 @@ int launch_persist(const GemmArgs& a, int epilogue, hipStream_t st) {
 }
 
 void set_persist(int mode, int grid) { g_mode = mode; g_grid = grid; }
+int persist_grid() { return grid_size(); }
 
 }  // namespace tvgemm
 

@@ -309,6 +309,12 @@ def gemm_set_persist(mode: int = -1, grid: int = 0) -> None:
     _capi.lib().tv_gemm_set_persist(int(mode), int(grid))
 
 
+def gemm_set_drip(mode: int = -1) -> None:
+    """The 256 x 192-tile persistent GEMM (csrc/gemm_drip.hip): -1 automatic (first choice wherever the shape allows and
+    every compute unit gets a few tiles), 0 never, 1 wherever the shape allows (tests on small grids)."""
+    _capi.lib().tv_gemm_set_drip(int(mode))
+
+
 # ------------------------------------------------------------------- SSD scan
 def _row_view(t: torch.Tensor, inner: int):
     """(B, L, ...) tensor whose trailing dims are contiguous with `inner`
