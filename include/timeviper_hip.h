@@ -277,11 +277,11 @@ int tv_selective_state_update(void* state, const void* x, const void* dt,
 int tv_gemm_bf16_fwd(const void* A, const void* W, const void* bias, void* C, int64_t M, int N,
                      int K, int64_t lda, int64_t ldw, int64_t ldc, int epilogue, int bias_dtype,
                      void* stream);
-/* Big shapes (both extents >= 256, N % 8 == 0, >= 4 tiles per compute unit; epilogue 2: K >= 1 152) run on a
- * PERSISTENT kernel whose tile epilogue is hidden inside the main loop (csrc/gemm_persist.hip); the rest on
- * one work-group per 256 x 256 tile (csrc/gemm.hip).  Same results bit for bit for epilogues 0 / 1; epilogue
- * 2 adds the old C in fp32 before the one rounding in both.  mode -1: automatic (default), 0: never, 1:
- * wherever the shape allows (tests); grid: work-groups of the persistent kernel, 0 = one per compute unit. */
+/* Big shapes (both extents >= 256, N % 8 == 0, >= 4 tiles per compute unit) with epilogue 0 or 1 run on a PERSISTENT
+ * kernel whose tile epilogue is hidden inside the main loop (csrc/gemm_persist.hip); the rest — epilogue 2 always — on one
+ * work-group per 256 x 256 tile (csrc/gemm.hip).  Same results bit for bit for epilogues 0 / 1.  mode -1: automatic
+ * (default), 0: never, 1: wherever the shape allows (tests); grid: work-groups of the persistent kernels, 0 = one per
+ * compute unit. */
 void tv_gemm_set_persist(int mode, int grid);
 /* Of the persistent kernels the first choice is csrc/gemm_drip.hip: 256 x 192 tiles (the ViT's widths 1 152 / 3 456 /
  * 4 352 are multiples of 192, not of 256) whose finished tile leaves during the NEXT tile's K loop — half of it parked in

@@ -22,6 +22,22 @@ needs2 = pytest.mark.skipif(NGPU < 2, reason="needs two GPUs: RCCL refuses two r
 UNI3 = "uni_2_0.75-uni_3_0.5-uni_6_0.25"
 
 
+class _TimedWork:
+    """What an async collective returns, with wait() timed: delegates everything else to the real Work."""
+
+    def __init__(self, work, timer, name, nbytes, t0):
+        self._work, self._timer, self._name, self._nbytes, self._t0 = work, timer, name, nbytes, t0
+
+    def wait(self, *a, **kw):
+        r = self._work.wait(*a, **kw)
+        torch.cuda.synchronize()
+        self._timer.rows.append((self._name, self._nbytes, (time.perf_counter() - self._t0) * 1e3))
+        return r
+
+    def __getattr__(self, item):
+        return getattr(self._work, item)
+
+
 class CollectiveTimer:
     """Wall time of every torch.distributed collective the runner issues (rank 0 prints a table when the test runs: the
     first numbers RCCL over xGMI gives this code, to be held against profiles/r05_sp_prediction.json).  Blocking calls are
@@ -45,15 +61,8 @@ class CollectiveTimer:
                 t0 = time.perf_counter()
                 work = _fn(*a, **kw)
                 if kw.get("async_op") and work is not None:
-                    timer, wait = self, work.wait
-
-                    def timed_wait(*wa, **wk):
-                        r = wait(*wa, **wk)
-                        torch.cuda.synchronize()
-                        timer.rows.append((_name + " (async)", nbytes, (time.perf_counter() - t0) * 1e3))
-                        return r
-                    work.wait = timed_wait
-                    return work
+                    # (c10d's Work is a pybind class without settable attributes: hand back a small stand-in that times wait())
+                    return _TimedWork(work, self, _name + " (async)", nbytes, t0)
                 torch.cuda.synchronize()
                 self.rows.append((_name, nbytes, (time.perf_counter() - t0) * 1e3))
                 return work

@@ -1191,11 +1191,10 @@ def test_gemm_fused_gelu_equals_gemm_then_gelu(K):
                                          (4096, 1152, 256, 8)])
 @pytest.mark.parametrize("epi", [0, 1, 2])
 def test_gemm_persistent_kernel(K, M, N, Kd, grid, epi):
-    """The persistent GEMM (csrc/gemm_persist.hip: tile epilogue inside the next tile's main loop, old C through the
-    matrix pipe) forced onto small grids so that every work-group walks several tiles, shifted edge tiles in M and N
-    included: against the fp64 product, and bit-equal to the per-tile kernel for the bias epilogues."""
-    if epi == 2 and Kd < 1152:
-        pytest.skip("accumulate variant takes K >= 1 152")
+    """The persistent GEMM (csrc/gemm_persist.hip: tile epilogue inside the next tile's main loop) forced onto small grids so
+    that every work-group walks several tiles, shifted edge tiles in M and N included: against the fp64 product, and
+    bit-equal to the per-tile kernel for the bias epilogues.  (The accumulating epilogue has no 256 x 256 persistent form —
+    it runs on the per-tile kernel whatever the setting: that case only re-checks the dispatch.)"""
     g = torch.Generator().manual_seed(M + N + Kd + epi)
     a = (torch.randn(M, Kd, generator=g) * 0.5).bfloat16().to(DEV)
     w = (torch.randn(N, Kd, generator=g) * (1.0 / math.sqrt(Kd))).bfloat16().to(DEV)

@@ -230,12 +230,18 @@ __global__ __launch_bounds__(512) void gemm_drip_kernel(DArgs da) {
     const void* base = uniform_ptr(a.C + (int64_t)(m0 + r0) * ldc + (n0 + c0));
     if (da.dbg & 2) { asm volatile("" ::"v"(o)); return; }
     const int skr = skip_rows(m0), skc = skip_cols(n0);
+    // (s_nop: a vector instruction must not overwrite the data registers of a 16-byte store in the next cycle, and the
+    // compiler does not know this statement is a store)
     if ((skr | skc) == 0) {
-      asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(drip_goff), "v"(o), "s"(base) : "memory");
+      const int fl = (da.dbg >> 6) & 3;       // dev: store flavours
+      if (fl == 0) asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(drip_goff), "v"(o), "s"(base) : "memory");
+      else if (fl == 1) asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(drip_goff), "v"(o), "s"(base) : "memory");
+      else if (fl == 2) asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(drip_goff), "v"(o), "s"(base) : "memory");
+      else asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1\n\ts_nop 1" ::"v"(drip_goff), "v"(o), "s"(base) : "memory");
     } else {          // shifted edge tile: the rows / columns that belong to the neighbour stay
       const int lx = opaque_lane();
       if (r0 + (lx >> 3) >= skr && c0 + 8 * (lx & 7) >= skc)
-        asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(drip_goff), "v"(o), "s"(base) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(drip_goff), "v"(o), "s"(base) : "memory");
     }
   };
   // old C of m-half 0 of the tile at (m0, n0) into the staging rows by LDS-DMA: a copy writes 1 KiB of LDS in lane order,
@@ -586,7 +592,7 @@ int launch_drip(const GemmArgs& a0, int epilogue, int grid, hipStream_t st) {
   da.ntiles = a0.tiles_m * da.tiles_n;
   {
     static const int gm_env = [] { const char* e = getenv("TV_GEMM_DRIP_GROUP_M"); return e ? atoi(e) : 0; }();     // dev tool
-    da.g.group_m = gm_env > 0 ? gm_env : (da.tiles_n >= 12 ? 4 : 8);
+    da.g.group_m = gm_env > 0 ? gm_env : 4;      // measured (2 / 4 / 8 / 16) at N 1 152 and 3 456: 4
     if (da.g.group_m > a0.tiles_m) da.g.group_m = a0.tiles_m;
   }
   static const int dbg_env = [] { const char* e = getenv("TV_GEMM_DBG"); return e ? atoi(e) : 0; }();

@@ -630,7 +630,7 @@ extern "C" int tv_layernorm_fwd(const void* x, const void* delta, const void* we
   TV_CHECK_ARG(rows >= 0 && dim > 0, "layernorm: bad sizes");
   if (rows == 0) return TV_OK;
   const int vec = dtype == TV_F32 ? 4 : 8;
-  if (!aligned16(x) || !aligned16(y) || !aligned16(weight) || (bias && !aligned16(bias)) ||
+  if (!aligned16(x) || !aligned16(y) || !aligned16(weight) || (bias && !aligned16(bias)) || (row_bias && !aligned16(row_bias)) ||
       (delta && !aligned16(delta)) || (sum_out && !aligned16(sum_out)) || x_stride % vec ||
       y_stride % vec || (delta && delta_stride % vec) || (sum_out && sum_stride % vec))
     TV_UNSUPPORTED("layernorm: pointers/strides must be 16-byte aligned");

@@ -95,7 +95,7 @@ __device__ __forceinline__ void decay_prefix_wave(const CorrArgs& a, const int h
     hor += __popcll(__ballot(c0 + lane < nch && !(pv < C_UNDERFLOW)));
     carry += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inc), 63));
   }
-  if (a.items && nch > 0) {         // (range 11 bits | head 10 | walker 5 | walkers - 1 5)
+  if (a.items && nch > 0) {         // (range 12 bits | head 10 | walker 5 | walkers - 1 5; the launcher keeps z < 4 096, h < 1 024)
     const int nwalk = min(MAXW, max(1, (hor + CPW - 1) / CPW));
     unsigned base = 0;
     if (lane == 0) base = atomicAdd(&a.counters[0], (unsigned)nwalk);
@@ -431,6 +431,8 @@ int tv_ssd_correct_all_launch(void* y, const void* dt, const void* A, const void
     // 8: 2 499 / 699, 16: 2 613 / 785, 32: 2 827 / 961).
     int slots = 0;
     if (const char* e = getenv("TV_CORR_SLOTS")) slots = atoi(e);
+    // a list item packs the range (batch x boundary) into 12 bits and the head into 10: beyond that the grid form
+    if (slots <= 0 && ((int64_t)batch * nsegc >= 4096 || nheads >= 1024)) slots = 6;
     if (slots > 0) {
       CorrArgs g = a;
       g.items = nullptr;

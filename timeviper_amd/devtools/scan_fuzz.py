@@ -77,6 +77,7 @@ def run(n, seed, verbose=False):
                                                           dt_limit=limit, initial_states=init, return_final_states=True,
                                                           return_total_decay=True, group_map=gmap)
                 impl = K.ssd_scan_last_impl()
+                assert impl == 6, f"the fuzz case ran on scan implementation {impl}, not on the head march (6)"
                 outs.append((y.clone(), fin.clone(), dec.clone()))
         finally:
             K.ssd_head_set_asm(-1)

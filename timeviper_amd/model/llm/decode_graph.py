@@ -18,6 +18,8 @@ from __future__ import annotations
 
 from typing import Callable
 
+import warnings
+
 import torch
 
 __all__ = ["GraphedDecodeStep"]
@@ -76,6 +78,10 @@ class GraphedDecodeStep:
                 # the eager step works where the capture does not: fall back to it for the rest of the generation
                 # (the device-side position / key counts were not touched: nothing of the capture executed)
                 self.capture_error = e
+                if isinstance(e, torch.cuda.OutOfMemoryError):
+                    raise               # not a capture problem: the eager loop would only run out of memory later
+                warnings.warn(f"decode: graph capture failed ({type(e).__name__}: {e}); every further token runs as an eager "
+                              "sequence of launches (several times slower per token)", RuntimeWarning, stacklevel=2)
                 for i, n in lens.items():
                     kb, vb = self.cache._kv_buf[i]
                     self.cache._kv_len[i] = n

@@ -181,6 +181,24 @@ class Mlp(nn.Module):
         return F.linear(h, w2, self.fc2.bias)
 
 
+def _accumulate(x2: torch.Tensor, h2: torch.Tensor, w: torch.Tensor, role: str) -> None:
+    """x2 += h2 @ w.T (one rounding of the sum to bf16), the residual stream's output projections.  Default: hipBLASLt
+    (`torch.addmm`, beta = 1).  The hand-written GEMM with the accumulating epilogue (csrc/gemm_drip.hip: 256 x 192 tiles —
+    1 152 columns are 6 of them, 4.5 of the library's 256-wide ones) takes the roles named in TV_VIT_OWN_ACCUM (comma
+    separated: proj, fc2) when the shape allows: bf16, K a multiple of 128 and >= 1 152, enough rows for every compute
+    unit to walk a few tiles."""
+    own = _OWN_ACCUM
+    if (role in own and x2.is_cuda and x2.dtype == torch.bfloat16 and h2.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
+            and not torch.is_grad_enabled() and w.shape[1] % 128 == 0 and w.shape[1] >= 1152 and w.shape[0] % 8 == 0
+            and x2.shape[0] >= 65536 and h2.stride(1) == 1 and w.stride(1) == 1):
+        K.linear_fused(h2, w, None, epilogue=K.GEMM_ACCUM, out=x2)
+    else:
+        torch.addmm(x2, h2, w.t(), out=x2)
+
+
+_OWN_ACCUM = tuple(r for r in os.environ.get("TV_VIT_OWN_ACCUM", "").split(",") if r)
+
+
 class LayerScale(nn.Module):
     def __init__(self, dim, init):
         super().__init__()
@@ -231,12 +249,12 @@ class Block(nn.Module):
         x2 = x.view(-1, x.shape[-1])
         h = K.layer_norm(x, n1.weight, n1.bias, n1.eps, row_bias=pend)
         o = self.attn.heads(h)
-        torch.addmm(x2, o.view(x2.shape), self.attn.proj.weight.t(), out=x2)
+        _accumulate(x2, o.view(x2.shape), self.attn.proj.weight, "proj")
         if pend_mid is None:          # (callers that do not carry the pre-summed rows)
             pend_mid = self.attn.proj.bias.float() if pend is None else pend + self.attn.proj.bias.float()
         h = K.layer_norm(x, n2.weight, n2.bias, n2.eps, row_bias=pend_mid)
         hid, w2 = self.mlp.hidden(h)
-        torch.addmm(x2, hid.view(x2.shape[0], -1), w2.t(), out=x2)
+        _accumulate(x2, hid.view(x2.shape[0], -1), w2, "fc2")
         return x, (pend_mid + self.mlp.fc2.bias.float() if pend_out is None else pend_out)
 
 
