@@ -89,9 +89,44 @@ class OpTimers:
     whose roofline the bench line carries: the SSD scan (HBM), the ViT and the causal LLM attention
     (MFMA), the patch-embedding GEMM (MFMA and HBM)."""
 
-    def __init__(self, K, event=None):
+    def __init__(self, K, event=None, model=None):
         self.K, self.on, self.rec, self.saved = K, False, {}, {}
         self.event = event or (lambda: torch.cuda.Event(enable_timing=True))
+        # library GEMMs (hipBLASLt through F.linear / torch.addmm) by ROLE: the last component of the owning nn.Linear's
+        # name (in_proj, out_proj, up_proj, down_proj, q_proj ... of the language model; qkv, proj, fc1, fc2 of the ViT;
+        # the projector's and the merge module's linears), looked up by the weight's storage, then by its shape (the ViT's
+        # zero-padded inference copies)
+        self.role_by_ptr, self.role_by_shape, self.lib_saved = {}, {}, {}
+        if model is not None:
+            for name, mod in model.named_modules():
+                if isinstance(mod, torch.nn.Linear):
+                    parts = name.split(".")
+                    role = parts[-1]
+                    if "vision" in name or "vit" in name.lower() or "blocks" in parts:
+                        role = "vit." + role
+                    elif "projector" in name:
+                        role = "projector." + role
+                    self.role_by_ptr[mod.weight.data_ptr()] = role
+                    self.role_by_shape.setdefault(tuple(mod.weight.shape), role)
+
+    def _useful(self, w):
+        """(rows, columns) of a weight (N, K) without the zero padding of the ViT's inference copies"""
+        return self.K.PADDED_USEFUL.get(w.data_ptr(), (w.shape[0], w.shape[1]))
+
+    def _lib_role(self, w):
+        r = self.role_by_ptr.get(w.data_ptr())
+        if r is None:
+            n, k = self._useful(w)
+            r = self.role_by_shape.get((n, k)) or f"{n}x{k}"
+        return r
+
+    def _record(self, key, val, fn):
+        e0, e1 = self.event(), self.event()
+        e0.record()
+        out = fn()
+        e1.record()
+        self.rec.setdefault(key, []).append((e0, e1, val))
+        return out
 
     def _wrap(self, name, classify):
         orig = getattr(self.K, name)
@@ -164,11 +199,34 @@ class OpTimers:
         self._wrap("rms_norm", rms)
         self._wrap("layer_norm", ln)
         self._wrap("gelu", gelu)
+        # the library GEMMs: F.linear (nn.Linear.forward goes through it) and torch.addmm (x += h W^T of the ViT stream)
+        import torch.nn.functional as F
+        lin, addmm = F.linear, torch.addmm
+        self.lib_saved = {"linear": lin, "addmm": addmm}
+
+        def timed_linear(x, w, b=None):
+            if not self.on or x.dim() < 2 or not x.is_cuda:
+                return lin(x, w, b)
+            rows = x.numel() // x.shape[-1]
+            n, k = self._useful(w)
+            return self._record("lib:" + self._lib_role(w), 2.0 * rows * n * k, lambda: lin(x, w, b))
+
+        def timed_addmm(inp, m1, m2, *a, **kw):
+            if not self.on or not m1.is_cuda:
+                return addmm(inp, m1, m2, *a, **kw)
+            wt = m2.t()                                    # (N, K) as stored (same storage)
+            n, k = self._useful(wt)
+            return self._record("lib:" + self._lib_role(wt) + " (+=)", 2.0 * m1.shape[0] * n * k,
+                                lambda: addmm(inp, m1, m2, *a, **kw))
+        F.linear, torch.addmm = timed_linear, timed_addmm
         return self
 
     def __exit__(self, *exc):
         for name, orig in self.saved.items():
             setattr(self.K, name, orig)
+        if self.lib_saved:
+            import torch.nn.functional as F
+            F.linear, torch.addmm = self.lib_saved["linear"], self.lib_saved["addmm"]
 
     def _ms(self, key):
         r = self.rec.get(key, [])
@@ -197,8 +255,8 @@ class OpTimers:
                        f"{tf.get('scan_source_id')}, tree {scan_source_id()}): re-run devtools/pmc_scan.sh")
         return {"bound": "hbm", "kernel": "ssd_scan (tv_ssd_scan_cb_fwd: ssd_head_asm_kernel — head-per-wave march, the 64-token step one "
                                           "generated, hand-scheduled instruction stream (csrc/ssd_head_step.inc) — x 8-16 sequence "
-                                          "segments (floating, reset and standard steps) + ssd_dt_transpose + ssd_seg_chain + "
-                                          "ssd_decay_prefix + ssd_correct kernels)",
+                                          "segments (floating, reset and standard steps) + ssd_dt_transpose + ssd_chain_prefix + "
+                                          "ssd_correct_list kernels)",
                 "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "traffic_source": src, "launches": len(r),
                 "avg_launch_us": round(ms * 1e3 / len(r), 1), "bytes_per_token": bytes_per_token}
@@ -268,7 +326,14 @@ class OpTimers:
                 self.hbm_roofline("rmsnorm", "rmsnorm_kernel (tv_rmsnorm_fwd, residual add fused; bytes: every row read / written once)"),
                 self.hbm_roofline("layernorm", "layernorm_rows_kernel (tv_layernorm_fwd, ViT, 8 rows per wave; bytes: every row read / written once)"),
                 self.hbm_roofline("gelu", "gelu_kernel (tv_gelu_fwd, in place: ViT MLP and projector; bytes: read + write)")]
+        # hipBLASLt GEMMs by role (useful FLOPs: zero-padded rows / columns of the ViT's inference copies are not counted)
+        for key in sorted(k for k in self.rec if k.startswith("lib:")):
+            out.append(self.mfma_roofline(key, f"hipBLASLt GEMM, role {key[4:]} (F.linear / torch.addmm; useful FLOPs)"))
         return [o for o in out if o]
+
+    def accounted_ms(self):
+        """Event time of everything this class times, in ms (all steps)"""
+        return sum(self._ms(k)[0] for k in self.rec)
 
 
 def cpu_baseline(cfg, frames_sample=256, vit_frames=16):
@@ -657,7 +722,7 @@ def run(args, env):
             torch.distributed.barrier()
         env.sync()
 
-    with torch.inference_mode(), env.kernels(), OpTimers(K, env.event) as st:
+    with torch.inference_mode(), env.kernels(), OpTimers(K, env.event, vlm) as st:
         for _ in range(args.warmup):
             step()
         barrier()
@@ -694,6 +759,9 @@ def run(args, env):
             # ... and every kernel with a stated roof, all event-timed inside the timed steps
             "rooflines": st.all_rooflines(scan_bytes_per_token(cfg), cfg),
         }
+        # how much of the step the event-timed operators (hand-written kernels and library GEMMs) account for
+        line["timed_ms_per_step"] = round(st.accounted_ms() / args.steps, 2)
+        line["timed_share_of_step"] = round(st.accounted_ms() / args.steps / ms, 4)
         if world == 1 and dev.type == "cuda" and line["roofline"]:
             # What a plain copy of the same size reaches on THIS box (read + write streams, outside the timed region): the
             # practical ceiling of an operator that reads x and writes y once — `peak` stays the 8 TB/s of the data sheet.

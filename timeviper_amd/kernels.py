@@ -309,6 +309,11 @@ def gemm_set_persist(mode: int = -1, grid: int = 0) -> None:
     _capi.lib().tv_gemm_set_persist(int(mode), int(grid))
 
 
+# zero-padded inference copies of weights (model/vit/siglip.py): storage address -> (useful rows, useful columns), so that a
+# FLOP count (bench.py) can leave the padding out whatever view of the copy a GEMM receives
+PADDED_USEFUL: dict = {}
+
+
 def gemm_set_drip(mode: int = -1) -> None:
     """The 256 x 192-tile persistent GEMM (csrc/gemm_drip.hip): -1 automatic (first choice wherever the shape allows and
     every compute unit gets a few tiles), 0 never, 1 wherever the shape allows (tests on small grids)."""

@@ -93,6 +93,16 @@ def _pad_rows(w: torch.Tensor, n: int) -> torch.Tensor:
     out = w.new_zeros((n,) + tuple(w.shape[1:]))
     out[: w.shape[0]] = w
     out._tv_useful_rows = w.shape[0]        # (bench.py counts useful flops)
+    if w.dim() == 2:
+        K.PADDED_USEFUL[out.data_ptr()] = (w.shape[0], w.shape[1])
+    return out
+
+
+def _pad_cols(w: torch.Tensor, k: int) -> torch.Tensor:
+    out = w.new_zeros((w.shape[0], k))
+    out[:, : w.shape[1]] = w
+    out._tv_useful_cols = w.shape[1]
+    K.PADDED_USEFUL[out.data_ptr()] = (w.shape[0], w.shape[1])
     return out
 
 
@@ -155,7 +165,7 @@ class Mlp(nn.Module):
         if ZeroPaddedLinears.wanted(x, Hd):
             w1, b1, w2 = self._padded.get((self.fc1.weight, self.fc1.bias, self.fc2.weight), lambda: (
                 _pad_rows(self.fc1.weight.detach(), _aligned(Hd)), _pad_rows(self.fc1.bias.detach(), _aligned(Hd)),
-                _pad_rows(self.fc2.weight.detach().t(), _aligned(Hd)).t().contiguous()))
+                _pad_cols(self.fc2.weight.detach(), _aligned(Hd))))
             if self._fused_fc1(x, w1):
                 return K.linear_fused(x, w1, b1, epilogue=K.GEMM_BIAS_GELU), w2
             h = F.linear(x, w1, b1)
