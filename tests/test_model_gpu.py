@@ -647,6 +647,55 @@ def test_realshape_prefill_plus_graphed_fused_decode_vs_reference_golden(monkeyp
         assert stepper.graph is not None
 
 
+def test_true_width_slice_vs_oracle():
+    """The language model at Nano-9B's TRUE width (hidden 4 480, 128 Mamba heads of 80 in 8 groups, d_state 128, MLP 15 680,
+    40 / 8 attention heads of 128): the first 16 layers of its pattern (8 Mamba, 7 MLP, the first attention layer) on 1 200
+    tokens with a "uni" pdrop stage in front of layer 7 and an "attn" stage ranked by the attention layer (14), against the
+    fp32 CPU oracle (oracle.model.causal_lm_ref) on the same random weights.  The bf16 run's kept indices are handed to the
+    oracle for the "attn" stage (bf16 against fp32 scores: ties resolve differently; the exact ranking is checked in fp32 by
+    test_pdrop_stage_indices_exact_vs_oracle_fp32); the "uni" stage must agree bit for bit.  Tolerance: relative L2 of the
+    last-position logits < 5e-2 (bf16 activations through 16 residual layers)."""
+    from timeviper_amd import kernels as K
+    from timeviper_amd.model.llm.nano import NemotronHConfig, NemotronHForCausalLM
+    pd = "uni_7_0.75-attn_14_0.5"
+    full = NemotronHConfig.nemotron_nano_9b_v2()
+    cfg = NemotronHConfig.nemotron_nano_9b_v2(vocab_size=2048, num_hidden_layers=16,
+                                              hybrid_override_pattern=full.hybrid_override_pattern[:16],
+                                              use_pdrop=True, pdrop_type=pd)
+    assert cfg.hybrid_override_pattern.count("*") == 1 and cfg.hybrid_override_pattern[14] == "*"
+    torch.manual_seed(16)
+    model = NemotronHForCausalLM(cfg).eval()
+    with torch.no_grad():          # separate the ranking scores (N(0, 0.02) weights give near-uniform attention)
+        mix = model.backbone.layers[14].mixer
+        mix.q_proj.weight.mul_(8.0)
+        mix.k_proj.weight.mul_(8.0)
+    sd = {k: v.detach().float() for k, v in model.state_dict().items()}
+    model = model.to(DEV).bfloat16()
+    tb, nv, ta = 20, 1100, 80
+    L = tb + nv + ta
+    g = torch.Generator().manual_seed(5)
+    emb = (torch.randn(1, L, cfg.hidden_size, generator=g) * 0.5).bfloat16()
+    pa = {"first_vision_token_positions": torch.tensor([tb]), "text_prompt_lens": [tb + ta], "num_vision_tokens": [nv],
+          "is_interleaved": False}
+    with torch.no_grad():
+        out = model(inputs_embeds=emb.to(DEV), train_pdrop_args=pa).logits
+    assert K.ssd_scan_last_impl() == 6, "the prefill did not run on the head-per-wave march"
+    assert out.shape == (1, 1, 2048) and torch.isfinite(out).all()
+    tr = [t["kept"].cpu() for t in model.backbone.last_pdrop_trace]
+    assert [len(t) for t in tr] == [int(nv * 0.75), int(nv * 0.5)]
+    assert torch.equal(tr[0], R.uniform_keep_indices_ref(nv, int(nv * 0.75)) + tb)          # "uni": exact integers
+    ocfg = om.OracleConfig.from_hf(cfg, pdrop_type=pd, merge_module="no_merge")
+    col = {}
+    ref = om.causal_lm_ref(sd, ocfg, emb.float(), pa, last_only=True, forced_kept=tr, collect=col)
+    e = relerr(out, ref)
+    assert e < 5e-2, e
+    # the oracle's own "attn" selection (fp32 scores) against the bf16 run's: mostly the same tokens
+    own = {}
+    om.causal_lm_ref(sd, ocfg, emb.float(), pa, last_only=True, collect=own)
+    inter = len(set(tr[1].tolist()) & set(own["kept"][1].tolist()))
+    assert inter >= 0.85 * len(tr[1]), (inter, len(tr[1]))
+
+
 def test_kv_cache_grows_in_place_and_matches_concatenation():
     """`update` writes a token into spare capacity instead of re-concatenating the cache (modeling_nano.py:246-251):
     the views it hands out hold exactly what torch.cat would."""

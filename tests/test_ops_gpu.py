@@ -177,6 +177,45 @@ def test_ssd_scan(K, impl, dtype, B, L, H, P, G, N):
         K.ssd_scan_set_impl(0)
 
 
+def test_ssd_scan_nano_geometry_vs_oracle(K):
+    """The scan at the MODEL's geometry against the token-by-token fp64 recurrence: 128 heads of 80 in 8 groups (16 heads —
+    four work-groups of the head march — share one B / C group, modeling_nano.py:639-653), d_state 128, 4 200 tokens (two
+    sequence segments and the carried-in correction), A = 1 .. 128 and a raw dt of standard deviation 1.3 as in the
+    synthetic 9B model (floating, re-basing, reset and standard steps all occur).  x, B, C come out of the conv + split +
+    C.B^T kernel at d_inner 10 240 / G 8 and are checked against the oracle's conv first; the scan then runs on the
+    default path with those fragments (head march, asserted)."""
+    B, L, H, P, G, N = 1, 4200, 128, 80, 8, 128
+    d_in, conv_dim = H * P, H * P + 2 * G * N
+    g = torch.Generator().manual_seed(4200)
+    xBC = (torch.randn(B, L, conv_dim, generator=g) * 1.5).bfloat16()
+    w = (torch.randn(conv_dim, 1, 4, generator=g) * 0.4).bfloat16()
+    b = (torch.randn(conv_dim, generator=g) * 0.1).bfloat16()
+    dt = (torch.randn(B, L, H, generator=g) * 1.3).bfloat16()
+    A = -torch.arange(1, H + 1, dtype=torch.float32)
+    D = torch.rand(H, generator=g) + 0.5
+    dtv = torch.exp(torch.rand(H, generator=g) * (math.log(0.1) - math.log(1e-3)) + math.log(1e-3))
+    dt_bias = dtv + torch.log(-torch.expm1(-dtv))
+    x, Bm, Cm, cb = K.causal_conv1d_xbc(xBC.to(DEV), w.to(DEV), b.to(DEV), d_in, G, N, return_cb=True)
+    assert cb is not None
+    ref = R.causal_conv1d_ref(xBC.float(), w.float(), b.float(), "silu")
+    close(x, ref[..., :d_in], *TOL[torch.bfloat16], "conv x")
+    close(Bm, ref[..., d_in:d_in + G * N].view(B, L, G, N), *TOL[torch.bfloat16], "conv B")
+    close(Cm, ref[..., d_in + G * N:].view(B, L, G, N), *TOL[torch.bfloat16], "conv C")
+    xh = x.view(B, L, H, P)
+    y, fin, dec = K.mamba_chunk_scan_combined(xh, dt.to(DEV), A.to(DEV), Bm, Cm, chunk_size=128, D=D.to(DEV),
+                                              dt_bias=dt_bias.to(DEV), dt_softplus=True, return_final_states=True,
+                                              return_total_decay=True, cb=cb)
+    assert K.ssd_scan_last_impl() == 6, "the scan did not run on the head-per-wave march"
+    # the oracle on the SAME bf16 x / B / C the kernel read
+    y_ref, fin_ref, dec_ref = R.ssd_recurrence_ref(xh.float().cpu(), dt.float(), A, Bm.float().cpu(), Cm.float().cpu(), D=D,
+                                                   dt_bias=dt_bias)
+    close(y, y_ref, 2e-2, 4e-2, "y")
+    close(fin, fin_ref, 2e-2, 2e-2, "final state")
+    close(dec, dec_ref, 1e-4, 1e-3, "total decay")
+    rel = float((y.float().cpu().double() - y_ref).norm() / y_ref.norm())
+    assert rel < 6e-3, rel            # bf16 outputs of fp32 sums: the error is the rounding of y
+
+
 @pytest.mark.parametrize("dtype,H,P,G,N", [(torch.float32, 8, 16, 2, 16), (torch.bfloat16, 16, 80, 8, 128)])
 def test_ssd_scan_initial_state_and_sharding(K, dtype, H, P, G, N):
     """shard chaining through initial_states == single pass."""
@@ -1299,8 +1338,9 @@ def test_gemm_drip_kernel(K, M, N, Kd, grid, epi):
         diff = (out.float() - tile.float()).abs()
         frac = float((diff > 0).float().mean())
         assert frac < 2e-3, f"{frac:.2e} of the elements differ from the per-tile kernel"
-        # one bf16 step of the larger of the two (GELU: of the pre-activation, slope <= 1.13)
-        lim = torch.maximum(out.float().abs(), tile.float().abs()) * 2.0 ** -7 * (1.2 if epi == 1 else 1.0) + 1e-3
+        # one bf16 step of the larger of the two (GELU: a step of the pre-activation through a slope <= 1.13, then the
+        # output's own rounding)
+        lim = torch.maximum(out.float().abs(), tile.float().abs()) * 2.0 ** -7 * (2.3 if epi == 1 else 1.0) + 1e-3
         assert bool((diff <= lim).all()), "more than one bf16 rounding step from the per-tile kernel"
 
 
