@@ -151,17 +151,21 @@ def run_scan(K, x, dt, A, Bm, Cm, D, dt_bias, **kw):
                                        return_final_states=True, return_total_decay=True, **kw)
 
 
-@pytest.mark.parametrize("impl", [1, 0, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("impl", [1, 0, 2, 3, 4, 5, 6, 8])
 @pytest.mark.parametrize("dtype,B,L,H,P,G,N", [
     (torch.float32, 1, 1024, 32, 64, 1, 16),      # BASELINE config 1
     (torch.float32, 2, 77, 8, 8, 2, 16),
     (torch.float32, 1, 5, 4, 24, 4, 40),
+    (torch.float32, 2, 1000, 6, 50, 3, 24),       # ragged last chunk, head_dim not a multiple of 4, 16 chunks
     (torch.bfloat16, 1, 300, 16, 80, 2, 128),     # Nano head shape
     (torch.bfloat16, 2, 129, 8, 64, 8, 128),
     (torch.bfloat16, 1, 1, 8, 80, 1, 128),
+    (torch.bfloat16, 1, 700, 4, 48, 2, 64),       # bf16 at a d_state the marches do not take
 ])
 def test_ssd_scan(K, impl, dtype, B, L, H, P, G, N):
-    if impl >= 2 and dtype != torch.bfloat16:
+    if impl == 8 and (N > 64 or L <= 64):
+        pytest.skip("the chunk-parallel generic kernel takes d_state <= 64 and at least two chunks")
+    if 2 <= impl < 8 and (dtype != torch.bfloat16 or N != 128):
         pytest.skip("MFMA march kernels are bf16 / d_state 128")
     K.ssd_scan_set_impl(impl)
     try:
@@ -169,10 +173,19 @@ def test_ssd_scan(K, impl, dtype, B, L, H, P, G, N):
         f = [t.float() for t in ins]
         y_ref, fin_ref, dec_ref = R.ssd_recurrence_ref(*f[:5], D=f[5], dt_bias=f[6])
         y, fin, dec = run_scan(K, *ins)
+        if impl == 8 or (impl == 0 and N <= 64 and L > 64):
+            assert K.ssd_scan_last_impl() == 8, "the chunk-parallel generic kernel did not run"
         rt, at = TOL[dtype]
         close(y, y_ref, rt, at * 2, "y")
         close(fin, fin_ref, rt, at, "final state")
         close(dec, dec_ref, 1e-4, 1e-4, "total decay")
+        if impl == 8:       # ... and with a state carried in
+            g = torch.Generator().manual_seed(L)
+            init = torch.randn(B, H, P, N, generator=g)
+            y_ref, fin_ref, dec_ref = R.ssd_recurrence_ref(*f[:5], D=f[5], dt_bias=f[6], initial_states=init)
+            y, fin, dec = run_scan(K, *ins, initial_states=init.to(DEV))
+            close(y, y_ref, rt, at * 2, "y (initial state)")
+            close(fin, fin_ref, rt, at, "final state (initial state)")
     finally:
         K.ssd_scan_set_impl(0)
 

@@ -43,6 +43,16 @@ int tv_ssd_slice_launch(const void* x, const void* dt, const void* A, const void
                         int dtype, int dt_softplus, float dt_min, float dt_max, int group_map,
                         void* workspace, size_t workspace_bytes, int wide, const void* cb_pre, hipStream_t st);
 
+// ssd_chunked.hip: the generic path's chunk-parallel form (small d_state, any dtype)
+bool tv_ssd_chunked_supported(int seqlen, int headdim, int dstate);
+size_t tv_ssd_chunked_workspace_bytes(int batch, int seqlen, int nheads, int headdim, int dstate);
+int tv_ssd_chunked_launch(const void* x, const void* dt, const void* A, const void* Bm, const void* Cm, const void* D,
+                          const void* dt_bias, const void* init_state, void* y, void* final_state, void* total_decay,
+                          int batch, int seqlen, int nheads, int headdim, int ngroups, int dstate, int64_t xsb, int64_t xsl,
+                          int64_t dsb, int64_t dsl, int64_t bsb, int64_t bsl, int64_t bsg, int64_t csb, int64_t csl,
+                          int64_t csg, int64_t ysb, int64_t ysl, int dtype, int dt_softplus, float dt_min, float dt_max,
+                          int group_map, void* workspace, hipStream_t st);
+
 // ssd_head.hip
 bool tv_ssd_head_supported(int seqlen, int nheads, int headdim, int ngroups, int dstate, int dtype,
                            int64_t xsl, int64_t bsl, int64_t bsg, int64_t csl, int64_t csg, int64_t ysl,
@@ -63,6 +73,8 @@ int tv_ssd_head_launch(const void* x, const void* dt, const void* A, const void*
 // slice-wave, 5 the same with 12 waves and one column tile per slice-wave, 6 head-per-wave march (ssd_head.hip:
 // a wave owns a head, a work-group the heads of one B/C group, up to 16 sequence segments + correction).  (7 was round 4's
 // two-waves-per-SIMD variant of it, ssd_pair.hip: 3.2 ms against 2.5 ms, removed in round 5; the number now means 6.)
+// 8 (round 6): the generic path in chunk-parallel form (ssd_chunked.hip: small d_state, 2 .. 64 chunks) — what automatic
+// selection takes where no march applies; 1 stays the token recurrence.
 // process-wide override for tests / dev tools; atomic so that concurrent callers never race on it
 static std::atomic<int> g_ssd_impl{0};
 static const int kAutoImpl = 6;   // head-per-wave march; falls back to 4, 3, the chunk march, the generic kernel
@@ -75,7 +87,8 @@ extern "C" int tv_ssd_scan_last_impl(void) { return g_ssd_last.load(std::memory_
 
 extern "C" size_t tv_ssd_scan_workspace_bytes(int batch, int seqlen, int nheads, int headdim,
                                               int ngroups, int dstate, int dtype) {
-  if (dtype != TV_BF16 || dstate != 128) return 0;
+  if (dtype != TV_BF16 || dstate != 128)
+    return (tv_ssd_chunked_workspace_bytes(batch, seqlen, nheads, headdim, dstate) + 255) / 256 * 256;
   const size_t narrow = tv_ssd_slice_workspace_bytes(batch, seqlen, nheads, headdim, ngroups, dstate, 0);
   const size_t wide = tv_ssd_slice_workspace_bytes(batch, seqlen, nheads, headdim, ngroups, dstate, 1);
   const size_t head = tv_ssd_head_workspace_bytes(batch, seqlen, nheads, headdim, ngroups);
@@ -116,8 +129,9 @@ static int scan_impl(const void* x, const void* dt, const void* A, const void* B
                (((uintptr_t)dt) & 3) == 0 &&
                tv_ssd_march_supported(seqlen, nheads, headdim, ngroups, dstate, dtype, x_stride_l,
                                       b_stride_l, b_stride_g, c_stride_l, c_stride_g, y_stride_l, x, Bm, Cm, y);
-  if (forced >= 2 && !march)
+  if (forced >= 2 && forced != 8 && !march)
     TV_UNSUPPORTED("ssd_scan: MFMA march kernel forced but shape/dtype unsupported");
+  if (forced == 8) march = false;
   const int impl = forced ? forced : kAutoImpl;
   const bool head_ok = march && (impl == 6 || impl == 7) && workspace && (((uintptr_t)dt) & 1) == 0 &&
       tv_ssd_head_supported(seqlen, nheads, headdim, ngroups, dstate, dtype, x_stride_l, b_stride_l, b_stride_g,
@@ -154,6 +168,15 @@ static int scan_impl(const void* x, const void* dt, const void* A, const void* B
                                dt_softplus, dt_min, dt_max, group_map, workspace, workspace_bytes,
                                st);
   }
+  if ((forced == 0 || forced == 8) && workspace && tv_ssd_chunked_supported(seqlen, headdim, dstate) &&
+      workspace_bytes >= tv_ssd_chunked_workspace_bytes(batch, seqlen, nheads, headdim, dstate)) {
+    g_ssd_last.store(8, std::memory_order_relaxed);
+    return tv_ssd_chunked_launch(x, dt, A, Bm, Cm, D, dt_bias, init_state, y, final_state, total_decay, batch, seqlen,
+                                 nheads, headdim, ngroups, dstate, x_stride_b, x_stride_l, dt_stride_b, dt_stride_l,
+                                 b_stride_b, b_stride_l, b_stride_g, c_stride_b, c_stride_l, c_stride_g, y_stride_b,
+                                 y_stride_l, dtype, dt_softplus, dt_min, dt_max, group_map, workspace, st);
+  }
+  if (forced == 8) TV_UNSUPPORTED("ssd_scan: chunk-parallel generic kernel forced but shape unsupported");
   g_ssd_last.store(1, std::memory_order_relaxed);
   return tv_ssd_generic_launch(x, dt, A, Bm, Cm, D, dt_bias, init_state, y, final_state,
                                total_decay, batch, seqlen, nheads, headdim, ngroups, dstate,
