@@ -41,7 +41,10 @@ def predict(n, step_ms, vit_ms, rowlocal_ms, attn_ms, rank_ms):
     links = min(n - 1, 7)
     gather_direct = N_MAMBA * (LAT + STATE_BYTES / LINK) * 1e3 if n > 1 else 0.0            # every peer on its own link
     gather_ring = N_MAMBA * (LAT + (n - 1) * STATE_BYTES / LINK) * 1e3 if n > 1 else 0.0    # one link pair, n - 1 hops
-    halo = N_MAMBA * LAT * 1e3 if n > 1 else 0.0
+    # round 6: the halo rows are projected first and gathered asynchronously UNDER in_proj (distributed.py::_mamba): hidden
+    # (in_proj of a shard takes >= 1.7 ms at 8 ranks against ~ 30 us of gather); the tiny product that makes them is priced
+    halo_hidden = N_MAMBA * LAT * 1e3 if n > 1 else 0.0
+    halo = N_MAMBA * 0.02 if n > 1 else 0.0
     correction = N_MAMBA * 0.15 if n > 1 else 0.0
     imbalance = {1: 1.0, 2: 1.25, 4: 1.40, 8: 1.48}[n]              # last rank's causal area over the mean, skewed split
     attn = attn_ms / n * imbalance
@@ -56,10 +59,16 @@ def predict(n, step_ms, vit_ms, rowlocal_ms, attn_ms, rank_ms):
         "ranks": n, "shard_tokens": round(shard), "scan_frac_at_shard": round(scan_frac(shard), 3),
         "per_rank_ms": {"vit_tome_projector": round(vit, 1), "llm_row_local": round(rowlocal, 1), "ssd_scan": round(scan, 1),
                         "state_all_gather_direct": round(gather_direct, 2), "state_all_gather_ring": round(gather_ring, 2),
-                        "conv_halo": round(halo, 2), "carried_in_correction": round(correction, 1),
+                        "conv_halo": round(halo, 2), "conv_halo_gather_hidden_under_in_proj": round(halo_hidden, 2),
+                        "carried_in_correction": round(correction, 1),
                         "causal_attention_last_rank": round(attn, 1), "kv_gather_per_layer": round(kv_ms, 2),
                         "q_proj_per_layer": round(qproj_ms, 2), "kv_gather_exposed": round(kv_exposed, 2),
                         "attn_ranking": round(ranking, 2)},
+        # what a rank waits for with nothing else to do: the shard-state gather of every Mamba layer (its inputs are the
+        # scan's last outputs and its result the correction's first input: nothing to run beside it), the K/V gather where it
+        # outlasts q_proj, the ranking's logit exchange
+        "exposed_collectives_ms": [round(gather_direct + kv_exposed + (ranking - rank_ms / n), 2),
+                                   round(gather_ring + kv_exposed + (ranking - rank_ms / n), 2)],
         "step_ms": [round(total_lo, 1), round(total_hi, 1)],
         "frames_per_s": [round(FRAMES / total_hi * 1e3), round(FRAMES / total_lo * 1e3)],
         "speedup_vs_1": [round(step_ms / total_hi, 2), round(step_ms / total_lo, 2)],

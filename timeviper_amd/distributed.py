@@ -38,6 +38,7 @@ import os
 from typing import List, Optional, Tuple
 
 import torch
+import torch.nn.functional as F
 import torch.distributed as dist
 
 from . import kernels as K
@@ -75,6 +76,17 @@ def all_gather_stack(t: torch.Tensor, group=None) -> torch.Tensor:
     out = torch.empty((world, flat.shape[1]), dtype=t.dtype, device=t.device)
     dist.all_gather_into_tensor(out, flat, group=group)
     return out.view((world,) + tuple(t.shape))
+
+
+def all_gather_stack_async(t: torch.Tensor, group=None):
+    """The same gather started asynchronously (RCCL runs it on its own stream): returns (out, work); `out` —
+    (world, *t.shape) — holds every rank's `t` once `work.wait()` has returned."""
+    world = dist.get_world_size(group)
+    t = t.contiguous()
+    flat = t.reshape(1, -1)
+    out = torch.empty((world, flat.shape[1]), dtype=t.dtype, device=t.device)
+    work = dist.all_gather_into_tensor(out, flat, group=group, async_op=True)
+    return out.view((world,) + tuple(t.shape)), work
 
 
 def balanced_lens(total: int, world: int) -> List[int]:
@@ -287,18 +299,24 @@ class SequenceParallelTimeViper:
     # ---------------------------------------------------------------- mixers
     def _mamba(self, mixer, normed):
         Bsz, L, _ = normed.shape
-        proj = mixer.in_proj(normed)
-        d_in, gts = mixer.intermediate_size, mixer.n_groups * mixer.ssm_state_size
-        gate, xBC, dt = proj.split([d_in, mixer.conv_dim, mixer.num_heads], dim=-1)
+        d_in = mixer.intermediate_size
         Kw = mixer.conv_kernel_size
         # halo: the K-1 pre-conv rows that precede this shard.  Every rank contributes its last
         # K-1 rows (front-padded with zeros when its shard is shorter) and their count, so a
         # shard shorter than K-1 — or empty — still hands the right rows to its successors.
+        # Those rows come FIRST, out of a product of their own (K-1 rows x conv_dim columns of in_proj: nothing beside the
+        # projection of the whole shard), and travel while that projection runs: the layer then has one exposed
+        # collective (the shard states behind the scan) instead of two.
         n_tail = min(L, Kw - 1)
-        tail = xBC.new_zeros((Bsz, Kw - 1, xBC.shape[-1]))
+        w_in, b_in = mixer.in_proj.weight, mixer.in_proj.bias
+        tail = normed.new_zeros((Bsz, Kw - 1, mixer.conv_dim))
         if n_tail:
-            tail[:, Kw - 1 - n_tail:] = xBC[:, L - n_tail:]
-        tails = all_gather_stack(tail, self.group)
+            tail[:, Kw - 1 - n_tail:] = F.linear(normed[:, L - n_tail:], w_in[d_in:d_in + mixer.conv_dim],
+                                                 None if b_in is None else b_in[d_in:d_in + mixer.conv_dim])
+        tails, tails_work = all_gather_stack_async(tail, self.group)
+        proj = mixer.in_proj(normed)
+        gate, xBC, dt = proj.split([d_in, mixer.conv_dim, mixer.num_heads], dim=-1)
+        tails_work.wait()
         cnts = [min(n, Kw - 1) for n in self._lens(L, xBC.device)]   # host-side inside forward(): no sync
         halo = None
         if self.rank > 0:
