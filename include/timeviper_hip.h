@@ -160,8 +160,9 @@ int tv_rmsnorm_gated_fwd(const void* x, const void* z, const void* weight,
  * chunk-invariant up to rounding) and is not part of the ABI.
  * total_decay (B,H) fp32, optional: sum_t dt_t*A_h over the sequence, the
  * per-head log-decay a sequence-sharded caller needs to chain shard states.
- * workspace: tv_ssd_scan_workspace_bytes() bytes of device memory (may be 0 /
- * NULL: the workspace-free kernels are used then); nothing persists in it
+ * workspace: tv_ssd_scan_workspace_bytes() bytes of device memory, 16-byte aligned (may be 0 /
+ * NULL: the workspace-free kernel, the fp32 token recurrence, is used then — correct for every
+ * shape and dtype, and two orders of magnitude slower than the marches); nothing persists in it
  * between calls.  seqlen == 0 is valid (the state passes through).
  * Approximations of the default bf16 kernel (head-per-wave march, csrc/ssd_head.hip), all far below
  * the bf16 rounding of y and bounded in tests/test_fullsize_gpu.py / test_ops_gpu.py:
@@ -238,14 +239,17 @@ int tv_ssd_state_correction(void* y, const void* dt, const void* A, const void* 
                             void* workspace, size_t workspace_bytes, void* stream);
 
 /* Force a particular implementation (testing/benchmarking; process-global):
- * 0 = auto (6 where it applies and a workspace is given, else 4 / 3, else the
- *     chunk march, else the generic kernel),
- * 1 = generic fp32 recurrence kernel (any dtype / shape),
- * 2 = MFMA chunk-march kernel (bf16, d_state 128; needs no workspace),
- * 3 = MFMA slice-march kernel, two work-groups per head (bf16, d_state 128; C.B^T
- *     pre-pass into `workspace`, tv_ssd_scan_workspace_bytes() bytes, 16-byte aligned),
- * 4 / 5 = whole-head slice march (8 / 12 waves) x sequence segments,
- * 6 = head-per-wave march (csrc/ssd_head.hip; head_dim 32 / 64 / 80). */
+ * 0 = auto (with a workspace: 6 where it applies, else 4 / 3; where no MFMA march applies — other dtypes, d_state != 128 —
+ *     8 where it applies, else 1.  Without a workspace: 1),
+ * 1 = generic fp32 token recurrence (any dtype / shape; the definition the others are tested against),
+ * 3 = MFMA slice march, slices of <= 40 columns of a head per work-group (bf16, d_state 128, head_dim a multiple of 8
+ *     that splits so; C.B^T pre-pass into `workspace`, tv_ssd_scan_workspace_bytes() bytes, 16-byte aligned),
+ * 4 = whole-head slice march (head_dim 56 .. 80; 8 waves) x sequence segments,
+ * 6 = head-per-wave march (csrc/ssd_head.hip; head_dim 32 / 64 / 80),
+ * 8 = the generic path in chunk-parallel form (csrc/ssd_chunked.hip: any dtype, d_state <= 64, head_dim <= 128, 65 ..
+ *     4 096 tokens; fp32 arithmetic, needs the workspace).
+ * 3 / 4 / 6 fall back (6 -> 4 -> 3) where the shape does not fit and fail with TV_ERR_UNSUPPORTED where none does.
+ * 2, 5 and 7 named kernels that measured slower and were removed (docs/history.md); they select 3, 4 and 6. */
 void tv_ssd_scan_set_impl(int impl);
 /* kernel family (same numbers) the most recent scan call of this process ran on; 0 before the first call */
 int tv_ssd_scan_last_impl(void);
@@ -314,18 +318,12 @@ int tv_flash_attn_fwd(const void* q, const void* k, const void* v, void* o,
                       float softmax_scale, int causal, int dtype, void* stream);
 
 /* Kernel variant for many short non-causal sequences of head_dim 65..80 (the SigLIP ViT frames; testing /
- * benchmarking, process-global): 0 = auto (the streaming kernel: 8 waves x 32 query rows, two waves per SIMD),
- * 1 = 4 waves x 64 query rows at one wave per SIMD with the two 32-row halves half a tile apart
- * (flash_fwd_w64_kernel), 2 = the same in-wave pipeline on 16-row halves, 8 waves, two per SIMD
- * (flash_fwd_w32_kernel); both bf16, >= 256 keys, row strides >= 128 elements; both slower at head_dim 72 —
- * DESIGN.md §5 — and therefore not the default.  Results agree within the operator's tolerance.
- * 3 = the streaming kernel with the row sums of P on the vector pipe (the form before round 5's ones column in the V
- * ring: `l` summed in fp32 before P is rounded) — always built, for A/B runs and tests.
- * Initial value: env TV_FA_W64. */
+ * benchmarking, process-global): 0 = auto (the streaming kernel: 8 waves x 32 query rows, two waves per SIMD, P's row
+ * sums out of the P.V MFMAs through a ones column in the V ring), 3 = the same kernel with the row sums on the vector
+ * pipe (`l` summed in fp32 before P is rounded) — for A/B runs and tests.  (1 / 2 named two measured-slower kernels,
+ * 4 x 64 and 8 x 32 query rows with in-wave pipelines, removed in round 6: docs/history.md; the values are accepted and
+ * mean 0.)  Initial value: env TV_FA_W64. */
 void tv_flash_attn_set_variant(int variant);
-/* 1 when the library was built with -DTV_FA_VARIANTS (the two variants above are compiled in), 0 in the
- * shipped build, where tv_flash_attn_set_variant() is accepted and has no effect. */
-int tv_flash_attn_variants_built(void);
 
 /* The same operator with the QK^T and PV products on the FP8 matrix path of CDNA4
  * (v_mfma_f32_32x32x64_f8f6f4, OCP e4m3 operands, fp32 accumulation, fp32 softmax): BASELINE

@@ -68,8 +68,8 @@ def test_scan_full_length_properties(K):
     assert rel(fb, fin) < 5e-3
     assert torch.allclose(da + db, dec, rtol=1e-4, atol=1e-2)
     del ya, yb
-    # (3) the two MFMA kernels (slice march / chunk march) are independent implementations
-    K.ssd_scan_set_impl(2)
+    # (3) the two MFMA kernels (head-per-wave march / whole-head slice march) are independent implementations
+    K.ssd_scan_set_impl(4)
     try:
         ym, fm, dm = run(K, x, dt, A, Bm, Cm, D, bias)
     finally:

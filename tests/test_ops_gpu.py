@@ -151,7 +151,7 @@ def run_scan(K, x, dt, A, Bm, Cm, D, dt_bias, **kw):
                                        return_final_states=True, return_total_decay=True, **kw)
 
 
-@pytest.mark.parametrize("impl", [1, 0, 2, 3, 4, 5, 6, 8])
+@pytest.mark.parametrize("impl", [1, 0, 6, 8])      # (3 / 4, the slice marches: test_ssd_scan_march_kernels)
 @pytest.mark.parametrize("dtype,B,L,H,P,G,N", [
     (torch.float32, 1, 1024, 32, 64, 1, 16),      # BASELINE config 1
     (torch.float32, 2, 77, 8, 8, 2, 16),
@@ -165,7 +165,7 @@ def run_scan(K, x, dt, A, Bm, Cm, D, dt_bias, **kw):
 def test_ssd_scan(K, impl, dtype, B, L, H, P, G, N):
     if impl == 8 and (N > 64 or L <= 64):
         pytest.skip("the chunk-parallel generic kernel takes d_state <= 64 and at least two chunks")
-    if 2 <= impl < 8 and (dtype != torch.bfloat16 or N != 128):
+    if impl == 6 and (dtype != torch.bfloat16 or N != 128):
         pytest.skip("MFMA march kernels are bf16 / d_state 128")
     K.ssd_scan_set_impl(impl)
     try:
@@ -248,14 +248,18 @@ def test_ssd_scan_initial_state_and_sharding(K, dtype, H, P, G, N):
     close(f1, fin_ref, rt, at)
 
 
-@pytest.mark.parametrize("impl", [2, 3, 4, 5, 6])
-@pytest.mark.parametrize("B,L,H,P,G", [(1, 1000, 16, 80, 8), (2, 449, 8, 64, 2), (1, 64, 4, 48, 1),
-                                       (1, 2049, 8, 80, 4), (1, 130, 4, 128, 2), (1, 65, 6, 24, 3),
-                                       (1, 5000, 8, 80, 8), (1, 4100, 4, 72, 2), (2, 2500, 4, 56, 1)])
+_MARCH_SHAPES = [(1, 1000, 16, 80, 8), (2, 449, 8, 64, 2), (1, 64, 4, 48, 1), (1, 2049, 8, 80, 4), (1, 130, 4, 128, 2),
+                 (1, 65, 6, 24, 3), (1, 5000, 8, 80, 8), (1, 4100, 4, 72, 2), (2, 2500, 4, 56, 1)]
+
+
+@pytest.mark.parametrize("impl,B,L,H,P,G",
+                         [(6,) + s for s in _MARCH_SHAPES]                    # the default (falls back to 4 / 3 by head_dim)
+                         + [(4,) + s for s in _MARCH_SHAPES if 56 <= s[3] <= 80 and s[1] != 5000]      # whole-head slice march
+                         + [(3,) + s for s in _MARCH_SHAPES if s[1] < 1000 or s[3] == 72])             # slices of a head
 def test_ssd_scan_march_kernels(K, impl, B, L, H, P, G):
     """the MFMA march kernels (forced): long sequences, ragged tails, several slice widths,
     initial state in, final state / total decay out, 'tile' head->group map.  impl 4 = whole-head
-    work-groups (head_dim 56..80; other widths fall back to impl 3's layout); from 2 048 tokens on
+    work-groups (head_dim 56..80); from 2 048 tokens on
     (few heads) it marches 2 or 4 sequence segments concurrently and completes the later ones with
     the carried-in state correction."""
     K.ssd_scan_set_impl(impl)
@@ -614,41 +618,6 @@ def test_flash_attention_streaming_row_sums_on_the_matrix_pipe(K, dtype, B, Lq, 
     e1 = (o1.float().cpu() - o_ref).norm() / o_ref.norm()
     e0 = (o0.float().cpu() - o_ref).norm() / o_ref.norm()
     assert e1 < 1.05 * e0 + 1e-5, (e1.item(), e0.item())           # and is no further from the fp32 oracle
-
-
-@pytest.mark.parametrize("B,Lq,Lk,Hq,Hkv,D", [
-    (24, 729, 729, 16, 16, 72),      # SigLIP frames: 3 query blocks, 12 key tiles, the last one holds 25 keys
-    (13, 300, 300, 13, 13, 72),      # 5 key tiles with a ragged tail, 2 query blocks, the last XCD's range ends early
-    (12, 768, 512, 16, 8, 80),       # GQA, head_dim 80 (no pad columns), Lk a multiple of the tile, Lq != Lk
-    (40, 260, 1000, 8, 8, 72),       # 2 query blocks of which the second holds 4 rows, 16 key tiles
-])
-@pytest.mark.parametrize("variant", [1, 2])
-def test_flash_attention_w64_variant(K, variant, B, Lq, Lk, Hq, Hkv, D):
-    """`tv_flash_attn_set_variant(1)`: flash_fwd_w64_kernel (4 waves x 64 query rows, the halves of a wave half a tile
-    apart, lazy rescale, row sums on the matrix pipe); `(2)`: flash_fwd_w32_kernel (the same pipeline on 16-row halves,
-    8 waves, two per SIMD) — against the fp32 oracle and against the default kernel; dominant keys in late tiles force
-    the reference maximum to move by more than the lazy threshold."""
-    if not K.flash_attn_variants_built():
-        pytest.skip("the shipped library is built without the two slower ViT attention variants "
-                    "(TV_FA_VARIANTS=1 python -m timeviper_amd.build compiles them in)")
-    g = torch.Generator().manual_seed(Lq * 7 + Lk + D)
-    qkv = torch.randn(B, max(Lq, Lk), Hq + 2 * Hkv, D, generator=g).to(torch.bfloat16).to(DEV)
-    q, k, v = qkv[:, :Lq, :Hq], qkv[:, :Lk, Hq:Hq + Hkv], qkv[:, :Lk, Hq + Hkv:]
-    k[:, Lk - 1] *= 4.0
-    k[:, Lk // 2] *= 3.0
-    k[:, 70] *= 5.0
-    o_ref, lse_ref = R.attention_ref(q.float().cpu(), k.float().cpu(), v.float().cpu(), False)
-    o0 = K.flash_attn_func(q, k, v, causal=False)
-    K.flash_attn_set_variant(variant)
-    try:
-        o, lse = K.flash_attn_func(q, k, v, causal=False, return_lse=True)
-        o2 = K.flash_attn_func(q, k, v, causal=False)
-    finally:
-        K.flash_attn_set_variant(0)
-    close(o, o_ref, 2e-2, 1e-2, "o")
-    close(lse, lse_ref, 1e-3, 2e-3, "lse")
-    close(o, o0.float().cpu(), 2e-2, 1e-2, "o vs default kernel")
-    assert torch.equal(o, o2)                 # no stale ring / staging state between calls
 
 
 def test_flash_attention_spiked_max(K):

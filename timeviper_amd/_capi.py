@@ -47,7 +47,6 @@ SIGNATURES = {
     "tv_gemm_set_drip": (None, [_i]),
     "tv_flash_attn_fwd": (_i, [_p] * 5 + [_i] * 6 + [_l] * 12 + [_f, _i, _i, _p]),
     "tv_flash_attn_set_variant": (None, [_i]),
-    "tv_flash_attn_variants_built": (_i, []),
     "tv_flash_attn_fp8_workspace_bytes": (_z, [_i] * 5),
     "tv_flash_attn_fp8_fwd": (_i, [_p] * 5 + [_i] * 6 + [_l] * 12 + [_f, _i, _i, _p, _z, _p]),
     "tv_gemv_bf16_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _l, _l, _l, _i, _p, _l, _p, _l, _p, _i, _f, _p, _l, _i,

@@ -31,8 +31,6 @@ if os.environ.get("TV_MARCH_ABLATE"):   # dev only: compile the scan kernel's ab
     FLAGS.append("-DTV_MARCH_ABLATE")
 if os.environ.get("TV_FA_STAMP"):       # dev only: per-phase stamps in the streaming attention kernel
     FLAGS.append("-DTV_FA_STAMP")
-if os.environ.get("TV_FA_VARIANTS"):    # dev only: the two measured-slower ViT attention kernels (attention_variants.hpp)
-    FLAGS.append("-DTV_FA_VARIANTS")
 if os.environ.get("TV_DRIP_STAMP"):     # dev only: per-phase cycle sums in the 256 x 192 GEMM (gemm_drip.hip)
     FLAGS.append("-DTV_DRIP_STAMP")
 if os.environ.get("TV_SLICE_STAMP"):    # dev only: per-wave barrier-wait stamps in ssd_slice.hip

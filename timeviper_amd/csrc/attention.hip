@@ -811,10 +811,6 @@ __global__ __launch_bounds__(512) void flash_fwd_stream_kernel(AttnArgs a) {
 }
 
 
-#ifdef TV_FA_VARIANTS
-#include "attention_variants.hpp"
-#endif
-
 std::atomic<int> g_fa_variant{[] { const char* v = getenv("TV_FA_W64"); return v ? atoi(v) : 0; }()};
 
 int tv_cu_count() {
@@ -848,32 +844,7 @@ int launch_fa_d(const AttnArgs& a, int B, hipStream_t st) {
         ax.o16 = ((uintptr_t)a.o % 16 == 0 && a.osb % 8 == 0 && a.osl % 8 == 0 && a.osh % 8 == 0) ? 1 : 0;
         static const int stream_ = [] { const char* v = getenv("TV_FA_STREAM"); return v ? atoi(v) : 1; }();
         const int64_t slots = (int64_t)ax.ppx * nqb;          // query blocks per XCD
-        bool w64_ok = false;
-#ifdef TV_FA_VARIANTS
-        const int w64_ = g_fa_variant.load(std::memory_order_relaxed);
-        if constexpr (KS == 5 && DT == 3 && sizeof(T) == 2 && Frag<T>::is_bf16)
-          w64_ok = w64_ && a.Lk >= 256 && a.ksl >= 128 && a.vsl >= 128 && slots > tv_cu_count() / 8 &&
-                   (int64_t)a.Lq * a.qsl * 2 < (1ll << 31);
-#endif
-        if (w64_ok) {
-#ifdef TV_FA_VARIANTS
-         if (w64_ == 2) {
-          if constexpr (KS == 5 && DT == 3 && Frag<T>::is_bf16) {
-            constexpr int lds4 = 2 * 4 * 64 * 256 + 8 * 4096;  // K and V rings + Q staging: 4 KiB a wave
-            e = hipFuncSetAttribute((const void*)flash_fwd_w32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
-            if (e == hipSuccess)
-              flash_fwd_w32_kernel<<<dim3((unsigned)(8 * (tv_cu_count() / 8)), 1, 1), 512, lds4, st>>>(ax);
-          }
-         } else {
-          if constexpr (KS == 5 && DT == 3 && Frag<T>::is_bf16) {
-            constexpr int lds4 = 2 * 4 * 64 * 256 + 4 * 8192;  // K and V rings: 4 stages x 64 rows x 256 B; Q staging: 8 KiB a wave
-            e = hipFuncSetAttribute((const void*)flash_fwd_w64_kernel<KS, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
-            if (e == hipSuccess)
-              flash_fwd_w64_kernel<KS, DT><<<dim3((unsigned)(8 * (tv_cu_count() / 8)), 1, 1), 256, lds4, st>>>(ax);
-          }
-         }
-#endif
-        } else if constexpr (KS > 6) {                         // head_dim 128: the second Q set does not fit the registers
+        if constexpr (KS > 6) {                                // head_dim 128: the second Q set does not fit the registers
           flash_fwd_kernel<T, KS, DT, 8, KT><<<dim3((unsigned)(pairs * nqb), 1, 1), 512, lds, st>>>(ax);
         } else if (stream_ && a.Lk > 32 * KT && slots > tv_cu_count() / 8) {
           // one resident work-group per CU streams its share of the query blocks
@@ -932,13 +903,6 @@ extern "C" int tv_fa_debug_stamps(unsigned long long* out) {
 #endif
 
 extern "C" void tv_flash_attn_set_variant(int variant) { g_fa_variant.store(variant, std::memory_order_relaxed); }
-extern "C" int tv_flash_attn_variants_built(void) {
-#ifdef TV_FA_VARIANTS
-  return 1;
-#else
-  return 0;
-#endif
-}
 
 extern "C" int tv_flash_attn_fwd(const void* q, const void* k, const void* v, void* o, void* lse,
                                  int batch, int seqlen_q, int seqlen_k, int nheads_q,

@@ -1,4 +1,4 @@
-// Device helpers shared by the SSD scan kernels (ssd_march.hip, ssd_slice.hip): MFMA and
+// Device helpers shared by the SSD scan kernels (ssd_slice.hip, ssd_head.hip, ssd_correct.hip): MFMA and
 // transposing-LDS-read wrappers, LDS-DMA as inline asm, DPP wave scan, fast softplus.
 #pragma once
 #include "common.hpp"

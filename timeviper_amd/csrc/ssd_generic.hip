@@ -5,7 +5,8 @@
 // every 16th state index n, keeps its state slice in registers for the whole
 // sequence, and the 16 n-lanes of a column reduce y with DPP shuffles.  Token
 // tiles are staged through LDS with coalesced loads.  The bf16 Nano-shape fast
-// path is the MFMA chunk-march kernel in ssd_march.hip.
+// paths are the MFMA marches of ssd_head.hip / ssd_slice.hip; small d_state with a
+// workspace goes to the chunk-parallel form in ssd_chunked.hip.
 // Reference semantics: modeling_nano.py:639-653, CPU twin :775-851.
 #include <type_traits>
 #include "common.hpp"

@@ -1,6 +1,6 @@
-// S3 dispatcher: tv_ssd_scan_fwd picks an MFMA march kernel (bf16, d_state 128,
-// MFMA-tileable head_dim: the slice march when a workspace is supplied, else the chunk
-// march) or the generic fp32 recurrence kernel.
+// S3 dispatcher: tv_ssd_scan_fwd picks an MFMA march kernel (bf16, d_state 128, MFMA-tileable head_dim, a
+// workspace supplied: the head-per-wave march, else a slice march) or the generic fp32 path (chunk-parallel
+// with a workspace and a small d_state, else the token recurrence).
 #include <atomic>
 #include "common.hpp"
 
@@ -12,21 +12,6 @@ int tv_ssd_generic_launch(const void* x, const void* dt, const void* A, const vo
                           int64_t bsl, int64_t bsg, int64_t csb, int64_t csl, int64_t csg, int64_t ysb, int64_t ysl,
                           int dtype, int dt_softplus, float dt_min, float dt_max, int group_map,
                           hipStream_t st);
-
-// ssd_march.hip
-bool tv_ssd_march_supported(int seqlen, int nheads, int headdim, int ngroups, int dstate,
-                            int dtype, int64_t xsl, int64_t bsl, int64_t bsg, int64_t csl, int64_t csg, int64_t ysl,
-                            const void* x, const void* Bm, const void* Cm, const void* y);
-size_t tv_ssd_march_workspace_bytes(int batch, int seqlen, int nheads, int headdim, int ngroups,
-                                    int dstate);
-int tv_ssd_march_launch(const void* x, const void* dt, const void* A, const void* Bm,
-                        const void* Cm, const void* D, const void* dt_bias,
-                        const void* init_state, void* y, void* final_state, void* total_decay,
-                        int batch, int seqlen, int nheads, int headdim, int ngroups, int dstate,
-                        int64_t xsb, int64_t xsl, int64_t dsb, int64_t dsl, int64_t bsb,
-                        int64_t bsl, int64_t bsg, int64_t csb, int64_t csl, int64_t csg, int64_t ysb, int64_t ysl,
-                        int dtype, int dt_softplus, float dt_min, float dt_max, int group_map,
-                        void* workspace, size_t workspace_bytes, hipStream_t st);
 
 // ssd_slice.hip
 bool tv_ssd_slice_supported(int seqlen, int nheads, int headdim, int ngroups, int dstate,
@@ -66,18 +51,17 @@ int tv_ssd_head_launch(const void* x, const void* dt, const void* A, const void*
                        int64_t ysl, int dt_softplus, float dt_min, float dt_max, int group_map,
                        void* workspace, size_t workspace_bytes, const void* cb_pre, hipStream_t st);
 
-// ssd_pair.hip
-// 0 auto, 1 generic recurrence, 2 chunk march (ssd_march.hip), 3 slice march, two work-groups per
-// head (ssd_slice.hip), 4 slice march, whole-head work-groups x concurrent sequence segments +
-// carried-in state correction (ssd_slice.hip + ssd_correct.hip), 8 waves with two column tiles per
-// slice-wave, 5 the same with 12 waves and one column tile per slice-wave, 6 head-per-wave march (ssd_head.hip:
-// a wave owns a head, a work-group the heads of one B/C group, up to 16 sequence segments + correction).  (7 was round 4's
-// two-waves-per-SIMD variant of it, ssd_pair.hip: 3.2 ms against 2.5 ms, removed in round 5; the number now means 6.)
-// 8 (round 6): the generic path in chunk-parallel form (ssd_chunked.hip: small d_state, 2 .. 64 chunks) — what automatic
-// selection takes where no march applies; 1 stays the token recurrence.
+// 0 auto, 1 generic token recurrence (ssd_generic.hip: the definition), 3 slice march, two or more work-groups per head
+// (ssd_slice.hip: the fallback for head dims that split into <= 40-column slices), 4 slice march, whole-head work-groups
+// (head_dim 56 .. 80) x concurrent sequence segments + carried-in state correction (ssd_slice.hip + ssd_correct.hip),
+// 6 head-per-wave march (ssd_head.hip: a wave owns a head, a work-group the heads of one B/C group, up to 16 sequence
+// segments + correction; head_dim 32 / 64 / 80), 8 the generic path in chunk-parallel form (ssd_chunked.hip: small
+// d_state, 2 .. 64 chunks) — what automatic selection takes where no march applies.
+// Removed, docs/history.md: 2 (round 1's chunk march; the number now means 3), 5 (round 3's 12-wave whole-head layout; now
+// means 4), 7 (round 4's two-waves-per-SIMD head march; now means 6).
 // process-wide override for tests / dev tools; atomic so that concurrent callers never race on it
 static std::atomic<int> g_ssd_impl{0};
-static const int kAutoImpl = 6;   // head-per-wave march; falls back to 4, 3, the chunk march, the generic kernel
+static const int kAutoImpl = 6;   // head-per-wave march; falls back to 4, 3, the generic path
 
 extern "C" void tv_ssd_scan_set_impl(int impl) { g_ssd_impl.store(impl, std::memory_order_relaxed); }
 // which kernel family the most recent tv_ssd_scan_fwd / _cb_fwd of this process ran on (the numbers above; tests assert
@@ -124,19 +108,16 @@ static int scan_impl(const void* x, const void* dt, const void* A, const void* B
     if (total_decay) (void)hipMemsetAsync(total_decay, 0, (size_t)batch * nheads * sizeof(float), st);
     return TV_OK;
   }
-  const int forced = g_ssd_impl.load(std::memory_order_relaxed);   // one read per call
-  bool march = forced != 1 && dt_stride_l % 2 == 0 && dt_stride_b % 2 == 0 &&
-               (((uintptr_t)dt) & 3) == 0 &&
-               tv_ssd_march_supported(seqlen, nheads, headdim, ngroups, dstate, dtype, x_stride_l,
-                                      b_stride_l, b_stride_g, c_stride_l, c_stride_g, y_stride_l, x, Bm, Cm, y);
-  if (forced >= 2 && forced != 8 && !march)
-    TV_UNSUPPORTED("ssd_scan: MFMA march kernel forced but shape/dtype unsupported");
-  if (forced == 8) march = false;
+  int forced = g_ssd_impl.load(std::memory_order_relaxed);   // one read per call
+  if (forced == 2) forced = 3;          // removed kernels: the numbers select their successors
+  if (forced == 5) forced = 4;
+  if (forced == 7) forced = 6;
+  const bool mfma_ok = forced != 1 && forced != 8 && workspace && dt_stride_l % 2 == 0 && dt_stride_b % 2 == 0 &&
+                       (((uintptr_t)dt) & 3) == 0;
   const int impl = forced ? forced : kAutoImpl;
-  const bool head_ok = march && (impl == 6 || impl == 7) && workspace && (((uintptr_t)dt) & 1) == 0 &&
+  if (mfma_ok && impl == 6 &&
       tv_ssd_head_supported(seqlen, nheads, headdim, ngroups, dstate, dtype, x_stride_l, b_stride_l, b_stride_g,
-                            c_stride_l, c_stride_g, y_stride_l, x, Bm, Cm, y);
-  if (head_ok) {
+                            c_stride_l, c_stride_g, y_stride_l, x, Bm, Cm, y)) {
     g_ssd_last.store(6, std::memory_order_relaxed);
     // the head-per-wave march takes every chunk itself (floating, reset and standard steps in the one kernel)
     return tv_ssd_head_launch(x, dt, A, Bm, Cm, D, dt_bias, init_state, y, final_state, total_decay, batch, seqlen,
@@ -144,13 +125,12 @@ static int scan_impl(const void* x, const void* dt, const void* A, const void* B
                               b_stride_l, b_stride_g, c_stride_b, c_stride_l, c_stride_g, y_stride_b, y_stride_l,
                               dt_softplus, dt_min, dt_max, group_map, workspace, workspace_bytes, cb, st);
   }
-  for (int wide = 2; wide >= 0; --wide) {       // impl 5 / 4 (and 6 where it does not apply): whole-head variants first, then two work-groups per head
-    if (wide == 2 && impl != 5) continue;
+  for (int wide = 1; wide >= 0; --wide) {       // impl 4 (and 6 where it does not apply): whole-head work-groups first, then slices of a head
     if (wide == 1 && impl != 4 && impl != 6) continue;
-    if (march && impl >= 3 && workspace &&
+    if (mfma_ok && impl >= 3 &&
         tv_ssd_slice_supported(seqlen, nheads, headdim, ngroups, dstate, dtype, x_stride_l, b_stride_l,
                                b_stride_g, c_stride_l, c_stride_g, y_stride_l, x, Bm, Cm, y, wide)) {
-      g_ssd_last.store(wide == 2 ? 5 : wide == 1 ? 4 : 3, std::memory_order_relaxed);
+      g_ssd_last.store(wide == 1 ? 4 : 3, std::memory_order_relaxed);
       return tv_ssd_slice_launch(x, dt, A, Bm, Cm, D, dt_bias, init_state, y, final_state,
                                  total_decay, batch, seqlen, nheads, headdim, ngroups, dstate,
                                  x_stride_b, x_stride_l, dt_stride_b, dt_stride_l, b_stride_b,
@@ -159,15 +139,8 @@ static int scan_impl(const void* x, const void* dt, const void* A, const void* B
                                  wide, cb, st);
     }
   }
-  if (march) {
-    g_ssd_last.store(2, std::memory_order_relaxed);
-    return tv_ssd_march_launch(x, dt, A, Bm, Cm, D, dt_bias, init_state, y, final_state,
-                               total_decay, batch, seqlen, nheads, headdim, ngroups, dstate,
-                               x_stride_b, x_stride_l, dt_stride_b, dt_stride_l, b_stride_b,
-                               b_stride_l, b_stride_g, c_stride_b, c_stride_l, c_stride_g, y_stride_b, y_stride_l, dtype,
-                               dt_softplus, dt_min, dt_max, group_map, workspace, workspace_bytes,
-                               st);
-  }
+  if (forced >= 3 && forced != 8)
+    TV_UNSUPPORTED("ssd_scan: MFMA march kernel forced but shape / dtype / alignment unsupported or no workspace given");
   if ((forced == 0 || forced == 8) && workspace && tv_ssd_chunked_supported(seqlen, headdim, dstate) &&
       workspace_bytes >= tv_ssd_chunked_workspace_bytes(batch, seqlen, nheads, headdim, dstate)) {
     g_ssd_last.store(8, std::memory_order_relaxed);

@@ -1,8 +1,8 @@
 // S3 (fast path, v2): Mamba-2 SSD selective scan as a "slice march" on CDNA4.
 //
-// Same single pass over HBM as ssd_march.hip (x, dt, B, C read once, y written once, the
-// running state never leaves the chip), reorganised around what bounded that kernel: LDS
-// operand traffic and the publish -> barrier -> re-read of the state every chunk.
+// A single pass over HBM (x, dt, B, C read once, y written once, the running state never leaves the
+// chip), organised around what bounded round 1's chunk march (state published to LDS, a barrier and a
+// re-read every chunk; removed in round 6, docs/history.md): LDS operand traffic and that round trip.
 //
 //   * A workgroup = (batch, head, <=48-column slice of head_dim), 12 waves, one barrier per
 //     64-token chunk.
@@ -224,27 +224,22 @@ __device__ __forceinline__ int xad(int a, int k, int b) {
 //   narrow: 0-2 slices, 3 x/dt/y, 4-6 + 11 B/C (+ one x~ piece each), 7-8 mask, 9 prep, 10 x~ pieces —
 //     the two mask waves, the heaviest VALU helpers, sit on different SIMDs; SIMD 3 has no slice-wave;
 //   wide:   0-2 slices (two column tiles each), 3 x/dt copies + prep, 4-5 B/C copies + y stores, 6-7 mask.
-//   wide12 (round 3): 12 waves of <= 168 registers: 0-4 slices with ONE column tile each — five slice-waves on the four
-//     SIMDs run their (latency-bound) steps side by side instead of three waves taking two tiles in turn —
-//     5 x/dt copies + prep, 6-7 + 10-11 B/C copies + in-place B~ scaling, 9 + 8 mask (wave 8, the light one,
-//     shares SIMD 0 with two slice-waves).
-template <int PW, bool W12> struct Roles {
+//   (round 3's 12-wave whole-head layout with one column tile per slice-wave, "impl 5", measured slower than this one and was
+//   removed in round 6: docs/history.md.)
+template <int PW> struct Roles {
   static constexpr bool WIDE = PW > 48;
-  static constexpr bool WIDE8 = WIDE && !W12, WIDE12 = WIDE && W12;
-  static constexpr int NWAVES = WIDE8 ? 8 : 12;
-  static constexpr int NC = WIDE8 ? 2 : 1;         // 16-column tiles per slice-wave
-  static constexpr int XIO = WIDE12 ? 5 : 3;       // x / dt DMA (+ y stores, narrow; + prep, wide)
+  static constexpr int NWAVES = WIDE ? 8 : 12;
+  static constexpr int NC = WIDE ? 2 : 1;          // 16-column tiles per slice-wave
+  static constexpr int XIO = 3;                    // x / dt DMA (+ y stores, narrow; + prep, wide)
   static constexpr int PREP = WIDE ? XIO : 9;      // dt -> softplus -> prefix sum, mask factors
   static constexpr int SCALE = WIDE ? -1 : 10;     // x~ pieces the four B/C waves do not take (narrow)
-  static constexpr int NBCW = WIDE8 ? 2 : 4;       // B/C copy waves
+  static constexpr int NBCW = WIDE ? 2 : 4;        // B/C copy waves
   static __device__ __forceinline__ int bc(int w) {
-    if (WIDE8) return (w == 4 || w == 5) ? w - 4 : -1;
-    if (WIDE12) return w == 6 ? 0 : w == 7 ? 1 : w == 10 ? 2 : w == 11 ? 3 : -1;
+    if (WIDE) return (w == 4 || w == 5) ? w - 4 : -1;
     return w == 4 ? 0 : w == 5 ? 1 : w == 6 ? 2 : w == 11 ? 3 : -1;
   }
   static __device__ __forceinline__ int mask(int w) {
-    if (WIDE8) return w == 6 ? 0 : w == 7 ? 1 : -1;
-    if (WIDE12) return w == 9 ? 0 : w == 8 ? 1 : -1;
+    if (WIDE) return w == 6 ? 0 : w == 7 ? 1 : -1;
     return w == 7 ? 0 : w == 8 ? 1 : -1;
   }
 };
@@ -271,11 +266,11 @@ __device__ unsigned long long g_slice_phases[8];
   } while (0)
 #endif
 
-template <int PT, int PW, bool W12>
-__global__ __launch_bounds__((Roles<PW, W12>::NWAVES * 64)) void ssd_slice_kernel(SliceArgs a) {
+template <int PT, int PW>
+__global__ __launch_bounds__((Roles<PW>::NWAVES * 64)) void ssd_slice_kernel(SliceArgs a) {
   typedef SliceSmem<PW> Smem;
   typedef Rings<PW> RG;
-  typedef Roles<PW, W12> RL;
+  typedef Roles<PW> RL;
   constexpr int STHREADS = RL::NWAVES * 64, NC = RL::NC;
   constexpr int NB = RG::NB, BD = RG::BD, DXS = RG::DXS, NXS = RG::NXS, NDT = RG::NDT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1099,14 +1094,14 @@ bool pick_slices(int P, int* nslices, int* pw, int wide = 0) {
   return false;
 }
 
-template <int PT, int PW, bool W12 = false>
+template <int PT, int PW>
 hipError_t launch_slice(const SliceArgs& a, dim3 grid, hipStream_t st) {
   const size_t lds = sizeof(SliceSmem<PW>);
   static_assert(sizeof(SliceSmem<PW>) <= 160 * 1024, "LDS budget");
-  hipError_t e = hipFuncSetAttribute((const void*)ssd_slice_kernel<PT, PW, W12>,
+  hipError_t e = hipFuncSetAttribute((const void*)ssd_slice_kernel<PT, PW>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  ssd_slice_kernel<PT, PW, W12><<<grid, Roles<PW, W12>::NWAVES * 64, lds, st>>>(a);
+  ssd_slice_kernel<PT, PW><<<grid, Roles<PW>::NWAVES * 64, lds, st>>>(a);
   return hipSuccess;
 }
 
@@ -1261,11 +1256,11 @@ int tv_ssd_slice_launch(const void* x, const void* dt, const void* A, const void
     case 24: e = launch_slice<2, 24>(a, grid, st); break;
     case 32: e = launch_slice<2, 32>(a, grid, st); break;
     case 40: e = launch_slice<3, 40>(a, grid, st); break;
-    // wide (mode 1): PT slice-waves x 2 column tiles, 8 waves; wide12 (mode 2): one tile per slice-wave, 12 waves
-    case 56: e = wide == 2 ? launch_slice<4, 56, true>(a, grid, st) : launch_slice<2, 56>(a, grid, st); break;
-    case 64: e = wide == 2 ? launch_slice<4, 64, true>(a, grid, st) : launch_slice<2, 64>(a, grid, st); break;
-    case 72: e = wide == 2 ? launch_slice<5, 72, true>(a, grid, st) : launch_slice<3, 72>(a, grid, st); break;
-    case 80: e = wide == 2 ? launch_slice<5, 80, true>(a, grid, st) : launch_slice<3, 80>(a, grid, st); break;
+    // wide: PT slice-waves x 2 column tiles, 8 waves
+    case 56: e = launch_slice<2, 56>(a, grid, st); break;
+    case 64: e = launch_slice<2, 64>(a, grid, st); break;
+    case 72: e = launch_slice<3, 72>(a, grid, st); break;
+    case 80: e = launch_slice<3, 80>(a, grid, st); break;
     default: TV_UNSUPPORTED("ssd_slice: slice width %d", a.pw);
   }
   if (e != hipSuccess) {

@@ -450,9 +450,10 @@ def selective_state_update(state, x, dt, A, B, C, D=None, z=None, dt_bias=None,
 
 
 def ssd_scan_set_impl(impl: int) -> None:
-    """0 auto (= 6 where it applies, else 4, 3, 2, 1), 1 generic fp32-recurrence kernel, 2 MFMA chunk-march kernel,
-    3 MFMA slice march with two work-groups per head, 4 / 5 whole-head slice march (8 / 12 waves) x sequence
-    segments, 6 head-per-wave march (ssd_head.hip).  Process-global (dev tools and tests)."""
+    """0 auto (= 6 where it applies, else 4, 3; other dtypes / d_state: 8, else 1), 1 generic fp32 token recurrence, 3 MFMA
+    slice march on <= 40-column slices of a head, 4 whole-head slice march x sequence segments, 6 head-per-wave march
+    (ssd_head.hip), 8 chunk-parallel fp32 form (ssd_chunked.hip); 2 / 5 / 7 (removed kernels) select 3 / 4 / 6.
+    Process-global (dev tools and tests)."""
     _capi.lib().tv_ssd_scan_set_impl(int(impl))
 
 
@@ -469,18 +470,9 @@ def ssd_scan_last_impl() -> int:
 
 # ------------------------------------------------------------------ attention
 def flash_attn_set_variant(variant: int) -> None:
-    """0 auto (ViT frames: the streaming kernel), 1 the 4 x 64-row one-wave-per-SIMD kernel, 2 the 8 x 32-row
-    two-waves-per-SIMD kernel with 16-row halves, where they apply (non-causal bf16, head_dim 65..80, >= 256 keys;
-    include/timeviper_hip.h).  The two variants are measured-slower experiments and only exist in a library built
-    with TV_FA_VARIANTS=1 (`flash_attn_variants_built()`); elsewhere the call has no effect.
-    3: the streaming kernel with P's row sums on the vector pipe instead of the ones column (always built; A/B).
-    Process-global (dev tools and tests)."""
+    """0 auto (ViT frames: the streaming kernel, P's row sums out of the P.V MFMAs), 3 the same kernel with the row sums on
+    the vector pipe (A/B, tests); include/timeviper_hip.h.  Process-global (dev tools and tests)."""
     _capi.lib().tv_flash_attn_set_variant(int(variant))
-
-
-def flash_attn_variants_built() -> bool:
-    """True in a library built with TV_FA_VARIANTS=1 (csrc/attention_variants.hpp compiled in)."""
-    return bool(_capi.lib().tv_flash_attn_variants_built())
 
 
 _ATTN_FP8 = {"on": False, "min_keys": 4096, "min_queries": 64}
