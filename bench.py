@@ -494,7 +494,8 @@ def config_decode(args):
     of `generate()` (modeling_nano.py:484-546, 1666-1689) on tv_causal_conv1d_update, tv_selective_state_update and
     tv_attn_decode_fwd.  `value`: tokens/s of the step replayed as ONE hipGraph (llm/decode_graph.py: static K / V
     buffers, key count on the device), greedy, the token fed back; the host-driven loop is timed beside it
-    (`config.eager_tokens_per_s`) and gives the per-kernel rooflines (events around the operator calls): the
+    (`config.eager_tokens_per_s`); the per-kernel rooflines come from the launches of one token, each operator's replayed
+    back to back as a graph of its own between two events: the
     matrix-vector products (HBM: every weight matrix once per token — the dominant kernel, 16.6 GB of the token's
     17.5 GB), the state update (the fp32 state of every head read and written once per token, 2 x 5.24 MB per Mamba
     layer) and the split-KV attention (K and V of the cache read once per token and attention layer)."""
@@ -515,25 +516,43 @@ def config_decode(args):
     emb = (torch.randn(1, L, cfg.hidden_size, device=dev, generator=g) * 0.02).bfloat16()
     steps, warm = max(args.steps, 16), max(args.warmup, 4)
     host_pos = torch.ones(1, dtype=torch.long)
-    recs = {"ssu": [], "attn": [], "gemv": []}
+    calls = {"ssu": [], "attn": [], "gemv": []}
 
-    def timed(name, orig, nbytes):
+    def recorded(name, orig, nbytes):
         def f(*a, **kw):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            out = orig(*a, **kw)
-            e1.record()
-            recs[name].append((e0, e1, nbytes(*a, **kw)))
-            return out
+            calls[name].append((orig, a, kw, nbytes(*a, **kw)))
+            return orig(*a, **kw)
         return f
 
     def roofline(name, kernel):
-        rec = recs[name]
-        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in rec)
-        gbs = sum(b for _, _, b in rec) / (ms * 1e-3) / 1e9
+        """The launches of one token's operator `name`, with the arguments the step gave them, replayed back to back as
+        one hipGraph between two events on the replay stream: per-launch time as inside the step's graph (events around
+        single calls of the host loop measured the launch gaps of 4 - 30 us kernels, not the kernels)."""
+        rec = calls[name]
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            for fn, a, kw, _ in rec:
+                fn(*a, **kw)
+            st.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=st):
+                for fn, a, kw, _ in rec:
+                    fn(*a, **kw)
+            graph.replay()
+            st.synchronize()
+            reps = 20
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            for _ in range(reps):
+                graph.replay()
+            e1.record(st)
+            st.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        nbytes = sum(b for *_, b in rec)
+        gbs = nbytes / (ms * 1e-3) / 1e9
         return {"bound": "hbm", "kernel": kernel, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "launches": len(rec),
-                "avg_launch_us": round(ms * 1e3 / len(rec), 2), "bytes_per_launch": rec[0][2]}
+                "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "launches": len(rec), "replays": reps,
+                "avg_launch_us": round(ms * 1e3 / len(rec), 2), "bytes_per_launch": round(nbytes / len(rec))}
     with torch.inference_mode():
         cache = HybridMambaAttentionDynamicCache(cfg, 1, dtype=torch.bfloat16, device=dev)
         out = llm(inputs_embeds=emb, past_key_values=cache, use_cache=True, cache_position=torch.zeros(1, dtype=torch.long))
@@ -542,16 +561,11 @@ def config_decode(args):
         for _ in range(warm):
             tok = llm(input_ids=tok, past_key_values=cache, use_cache=True, cache_position=host_pos).logits[:, -1].argmax(-1).view(1, 1)
         torch.cuda.synchronize()
-        orig_ssu, orig_attn, orig_gemv = K.selective_state_update, K.flash_attn_decode, K.gemv_fused
-        K.gemv_fused = timed("gemv", orig_gemv, lambda x, w, *a, **kw: w.numel() * w.element_size())
-        K.selective_state_update = timed("ssu", orig_ssu, lambda state, *a, **kw: 2 * state.numel() * state.element_size())
-        K.flash_attn_decode = timed("attn", orig_attn, lambda q, k, v, *a, **kw: 2 * k.shape[0] * k.shape[1] * k.shape[2] * k.shape[3] * k.element_size())
         t0 = time.perf_counter()
         for _ in range(steps):
             tok = llm(input_ids=tok, past_key_values=cache, use_cache=True, cache_position=host_pos).logits[:, -1].argmax(-1).view(1, 1)
         torch.cuda.synchronize()
         eager_s = time.perf_counter() - t0
-        K.selective_state_update, K.flash_attn_decode, K.gemv_fused = orig_ssu, orig_attn, orig_gemv
         # ---- the same step as one graph launch per token
         gsteps = max(steps, 64)
         cache.begin_static_decode(warm + gsteps + 8)
@@ -567,14 +581,24 @@ def config_decode(args):
             tok = stepper.step(tok).view(1, 1)
         torch.cuda.synchronize()
         dt_s = time.perf_counter() - t0
-        out = stepper.logits
+        out = stepper.logits.clone()
+        # ---- per-operator rooflines: one more host-driven token with the operator calls recorded, each operator's launches
+        # of that token replayed as a graph of their own (after everything that is timed: the replays advance the states)
+        orig_ssu, orig_attn, orig_gemv = K.selective_state_update, K.flash_attn_decode, K.gemv_fused
+        K.gemv_fused = recorded("gemv", orig_gemv, lambda x, w, *a, **kw: w.numel() * w.element_size())
+        K.selective_state_update = recorded("ssu", orig_ssu, lambda state, *a, **kw: 2 * state.numel() * state.element_size())
+        K.flash_attn_decode = recorded("attn", orig_attn, lambda q, k, v, *a, **kw: 2 * k.shape[0] * k.shape[1] * k.shape[2] * k.shape[3] * k.element_size())
+        try:
+            llm(input_ids=tok, past_key_values=cache, use_cache=True, cache_position=host_pos)
+        finally:
+            K.selective_state_update, K.flash_attn_decode, K.gemv_fused = orig_ssu, orig_attn, orig_gemv
+        torch.cuda.synchronize()
+        rl_gemv = roofline("gemv", "gemv_rows_kernel / gemv_bf16_kernel / gemv_splitk_reg_kernel (tv_gemv_bf16_fwd: every linear layer of the "
+                                   "token, norm / activation prologues, conv-update epilogue; bytes: the weight matrices)")
+        rl_ssu = roofline("ssu", "state_update_chain_kernel (tv_selective_state_update)")
+        rl_attn = roofline("attn", "attn_decode_kernel + attn_decode_merge_kernel (tv_attn_decode_fwd)")
     assert torch.isfinite(out.float()).all()
     weights = sum(p.numel() * p.element_size() for n, p in llm.named_parameters() if "embed" not in n)
-    rl_gemv = roofline("gemv", "gemv_rows_kernel / gemv_bf16_kernel (tv_gemv_bf16_fwd: every linear layer of the token, norm / activation "
-                               "prologues, conv-update epilogue; bytes: the weight matrices)")
-    rl_gemv["bytes_per_launch"] = round(sum(b for _, _, b in recs["gemv"]) / len(recs["gemv"]))
-    rl_ssu = roofline("ssu", "state_update_rows_kernel (tv_selective_state_update)")
-    rl_attn = roofline("attn", "attn_decode_kernel + attn_decode_merge_kernel (tv_attn_decode_fwd)")
     print(json.dumps({
         "metric": "decode tokens/s, TimeViper-9B, batch 1, one token against a 2 048-frame prefill cache",
         "value": round(gsteps / dt_s, 2), "unit": "tokens/s", "n_gpus": 1, "steps": gsteps, "warmup": warm,

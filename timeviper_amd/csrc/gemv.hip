@@ -40,14 +40,23 @@ struct GemvArgs {
   int conv_lo, conv_hi;
 };
 
-// the 8 norm weights of one 16-byte piece of x, as floats (fp32 weights: two 16-byte loads, bf16: one)
-__device__ __forceinline__ void normw8(const void* w, int f32, int i0, float (&out)[8]) {
+// the 8 norm weights of one 16-byte piece of x: requested here (fp32 weights: two 16-byte loads, bf16: one), turned into
+// floats by normw_get — AFTER every other request of the prologue is out: a conversion next to the load is a wait for it
+struct NormW { f32x4 lo, hi; };
+__device__ __forceinline__ NormW normw_load(const void* w, int f32, int i0) {
+  // no branch: a value that arrives through one of two paths is copied where they join, and a copy is a wait for the load
+  const char* base = (const char*)w + (size_t)i0 * (f32 ? 4 : 2);
+  NormW r;
+  r.lo = *(const f32x4*)base;
+  r.hi = *(const f32x4*)(base + (f32 ? 16 : 0));       // (bf16 weights: the same 16 bytes again)
+  return r;
+}
+__device__ __forceinline__ void normw_get(const NormW& r, int f32, float (&out)[8]) {
   if (f32) {
-    const f32x4 lo = *(const f32x4*)((const float*)w + i0), hi = *(const f32x4*)((const float*)w + i0 + 4);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { out[j] = lo[j]; out[4 + j] = hi[j]; }
+    for (int j = 0; j < 4; ++j) { out[j] = r.lo[j]; out[4 + j] = r.hi[j]; }
   } else {
-    const bf16x8 v = *(const bf16x8*)((const bf16_t*)w + i0);
+    const bf16x8 v = __builtin_bit_cast(bf16x8, r.lo);
 #pragma unroll
     for (int j = 0; j < 8; ++j) out[j] = (float)v[j];
   }
@@ -67,14 +76,15 @@ __device__ __forceinline__ float dot8(bf16x8 a, bf16x8 b, float acc) {
 }
 
 // f(x) -> LDS (bf16, [M][K]); ends with a barrier
-template <int PRO>
-__device__ __forceinline__ void gemv_prologue(const GemvArgs& a, bf16_t* fx, float* red) {
+template <int PRO, typename F>
+__device__ __forceinline__ void gemv_prologue(const GemvArgs& a, bf16_t* fx, float* red, F&& after_loads) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = a.K, nv = K / 8;
   for (int m = 0; m < a.M; ++m) {
     const bf16_t* xr = a.x + (int64_t)m * a.xs;
     bf16_t* fr = fx + (int64_t)m * K;
     if (PRO == PRO_NONE || PRO == PRO_RELU2) {
+      if (m == 0) after_loads();
       for (int iv = tid; iv < nv; iv += GV_THREADS) {
         bf16x8 v = *(const bf16x8*)(xr + 8 * iv);
         if (PRO == PRO_RELU2) {
@@ -88,20 +98,27 @@ __device__ __forceinline__ void gemv_prologue(const GemvArgs& a, bf16_t* fx, flo
       }
     } else if (PRO == PRO_RMSNORM) {
       constexpr int MAXV = 4;                        // K <= 8 * 256 * 4 (launcher)
-      float vals[MAXV][8], wv[MAXV][8];              // (the weights are requested with x, not behind the reduction)
+      float vals[MAXV][8];
+      NormW wq[MAXV];                                // (the weights are requested with x, not behind the reduction)
       float ssq = 0.f;
+      bf16x8 xq[MAXV], dq[MAXV];
 #pragma unroll
-      for (int k = 0; k < MAXV; ++k) {
-        const int iv = tid + k * GV_THREADS;
-        if (iv < nv) normw8(a.norm_w, a.norm_w_f32, 8 * iv, wv[k]);
+      for (int k = 0; k < MAXV; ++k) {               // (lanes past the end request the last piece again: no branch around a load)
+        const int iv = min(tid + k * GV_THREADS, nv - 1);
+        wq[k] = normw_load(a.norm_w, a.norm_w_f32, 8 * iv);
+        xq[k] = *(const bf16x8*)(xr + 8 * iv);
+        dq[k] = *(const bf16x8*)((a.delta ? a.delta + (int64_t)m * a.ds : xr) + 8 * iv);      // (no delta: x again, unused)
       }
+      __builtin_amdgcn_sched_barrier(0);
+      if (m == 0) after_loads();
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int k = 0; k < MAXV; ++k) {
         const int iv = tid + k * GV_THREADS;
         if (iv < nv) {
-          bf16x8 v = *(const bf16x8*)(xr + 8 * iv);
+          bf16x8 v = xq[k];
           if (a.delta) {
-            const bf16x8 d = *(const bf16x8*)(a.delta + (int64_t)m * a.ds + 8 * iv);
+            const bf16x8 d = dq[k];
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = (bf16_t)((float)v[j] + (float)d[j]);     // the add rounds to bf16 (:966)
           }
@@ -126,54 +143,70 @@ __device__ __forceinline__ void gemv_prologue(const GemvArgs& a, bf16_t* fx, flo
         const int iv = tid + k * GV_THREADS;
         if (iv < nv) {
           bf16x8 o;
+          float wv[8];
+          normw_get(wq[k], a.norm_w_f32, wv);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) o[j] = (bf16_t)(wv[k][j] * (vals[k][j] * rstd));
+          for (int j = 0; j < 8; ++j) o[j] = (bf16_t)(wv[j] * (vals[k][j] * rstd));
           *(bf16x8*)(fr + 8 * iv) = o;
         }
       }
     } else {                                         // PRO_GATED: a wave per group of `group` channels
-      constexpr int MAXV = 4;                        // group <= 8 * 64 * 4 (launcher)
+      constexpr int MAXV = 4, GPW = 1;               // group <= 8 * 64 * 4 (launcher)
       const int ngroups = K / a.group, gv = a.group / 8;
-      for (int g = wave; g < ngroups; g += GV_WAVES) {
-        bf16x8 xv[MAXV], zv[MAXV];
-        float wv[MAXV][8];                           // (x, gate and weights of the group are requested together)
+      if (m == 0 && wave >= ngroups) after_loads();
+      for (int g0 = wave; g0 < ngroups; g0 += GPW * GV_WAVES) {
+        bf16x8 xv[GPW][MAXV], zv[GPW][MAXV];
+        NormW wq[GPW][MAXV];                         // (x, gate and weights of a group are requested together, the first group's in front of W)
 #pragma unroll
-        for (int k = 0; k < MAXV; ++k) {
-          const int iv = lane + k * 64;
-          if (iv < gv) {
-            xv[k] = *(const bf16x8*)(xr + (int64_t)g * a.group + 8 * iv);
-            if (a.gate) zv[k] = *(const bf16x8*)(a.gate + (int64_t)m * a.gs + (int64_t)g * a.group + 8 * iv);
-            normw8(a.norm_w, a.norm_w_f32, g * a.group + 8 * iv, wv[k]);
+        for (int i = 0; i < GPW; ++i) {
+          const int g = min(g0 + i * GV_WAVES, ngroups - 1);
+#pragma unroll
+          for (int k = 0; k < MAXV; ++k) {
+            const int iv = min(lane + k * 64, gv - 1);
+            xv[i][k] = *(const bf16x8*)(xr + (int64_t)g * a.group + 8 * iv);
+            zv[i][k] = *(const bf16x8*)((a.gate ? a.gate + (int64_t)m * a.gs : xr) + (int64_t)g * a.group + 8 * iv);
+            wq[i][k] = normw_load(a.norm_w, a.norm_w_f32, g * a.group + 8 * iv);
           }
         }
-        float vals[MAXV][8];
-        float ssq = 0.f;
+        __builtin_amdgcn_sched_barrier(0);
+        if (m == 0 && g0 == wave) after_loads();
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k = 0; k < MAXV; ++k) {
-          const int iv = lane + k * 64;
-          if (iv < gv) {
+        for (int i = 0; i < GPW; ++i) {
+          const int g = g0 + i * GV_WAVES;
+          if (g < ngroups) {
+            float vals[MAXV][8];
+            float ssq = 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              float f = (float)xv[k][j];
-              if (a.gate) {
-                const float gt = (float)zv[k][j];
-                f *= gt * __builtin_amdgcn_rcpf(1.f + __expf(-gt));
+            for (int k = 0; k < MAXV; ++k) {
+              const int iv = lane + k * 64;
+              if (iv < gv) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                  float f = (float)xv[i][k][j];
+                  if (a.gate) {
+                    const float gt = (float)zv[i][k][j];
+                    f *= gt * __builtin_amdgcn_rcpf(1.f + __expf(-gt));
+                  }
+                  vals[k][j] = f;
+                  ssq = fmaf(f, f, ssq);
+                }
               }
-              vals[k][j] = f;
-              ssq = fmaf(f, f, ssq);
             }
-          }
-        }
-        ssq = wave_sum(ssq);
-        const float rstd = rsqrtf(ssq / (float)a.group + a.eps);
+            ssq = wave_sum(ssq);
+            const float rstd = rsqrtf(ssq / (float)a.group + a.eps);
 #pragma unroll
-        for (int k = 0; k < MAXV; ++k) {
-          const int iv = lane + k * 64;
-          if (iv < gv) {
-            bf16x8 o;
+            for (int k = 0; k < MAXV; ++k) {
+              const int iv = lane + k * 64;
+              if (iv < gv) {
+                bf16x8 o;
+                float wv[8];
+                normw_get(wq[i][k], a.norm_w_f32, wv);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (bf16_t)(wv[k][j] * (vals[k][j] * rstd));
-            *(bf16x8*)(fr + (int64_t)g * a.group + 8 * iv) = o;
+                for (int j = 0; j < 8; ++j) o[j] = (bf16_t)(wv[j] * (vals[k][j] * rstd));
+                *(bf16x8*)(fr + (int64_t)g * a.group + 8 * iv) = o;
+              }
+            }
           }
         }
       }
@@ -183,9 +216,15 @@ __device__ __forceinline__ void gemv_prologue(const GemvArgs& a, bf16_t* fx, flo
 
 }
 
+// 16 bytes of W; NT: non-temporal (a weight byte is used once a token: it should not displace x / the norm weights in L2)
+template <bool NT>
+__device__ __forceinline__ bf16x8 ldw8(const bf16_t* p) {
+  return NT ? __builtin_nontemporal_load((const bf16x8*)p) : *(const bf16x8*)p;
+}
+
 // MT: 1 = one row of x (the batch-1 decode step), GV_MAXM = up to four (a.M);  R rows of W at a time, NB load
 // instructions per row and batch (R * NB loads in flight per wave).  Used for K >= 8 192.
-template <int PRO, int MT, int R, int NB>
+template <int PRO, int MT, int R, int NB, bool NT, bool PF>
 __global__ __launch_bounds__(GV_THREADS) void gemv_bf16_kernel(GemvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gv_smem[];
   bf16_t* fx = (bf16_t*)gv_smem;                     // [M][K]
@@ -210,15 +249,15 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_bf16_kernel(GemvArgs a) {
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
           const bf16x8 z = {};
-          dst[u][r] = 64 * (i0 + u) + lane < np ? *(const bf16x8*)(wp + 512 * (i0 + u)) : z;
+          dst[u][r] = 64 * (i0 + u) + lane < np ? ldw8<NT>(wp + 512 * (i0 + u)) : z;
         }
       }
     }
   };
   bf16x8 cur[NB][R];
-  if ((int)blockIdx.x < a.N) load_batch(cur, blockIdx.x, 0);
-
-  gemv_prologue<PRO>(a, fx, red);
+  // the requests for the first rows of W go out BEHIND those for the prologue's operands: a wave's loads return in order, and
+  // the prologue must not wait for 16 KB of W to learn x
+  gemv_prologue<PRO>(a, fx, red, [&]() __attribute__((always_inline)) { if ((int)blockIdx.x < a.N) load_batch(cur, blockIdx.x, 0); });
 
   // ---------------------------------------------------------------- the products
   const bf16_t* fl = fx + 8 * (p0 + lane);
@@ -244,8 +283,12 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_bf16_kernel(GemvArgs a) {
         }
     };
     const bool more = n0 + R * G < a.N;
-    bf16x8 nxt[NB][R];
-    if (more) load_batch(nxt, n0 + R * G, 0);
+    bf16x8 nxt[PF ? NB : 1][PF ? R : 1];
+    if constexpr (PF) {
+      if (more) load_batch(nxt, n0 + R * G, 0);
+    } else {
+      if (n0 != (int)blockIdx.x) load_batch(cur, n0, 0);
+    }
     fma_batch(cur, 0);
     for (int i0 = NB; i0 < nins; i0 += NB) {
       bf16x8 wv[NB][R];
@@ -274,11 +317,13 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_bf16_kernel(GemvArgs a) {
       }
       par ^= 1; gi = 0; nflush = n0 + R * G;
     }
-    if (more) {
+    if constexpr (PF) {
+      if (more) {
 #pragma unroll
-      for (int u = 0; u < NB; ++u)
+        for (int u = 0; u < NB; ++u)
 #pragma unroll
-        for (int r = 0; r < R; ++r) cur[u][r] = nxt[u][r];
+          for (int r = 0; r < R; ++r) cur[u][r] = nxt[u][r];
+      }
     }
   }
 }
@@ -286,9 +331,8 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_bf16_kernel(GemvArgs a) {
 // The same product with a ROW of W per wave (two at a time, 16 loads in flight), for K < 8 192: a row is 3 - 16 load
 // instructions, too few to split four ways (the waves of a work-group would meet at a barrier every 12 loads), and N is
 // large where K is small in this model (in_proj 22 656 x 4 480, up_proj 15 680 x 4 480: 8 - 11 rows a wave).
-template <int PRO, int MT>
+template <int PRO, int MT, bool NT, int R, int NB>
 __global__ __launch_bounds__(GV_THREADS) void gemv_rows_kernel(GemvArgs a) {
-  constexpr int R = 2, NB = 10;                     // (K = 4 480 is 9 load instructions a row: one batch, 18 loads in flight)
   extern __shared__ __attribute__((aligned(16))) unsigned char gv_smem[];
   bf16_t* fx = (bf16_t*)gv_smem;                     // [M][K]
   __shared__ float red[GV_WAVES];
@@ -304,15 +348,14 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_rows_kernel(GemvArgs a) {
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
           const bf16x8 z = {};
-          dst[u][r] = 64 * (i0 + u) + lane < nv ? *(const bf16x8*)(wp + 512 * (i0 + u)) : z;
+          dst[u][r] = 64 * (i0 + u) + lane < nv ? ldw8<NT>(wp + 512 * (i0 + u)) : z;
         }
       }
     }
   };
   bf16x8 cur[NB][R];
-  if (gw < a.N) load_batch(cur, gw, 0);              // in flight while the prologue runs
-
-  gemv_prologue<PRO>(a, fx, red);
+  // in flight while the prologue runs, requested behind the prologue's own operands (a wave's loads return in order)
+  gemv_prologue<PRO>(a, fx, red, [&]() __attribute__((always_inline)) { if (gw < a.N) load_batch(cur, gw, 0); });
 
   const bf16_t* fl = fx + 8 * lane;
   for (int n0 = gw; n0 < a.N; n0 += R * TW) {
@@ -389,6 +432,141 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_rows_kernel(GemvArgs a) {
   }
 }
 
+// ---------------------------------------------------------------- round 6: one row of x, split-K, f(x) in registers
+// The split-K kernel above stages f(x) in LDS behind a barrier: 1.5 - 3 us in front of the first product of a work-group
+// that streams 160 - 280 KB in 16 - 24 us.  With one row of x a wave needs only ITS quarter of f(x) (5 - 8 pieces of 16
+// bytes a lane: 20 - 32 registers), so it can hold it itself and start its products as soon as its own operands are
+// there: no LDS, no barrier in front of the stream (out_proj 20.7 -> 18.0 us, down_proj 26.0 -> 23.9 us).
+// Same rounding points and the same accumulation order of the products as the LDS kernel.  (The row-per-wave kernel
+// stays on LDS: a wave would have to hold — and every one of the 2 048 waves to fetch — the whole of x, delta and the
+// norm weights: measured slower inside the decode step, 3.71 against 3.54 ms a token.)
+// split-K: wave w of a work-group holds pieces [w pw, w pw + np) of f(x) (np <= 64 NB), R rows of W at a time
+// FULL: every wave's slice is exactly NB load instructions (no lane is ever past its end: no predicate anywhere)
+template <int PRO, int R, int NB, bool NT, bool FULL>
+__global__ __launch_bounds__(GV_THREADS) void gemv_splitk_reg_kernel(GemvArgs a) {
+  static_assert(PRO == PRO_NONE || PRO == PRO_RELU2 || PRO == PRO_GATED, "prologues of the split-K register kernel");
+  constexpr int GB = 4, MAXG = 4;                    // row groups between two meetings of the waves; norm groups a slice
+  __shared__ float part[2][GB][GV_WAVES][R];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int K = a.K, nv = K / 8;
+  const int G = gridDim.x;
+  const int pw = (nv + GV_WAVES - 1) / GV_WAVES, p0 = wave * pw;
+  const int np = min(nv - p0, pw);                   // (= pw > 0: launcher)
+  bf16x8 fx[NB];
+  bf16x8 zv[PRO == PRO_GATED ? NB : 1];
+  NormW wq[PRO == PRO_GATED ? NB : 1];
+#pragma unroll
+  for (int u = 0; u < NB; ++u) {
+    const int q = 64 * u + lane;
+    const bf16x8 z = {};
+    const int qc = p0 + (FULL ? q : min(q, np - 1));   // (np = pw > 0, launcher; lanes past the end: the last piece again, unused)
+    fx[u] = *(const bf16x8*)(a.x + 8 * qc);
+    if constexpr (PRO == PRO_GATED) {
+      zv[u] = *(const bf16x8*)((a.gate ? a.gate : a.x) + 8 * qc);
+      wq[u] = normw_load(a.norm_w, a.norm_w_f32, 8 * qc);
+    }
+    (void)z;
+  }
+  auto load_rows = [&](bf16x8 (&dst)[NB][R], int n0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (n0 + r * G < a.N) {                        // (work-group uniform)
+        const bf16_t* wp = a.W + (int64_t)(n0 + r * G) * a.ldw + 8 * (p0 + lane);
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+          const bf16x8 z = {};
+          dst[u][r] = (FULL || 64 * u + lane < np) ? ldw8<NT>(wp + 512 * u) : z;
+        }
+      }
+    }
+  };
+  bf16x8 cur[NB][R];
+  load_rows(cur, blockIdx.x);
+  __builtin_amdgcn_sched_barrier(0);                 // (the prologue's arithmetic stays behind the requests for W)
+  if constexpr (PRO == PRO_RELU2) {
+#pragma unroll
+    for (int u = 0; u < NB; ++u)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float r = fmaxf((float)fx[u][j], 0.f);
+        fx[u][j] = (bf16_t)(r * r);
+      }
+  } else if constexpr (PRO == PRO_GATED) {
+    // the slice holds whole norm groups (launcher): piece q belongs to group q / gv of the slice
+    const int gv = a.group / 8;
+    float vals[NB][8], psq[NB];
+    int gid[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const int q = 64 * u + lane;
+      gid[u] = (FULL || q < np) ? (int)((unsigned)q / (unsigned)gv) : -1;
+      psq[u] = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float f = (float)fx[u][j];
+        if (a.gate) {
+          const float gt = (float)zv[u][j];
+          f *= gt * __builtin_amdgcn_rcpf(1.f + __expf(-gt));
+        }
+        vals[u][j] = f;
+        psq[u] = fmaf(f, f, psq[u]);
+      }
+    }
+    float rstd[MAXG];
+#pragma unroll
+    for (int g = 0; g < MAXG; ++g) {
+      float sg = 0.f;
+#pragma unroll
+      for (int u = 0; u < NB; ++u) sg += gid[u] == g ? psq[u] : 0.f;
+      rstd[g] = rsqrtf(wave_sum_dpp(sg) / (float)a.group + a.eps);
+    }
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      float rs = rstd[0];
+#pragma unroll
+      for (int g = 1; g < MAXG; ++g) rs = gid[u] == g ? rstd[g] : rs;
+      float wv[8];
+      normw_get(wq[u], a.norm_w_f32, wv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) fx[u][j] = (bf16_t)(wv[j] * (vals[u][j] * rs));
+    }
+  }
+
+  int par = 0, gi = 0, nflush = blockIdx.x;          // gi: groups since the last meeting; nflush: first row of the first of them
+  for (int n0 = blockIdx.x; n0 < a.N; n0 += R * G) {
+    if (n0 != (int)blockIdx.x) load_rows(cur, n0);
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int u = 0; u < NB; ++u)
+      if (FULL || 64 * u + lane < np) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          if (n0 + r * G < a.N) acc[r] = dot8(cur[u][r], fx[u], acc[r]);
+      }
+    const bool more = n0 + R * G < a.N;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float sm = wave_total(acc[r]);
+      if (lane == 0) part[par][gi][wave][r] = sm;
+    }
+    if (++gi == GB || !more) {
+      __syncthreads();
+      for (int i = tid; i < gi * R; i += GV_THREADS) {
+        const int j = i / R, r = i % R, n = nflush + (j * R + r) * G;
+        if (n < a.N) {
+          float sm = 0.f;
+#pragma unroll
+          for (int w = 0; w < GV_WAVES; ++w) sm += part[par][j][w][r];
+          a.y[n] = (bf16_t)(sm + (a.bias ? (float)a.bias[n] : 0.f));
+        }
+      }
+      par ^= 1; gi = 0; nflush = n0 + R * G;
+    }
+  }
+}
+
 int cu_count() {
   static const int n = [] {
     int dev = 0, cus = 0;
@@ -400,10 +578,14 @@ int cu_count() {
   return n;
 }
 
-template <int PRO, int MT, int R, int NB>
+// dev switches (A/B runs): TV_GEMV_NT = 0 plain loads of W; TV_GEMV_WGS = work-groups per CU (default 2)
+int gemv_nt() { static const int v = [] { const char* e = getenv("TV_GEMV_NT"); return e ? atoi(e) : 1; }(); return v; }
+int gemv_wgs() { static const int v = [] { const char* e = getenv("TV_GEMV_WGS"); return e ? atoi(e) : 2; }(); return v < 1 ? 1 : v; }
+
+template <int PRO, int MT, int R, int NB, bool NT, bool PF>
 int launch_gemv_r(const GemvArgs& a, hipStream_t st) {
   const size_t lds = (size_t)a.M * a.K * sizeof(bf16_t);
-  static const hipError_t attr = hipFuncSetAttribute((const void*)gemv_bf16_kernel<PRO, MT, R, NB>,
+  static const hipError_t attr = hipFuncSetAttribute((const void*)gemv_bf16_kernel<PRO, MT, R, NB, NT, PF>,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
   if (attr != hipSuccess) {
     tv_set_error("gemv: cannot reserve 128 KiB of LDS: %s", hipGetErrorString(attr));
@@ -411,31 +593,58 @@ int launch_gemv_r(const GemvArgs& a, hipStream_t st) {
   }
   // two work-groups per CU; fewer when there are not R rows for each
   int wgs = (a.N + R - 1) / R;
-  const int most = 2 * cu_count();
+  const int most = gemv_wgs() * cu_count();
   if (wgs > most) wgs = most;
-  gemv_bf16_kernel<PRO, MT, R, NB><<<dim3((unsigned)wgs), GV_THREADS, lds, st>>>(a);
+  gemv_bf16_kernel<PRO, MT, R, NB, NT, PF><<<dim3((unsigned)wgs), GV_THREADS, lds, st>>>(a);
   TV_LAUNCH_CHECK();
 }
-template <int PRO, int MT>
+template <int PRO, int MT, bool NT, int R, int NB>
 int launch_gemv_rows(const GemvArgs& a, hipStream_t st) {
   const size_t lds = (size_t)a.M * a.K * sizeof(bf16_t);
-  static const hipError_t attr = hipFuncSetAttribute((const void*)gemv_rows_kernel<PRO, MT>,
+  static const hipError_t attr = hipFuncSetAttribute((const void*)gemv_rows_kernel<PRO, MT, NT, R, NB>,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
   if (attr != hipSuccess) {
     tv_set_error("gemv: cannot reserve 128 KiB of LDS: %s", hipGetErrorString(attr));
     return TV_ERR_LAUNCH;
   }
-  int wgs = (a.N + 2 * GV_WAVES - 1) / (2 * GV_WAVES);            // >= one row pair per wave, two work-groups per CU
-  const int most = 2 * cu_count();
+  int wgs = (a.N + R * GV_WAVES - 1) / (R * GV_WAVES);            // >= one row group per wave, two work-groups per CU
+  const int most = gemv_wgs() * cu_count();
   if (wgs > most) wgs = most;
-  gemv_rows_kernel<PRO, MT><<<dim3((unsigned)wgs), GV_THREADS, lds, st>>>(a);
+  gemv_rows_kernel<PRO, MT, NT, R, NB><<<dim3((unsigned)wgs), GV_THREADS, lds, st>>>(a);
   TV_LAUNCH_CHECK();
+}
+template <int PRO, bool NT>
+int launch_splitk_reg(const GemvArgs& a, hipStream_t st) {
+  int wgs = (a.N + 1) / 2;
+  const int most = gemv_wgs() * cu_count();
+  if (wgs > most) wgs = most;
+  const int pw = a.K / 8 / GV_WAVES;                 // (reg_takes: K / 8 is a multiple of the four waves)
+  if (pw == 64 * 5) gemv_splitk_reg_kernel<PRO, 2, 5, NT, true><<<dim3((unsigned)wgs), GV_THREADS, 0, st>>>(a);          // K = 10 240
+  else if (pw == 64 * 8) gemv_splitk_reg_kernel<PRO, 2, 8, NT, true><<<dim3((unsigned)wgs), GV_THREADS, 0, st>>>(a);     // K = 16 384
+  else gemv_splitk_reg_kernel<PRO, 2, 8, NT, false><<<dim3((unsigned)wgs), GV_THREADS, 0, st>>>(a);
+  TV_LAUNCH_CHECK();
+}
+// One row of x (the batch-1 decode step), split-K, with f(x) in registers where the shape allows it; TV_GEMV_REG=0 (dev) keeps the LDS kernel
+template <int PRO>
+bool reg_takes(const GemvArgs& a) {
+  static const int on = [] { const char* e = getenv("TV_GEMV_REG"); return e ? atoi(e) : 1; }();
+  if (!on || a.M != 1 || a.conv_state) return false;
+  const int nv = a.K / 8, pw = nv / GV_WAVES;
+  if (nv % GV_WAVES || pw > 64 * 8) return false;
+  if (PRO == PRO_GATED) return (pw * 8) % a.group == 0 && pw * 8 / a.group <= 4;       // whole norm groups a wave
+  return PRO == PRO_NONE || PRO == PRO_RELU2;
 }
 template <int PRO, int MT>
 int launch_gemv_m(const GemvArgs& a, hipStream_t st) {
   static const int force = [] { const char* e = getenv("TV_GEMV_SPLITK"); return e ? atoi(e) : -1; }();    // (dev: 0 / 1)
   const bool splitk = a.conv_state ? false : (force >= 0 ? force != 0 : a.K >= 8192);
-  return splitk ? launch_gemv_r<PRO, MT, 2, 8>(a, st) : launch_gemv_rows<PRO, MT>(a, st);
+  if constexpr (MT == 1 && PRO != PRO_RMSNORM) {
+    if (splitk && reg_takes<PRO>(a)) return gemv_nt() ? launch_splitk_reg<PRO, true>(a, st) : launch_splitk_reg<PRO, false>(a, st);
+  }
+  // (the gated prologue holds two groups' operands in registers: no second set of W rows beside them)
+  constexpr bool PF = PRO != PRO_GATED;
+  if (!gemv_nt()) return splitk ? launch_gemv_r<PRO, MT, 2, 8, false, PF>(a, st) : launch_gemv_rows<PRO, MT, false, 2, 10>(a, st);
+  return splitk ? launch_gemv_r<PRO, MT, 2, 8, true, PF>(a, st) : launch_gemv_rows<PRO, MT, true, 2, 10>(a, st);
 }
 template <int PRO>
 int launch_gemv(const GemvArgs& a, hipStream_t st) {

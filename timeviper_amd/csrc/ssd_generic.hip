@@ -171,51 +171,65 @@ __global__ void state_update_kernel(float* __restrict__ state, const T* __restri
 
 // Decode step for d_state = 4 LPR (16 .. 256): LPR lanes share a state row (16 bytes = 4 fp32 each), a wave covers
 // 64 / LPR rows per load — coalesced 512-byte rows instead of one thread walking its row with 4-byte loads at a 512-byte
-// lane stride (36.7 us for the 2 x 5.2 MB of a Nano layer = 3.6 % of the HBM roofline, bench.py --config decode, round 4).
+// lane stride (36.7 us for the 2 x 5.2 MB of a Nano layer, round 4).  The launch is a latency chain, not a stream (a Nano
+// layer is 10 240 rows = 5.2 MB, 20 KB a CU; an empty launch of this grid inside the decode graph takes 1.85 us):
+// round 6 keeps ONE state row per lane group in flight per wave (5 120 waves; two and four rows a wave measured 4.7 and
+// 5.6 us against 4.3), requests every scalar of the row (dt, dt_bias, A, D, x) and its B / C pieces in front of the state,
+// reads and writes the state non-temporally (nothing re-reads it before the next token, 16.6 GB of weights later) and sums
+// over d_state on DPP (row_shr inside a 16-lane row, row_bcast across rows: the group's last lane holds the sum) instead
+// of five ds_bpermute round trips: 5.5 -> 4.3 us a launch back to back in a graph (devtools/bench_ssu.py), 7.9 -> 5.2 us
+// inside the decode step.
+template <int LPR>
+__device__ __forceinline__ float group_sum_dpp(float v) {      // valid in the last lane of every LPR-lane group
+  if (LPR >= 2) v = tv_dpp_add<0x111, 0xf>(v);                  // row_shr:1
+  if (LPR >= 4) v = tv_dpp_add<0x112, 0xf>(v);                  // row_shr:2
+  if (LPR >= 8) v = tv_dpp_add<0x114, 0xf>(v);                  // row_shr:4
+  if (LPR >= 16) v = tv_dpp_add<0x118, 0xf>(v);                 // row_shr:8
+  if (LPR >= 32) v = tv_dpp_add<0x142, 0xa>(v);                 // row_bcast:15 -> rows 1, 3
+  if (LPR >= 64) v = tv_dpp_add<0x143, 0xc>(v);                 // row_bcast:31 -> rows 2, 3
+  return v;
+}
+
 template <typename T, int LPR>
-__global__ __launch_bounds__(256) void state_update_rows_kernel(float* __restrict__ state, const T* __restrict__ x,
-                                                                const T* __restrict__ dt, const float* __restrict__ A,
-                                                                const T* __restrict__ Bm, const T* __restrict__ Cm,
-                                                                const float* __restrict__ D, const float* __restrict__ dt_bias,
-                                                                T* __restrict__ y, int H, int P, int G, int softplus,
-                                                                int rows_total) {
-  // Round 5: ITERS 4 -> 2 (twice the work-groups: a Nano layer is 10 240 rows = 5.2 MB, 20 KB a CU — the launch is a
-  // latency chain, not a stream), 32-bit row arithmetic with ONE division pair per wave (the 64-bit / % of every
-  // iteration were ~100 instructions each in front of the first load), B and C as 8-byte loads.
-  constexpr int N = 4 * LPR, RPW = 64 / LPR, ITERS = 2;
+__global__ __launch_bounds__(256) void state_update_chain_kernel(float* __restrict__ state, const T* __restrict__ x,
+                                                                        const T* __restrict__ dt, const float* __restrict__ A,
+                                                                        const T* __restrict__ Bm, const T* __restrict__ Cm,
+                                                                        const float* __restrict__ D,
+                                                                        const float* __restrict__ dt_bias, T* __restrict__ y,
+                                                                        int H, int P, int G, int softplus, int rows_total) {
+  constexpr int N = 4 * LPR, RPW = 64 / LPR, IT = 1, WAVES = 4;      // IT: state rows per lane group in flight
   typedef typename std::conditional<std::is_same<T, float>::value, f32x4, typename std::conditional<std::is_same<T, bf16_t>::value, bf16x4, f16x4>::type>::type vec4_t;
   const int lane = threadIdx.x & 63;
-  const int w = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int w = (int)blockIdx.x * WAVES + (threadIdx.x >> 6);
   const int sub = lane / LPR, ln = lane % LPR;
-  // every load of the wave's ITERS x RPW rows is issued before the first use (rows past the end re-read the last one)
-  int row[ITERS];
-  f32x4 sv[ITERS];
-  float dtv[ITERS], xr[ITERS];
-  int hh[ITERS];
-  vec4_t Bv[ITERS], Cv[ITERS];
   const int hpg = H / G;
+  int row[IT];
+  f32x4 sv[IT];
+  float dtv[IT], xr[IT], av[IT], bv[IT], dv[IT];
+  vec4_t Bv[IT], Cv[IT];
 #pragma unroll
-  for (int it = 0; it < ITERS; ++it) {
-    row[it] = (w * ITERS + it) * RPW + sub;             // (b, h, p) flattened
+  for (int it = 0; it < IT; ++it) {
+    row[it] = (w * IT + it) * RPW + sub;                // (b, h, p) flattened
     const int rc = row[it] < rows_total ? row[it] : rows_total - 1;
     const int bh = (int)((unsigned)rc / (unsigned)P);
     const int b = (int)((unsigned)bh / (unsigned)H);
-    hh[it] = bh - b * H;
-    const int g = (int)((unsigned)hh[it] / (unsigned)hpg);
-    sv[it] = *((const f32x4*)(state + (int64_t)rc * N) + ln);
+    const int h = bh - b * H;
+    const int g = (int)((unsigned)h / (unsigned)hpg);
+    sv[it] = __builtin_nontemporal_load((const f32x4*)(state + (int64_t)rc * N) + ln);
     dtv[it] = to_f32(dt[bh]);
     xr[it] = to_f32(x[rc]);
+    av[it] = A[h];
+    bv[it] = dt_bias ? dt_bias[h] : 0.f;
+    dv[it] = D ? D[h] : 0.f;
     Bv[it] = *(const vec4_t*)(Bm + (int64_t)(b * G + g) * N + 4 * ln);
     Cv[it] = *(const vec4_t*)(Cm + (int64_t)(b * G + g) * N + 4 * ln);
   }
 #pragma unroll
-  for (int it = 0; it < ITERS; ++it) {
+  for (int it = 0; it < IT; ++it) {
     const bool ok = row[it] < rows_total;
-    const int h = hh[it];
-    float d = dtv[it] + (dt_bias ? dt_bias[h] : 0.f);
+    float d = dtv[it] + bv[it];
     if (softplus) d = softplus_f(d);
-    const float dec = expf(d * A[h]);
-    const float dh = D ? D[h] : 0.f;
+    const float dec = expf(d * av[it]);
     const float xv = d * xr[it];
     float part = 0.f;
     f32x4 v;
@@ -224,10 +238,9 @@ __global__ __launch_bounds__(256) void state_update_rows_kernel(float* __restric
       v[i] = fmaf(dec, sv[it][i], xv * to_f32(Bv[it][i]));
       part = fmaf(v[i], to_f32(Cv[it][i]), part);
     }
-    if (ok) *((f32x4*)(state + (int64_t)row[it] * N) + ln) = v;
-#pragma unroll
-    for (int o = LPR / 2; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
-    if (ok && ln == 0) y[row[it]] = from_f32<T>(fmaf(dh, xr[it], part));
+    if (ok) __builtin_nontemporal_store(v, (f32x4*)(state + (int64_t)row[it] * N) + ln);
+    part = group_sum_dpp<LPR>(part);
+    if (ok && ln == LPR - 1) y[row[it]] = from_f32<T>(fmaf(dv[it], xr[it], part));
   }
 }
 
@@ -274,10 +287,10 @@ extern "C" int tv_selective_state_update(void* state, const void* x, const void*
   if (dstate % 4 == 0 && (lpr == 4 || lpr == 8 || lpr == 16 || lpr == 32 || lpr == 64) && (((uintptr_t)state) & 15) == 0 &&
       (((uintptr_t)Bm | (uintptr_t)Cm) & 15) == 0 && (int64_t)batch * nheads * headdim < (1ll << 31)) {
     const int64_t rows = (int64_t)batch * nheads * headdim;
-    const int64_t rows_per_block = 4 * 2 * (64 / lpr);          // 4 waves x 2 iterations x rows per wave-instruction
+    const int64_t rows_per_block = 4 * (64 / lpr);              // 4 waves x rows per wave-instruction
     const dim3 rgrid((unsigned)((rows + rows_per_block - 1) / rows_per_block));
 #define TV_SUR(T, LPR)                                                                                        \
-    state_update_rows_kernel<T, LPR><<<rgrid, 256, 0, s>>>((float*)state, (const T*)x, (const T*)dt,          \
+    state_update_chain_kernel<T, LPR><<<rgrid, 256, 0, s>>>((float*)state, (const T*)x, (const T*)dt,         \
         (const float*)A, (const T*)Bm, (const T*)Cm, (const float*)D, (const float*)dt_bias, (T*)y, nheads,   \
         headdim, ngroups, dt_softplus, (int)rows)
 #define TV_SUR_T(T)                                                                                           \

@@ -1,5 +1,6 @@
 """Dev tool: tv_gemv_bf16_fwd against torch.nn.functional.linear (+ the stand-alone single-row kernels) on the linear
 layers of one Nemotron-Nano-9B-v2 decode token.  usage (GPU box): python timeviper_amd/devtools/bench_gemv.py"""
+import os
 import sys
 import pathlib
 
@@ -64,6 +65,12 @@ def main():
             ours = lambda: K.gemv_fused(x, nextw(), None)
             lib = lambda: F.linear(x, nextw())
         gemm_only = lambda: F.linear(x, nextw())
+        if os.environ.get("TV_BENCH_GEMV_FAST"):         # ours only, with and without the prologue
+            plain = lambda: K.gemv_fused(x, nextw(), None)
+            t_o, t_p = timeit(ours), timeit(plain)
+            gb = N * Kd * 2 / 1e9
+            print(f"{name:20s} N {N:6d} K {Kd:5d}: ours {t_o:7.1f} us = {gb / t_o * 1e6:6.0f} GB/s | without the prologue {t_p:7.1f} us", flush=True)
+            continue
         t_o, t_l, t_g = timeit(ours), timeit(lib), timeit(gemm_only)
         gb = N * Kd * 2 / 1e9
         print(f"{name:20s} N {N:6d} K {Kd:5d}: ours {t_o:7.1f} us = {gb / t_o * 1e6:6.0f} GB/s | torch {t_l:7.1f} us "
