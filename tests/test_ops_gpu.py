@@ -252,34 +252,31 @@ _MARCH_SHAPES = [(1, 1000, 16, 80, 8), (2, 449, 8, 64, 2), (1, 64, 4, 48, 1), (1
                  (1, 65, 6, 24, 3), (1, 5000, 8, 80, 8), (1, 4100, 4, 72, 2), (2, 2500, 4, 56, 1)]
 
 
-@pytest.mark.parametrize("impl,B,L,H,P,G",
-                         [(6,) + s for s in _MARCH_SHAPES]                    # the default (falls back to 4 / 3 by head_dim)
-                         + [(4,) + s for s in _MARCH_SHAPES if 56 <= s[3] <= 80 and s[1] != 5000]      # whole-head slice march
-                         + [(3,) + s for s in _MARCH_SHAPES if s[1] < 1000 or s[3] == 72])             # slices of a head
-def test_ssd_scan_march_kernels(K, impl, B, L, H, P, G):
+@pytest.mark.parametrize("B,L,H,P,G", _MARCH_SHAPES)
+def test_ssd_scan_march_kernels(K, B, L, H, P, G):
     """the MFMA march kernels (forced): long sequences, ragged tails, several slice widths,
-    initial state in, final state / total decay out, 'tile' head->group map.  impl 4 = whole-head
-    work-groups (head_dim 56..80); from 2 048 tokens on
-    (few heads) it marches 2 or 4 sequence segments concurrently and completes the later ones with
-    the carried-in state correction."""
-    K.ssd_scan_set_impl(impl)
-    try:
-        ins = scan_inputs(B, L, H, P, G, 128, 3 * L + H, torch.bfloat16)
-        g = torch.Generator().manual_seed(L)
-        init = torch.randn(B, H, P, 128, generator=g)
-        f = [t.float() for t in ins]
-        for gmap in ("block", "tile"):
-            y_ref, fin_ref, dec_ref = R.ssd_recurrence_ref(*f[:5], D=f[5], dt_bias=f[6],
-                                                           initial_states=init, group_map=gmap)
-            y, fin, dec = run_scan(K, *ins, initial_states=init.to(DEV), group_map=gmap)
-            close(y, y_ref, 2e-2, 4e-2, f"y {gmap}")
-            close(fin, fin_ref, 2e-2, 2e-2, f"final state {gmap}")
-            close(dec, dec_ref, 1e-4, 1e-4, "total decay")
-    finally:
-        K.ssd_scan_set_impl(0)
+    initial state in, final state / total decay out, 'tile' head->group map.  6 = the head-per-wave march (falls back to
+    4 / 3 by head_dim); 4 = whole-head work-groups (head_dim 56..80): from 2 048 tokens on (few heads) it marches 2 or 4
+    sequence segments concurrently and completes the later ones with the carried-in state correction; 3 = slices of a
+    head.  One fp32 recurrence (the CPU reference: most of the test's time) serves every kernel of a shape."""
+    impls = [6] + ([4] if 56 <= P <= 80 and L != 5000 else []) + ([3] if L < 1000 or P == 72 else [])
+    ins = scan_inputs(B, L, H, P, G, 128, 3 * L + H, torch.bfloat16)
+    g = torch.Generator().manual_seed(L)
+    init = torch.randn(B, H, P, 128, generator=g)
+    f = [t.float() for t in ins]
+    for gmap in ("block", "tile"):
+        y_ref, fin_ref, dec_ref = R.ssd_recurrence_ref(*f[:5], D=f[5], dt_bias=f[6], initial_states=init, group_map=gmap)
+        for impl in impls:
+            K.ssd_scan_set_impl(impl)
+            try:
+                y, fin, dec = run_scan(K, *ins, initial_states=init.to(DEV), group_map=gmap)
+            finally:
+                K.ssd_scan_set_impl(0)
+            close(y, y_ref, 2e-2, 4e-2, f"y {gmap} impl {impl}")
+            close(fin, fin_ref, 2e-2, 2e-2, f"final state {gmap} impl {impl}")
+            close(dec, dec_ref, 1e-4, 1e-4, f"total decay impl {impl}")
 
 
-@pytest.mark.parametrize("impl", [6, 4])
 @pytest.mark.parametrize("regime,a_lo,a_hi,dt_mean,dt_std", [
     ("no decay to speak of", 1e-4, 1e-3, -3.0, 0.3),       # 2^-0.01 a chunk: the frame never moves, the state grows with L
     ("slow", 0.05, 0.3, -1.0, 0.5),                       # a few bits a chunk: floating steps, a re-base every few chunks
@@ -289,7 +286,7 @@ def test_ssd_scan_march_kernels(K, impl, B, L, H, P, G):
     ("violent", 50.0, 200.0, 1.0, 2.0),                   # every chunk forgets everything: standard steps only
     ("token spikes", 0.01, 0.05, -2.0, 4.0),              # mostly slow, single tokens with dt ~ e^8
 ])
-def test_ssd_scan_decay_regimes(K, impl, regime, a_lo, a_hi, dt_mean, dt_std):
+def test_ssd_scan_decay_regimes(K, regime, a_lo, a_hi, dt_mean, dt_std):
     """Every step kind of the head-per-wave march (floating frame, re-base, reset, standard) and the hand-overs between
     them, against the fp32 recurrence; impl 4 (round 2's slice march) takes the same inputs.  Heads of one work-group
     get different A, so the kinds mix inside a work-group; 2 600 tokens = 2 - 4 sequence segments with carried-in
@@ -306,22 +303,23 @@ def test_ssd_scan_decay_regimes(K, impl, regime, a_lo, a_hi, dt_mean, dt_std):
     init = torch.randn(B, H, P, N, generator=g)
     f = [t.float() for t in ins]
     y_ref, fin_ref, dec_ref = R.ssd_recurrence_ref(*f[:5], D=f[5], dt_bias=f[6], initial_states=init)
-    K.ssd_scan_set_impl(impl)
-    try:
-        y, fin, dec = run_scan(K, *ins, initial_states=init.to(DEV))
-    finally:
-        K.ssd_scan_set_impl(0)
-    assert torch.isfinite(y.float()).all() and torch.isfinite(fin).all()
-    # y is bf16 and its terms are products of bf16-rounded operands (x~ = bf16(w x), C.B^T in bf16 — the reference's
-    # chunked kernels round the same way) summed with cancellation: the error is judged against the row's magnitude.
-    # Measured: 0.025 - 0.033 for both MFMA kernels in every regime (the fp32 generic kernel: 0.004 = the bf16 store).
-    scale = y_ref.abs().amax(dim=-1, keepdim=True).clamp_min(1.0)
-    err = ((y.float().cpu() - y_ref).abs() / scale).max().item()
-    assert err < 5e-2, (regime, err)
-    fscale = fin_ref.abs().amax().clamp_min(1.0)
-    ferr = ((fin.cpu() - fin_ref).abs().max() / fscale).item()
-    assert ferr < 1e-2, (regime, ferr)
-    close(dec, dec_ref, 1e-4, 1e-4 * max(1.0, float(dec_ref.abs().max())), "total decay")
+    for impl in (6, 4):                # (one reference for both kernels: the CPU recurrence is most of the test's time)
+        K.ssd_scan_set_impl(impl)
+        try:
+            y, fin, dec = run_scan(K, *ins, initial_states=init.to(DEV))
+        finally:
+            K.ssd_scan_set_impl(0)
+        assert torch.isfinite(y.float()).all() and torch.isfinite(fin).all()
+        # y is bf16 and its terms are products of bf16-rounded operands (x~ = bf16(w x), C.B^T in bf16 — the reference's
+        # chunked kernels round the same way) summed with cancellation: the error is judged against the row's magnitude.
+        # Measured: 0.025 - 0.033 for both MFMA kernels in every regime (the fp32 generic kernel: 0.004 = the bf16 store).
+        scale = y_ref.abs().amax(dim=-1, keepdim=True).clamp_min(1.0)
+        err = ((y.float().cpu() - y_ref).abs() / scale).max().item()
+        assert err < 5e-2, (regime, impl, err)
+        fscale = fin_ref.abs().amax().clamp_min(1.0)
+        ferr = ((fin.cpu() - fin_ref).abs().max() / fscale).item()
+        assert ferr < 1e-2, (regime, impl, ferr)
+        close(dec, dec_ref, 1e-4, 1e-4 * max(1.0, float(dec_ref.abs().max())), f"total decay (impl {impl})")
 
 
 @pytest.mark.parametrize("regime,a_lo,a_hi,dt_mean,dt_std,L", [

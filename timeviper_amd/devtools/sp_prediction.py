@@ -2,11 +2,11 @@
 single-GPU measurements and xGMI link rates, written as profiles/rNN_sp_prediction.json — a FALSIFIABLE artefact: the
 first SCALE run on a multi-GPU node can be judged against it component by component.
 
-    python timeviper_amd/devtools/sp_prediction.py [--round 5] [--step-ms 8355] [--out profiles/r05_sp_prediction.json]
+    python timeviper_amd/devtools/sp_prediction.py [--round 6] [--step-ms 8084] [--out profiles/r06_sp_prediction.json]
 
 Inputs (all stated in the output): the single-GPU step and its split (profiles/rNN_bench_final_summary.md), the scan's
-measured roofline fraction by sequence length (it falls with the shard: 0.338 at 163 940 tokens, 0.217 at 32 868, 0.116 at
-4 196: profiles/r04_config{2,3}.json), 153 GB/s per xGMI link and direction, 30 us per collective.
+measured roofline fraction by sequence length (it falls with the shard: 0.406 at 163 940 tokens, 0.277 at 32 868, 0.145 at
+4 196: profiles/r06_config{2,3}.json), 153 GB/s per xGMI link and direction, 30 us per collective.
 """
 import argparse
 import json
@@ -22,7 +22,7 @@ LAT = 30e-6                  # per collective
 
 def scan_frac(tokens):
     """measured points (tokens -> fraction of 8 TB/s), interpolated linearly in log2(tokens)"""
-    pts = [(4196, 0.116), (32868, 0.217), (163940, 0.338)]
+    pts = [(4196, 0.145), (32868, 0.277), (163940, 0.406)]        # profiles/r06_config{2,3}.json, r06_bench_plain_line.json
     if tokens <= pts[0][0]:
         return pts[0][1]
     for (a, fa), (b, fb) in zip(pts, pts[1:]):
@@ -77,11 +77,11 @@ def predict(n, step_ms, vit_ms, rowlocal_ms, attn_ms, rank_ms):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--round", type=int, default=5)
-    ap.add_argument("--step-ms", type=float, default=8355.0, help="measured single-GPU step")
+    ap.add_argument("--round", type=int, default=6)
+    ap.add_argument("--step-ms", type=float, default=8084.0, help="measured single-GPU step")
     ap.add_argument("--vit-frac", type=float, default=0.882, help="ViT + ToMe + projector share of the step")
-    ap.add_argument("--attn-ms", type=float, default=325.0, help="4 causal attention layers, single GPU")
-    ap.add_argument("--scan-ms", type=float, default=44.0, help="27 scans, single GPU")
+    ap.add_argument("--attn-ms", type=float, default=318.0, help="4 causal attention layers, single GPU")
+    ap.add_argument("--scan-ms", type=float, default=37.0, help="27 scans, single GPU")
     ap.add_argument("--rank-ms", type=float, default=3.0)
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
@@ -92,7 +92,7 @@ def main():
                 "the first measured SCALE run; ranges = state all-gather as direct peer copies / as a single-link ring",
         "inputs": {"single_gpu_step_ms": a.step_ms, "vit_share": a.vit_frac, "llm_row_local_ms": round(rowlocal, 1),
                    "causal_attention_ms": a.attn_ms, "scan_ms": a.scan_ms, "scan_bytes_per_token_layer": SCAN_BYTES,
-                   "scan_frac_by_tokens": {"4196": 0.116, "32868": 0.217, "163940": 0.338},
+                   "scan_frac_by_tokens": {"4196": 0.145, "32868": 0.277, "163940": 0.406},
                    "xgmi_link_GBps": LINK / 1e9, "collective_latency_us": LAT * 1e6, "state_bytes_per_rank_layer": STATE_BYTES},
         "predictions": [predict(n, a.step_ms, vit, rowlocal, a.attn_ms, a.rank_ms) for n in (2, 4, 8)],
     }
