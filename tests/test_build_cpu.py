@@ -1,3 +1,4 @@
+import os
 """Build-time checks on the gfx950 code objects (no GPU needed: hipcc cross-compiles, llvm-objdump / llvm-readelf read
 the result).
 
@@ -173,3 +174,53 @@ def test_gemm_drip_accumulator_registers_are_left_alone(tmp_path):
         if "scratch_" in ln:
             bad.append(ln.strip())
     assert not bad, bad[:10]
+
+@needs_tools
+def test_vit_attention_asm_kernel_keeps_out_of_the_body_s_registers(tmp_path):
+    """flash_fwd_vit_kernel (csrc/attention_vit.hpp) keeps P, the running maxima (v[TV_FAV_V0 ..]) and O / S / Q (a0 .. a231)
+    in named registers ACROSS the statements of a query block: between the block's first statement (TV_FAV_BEGIN_ASM) and
+    its last (TV_FAV_EPI_ASM) the compiler must use no vector register >= TV_FAV_V0 and no accumulation register below
+    232, and the kernel must have no scratch."""
+    md = kernel_metadata("attention.hip", tmp_path)
+    k = [v for n, v in md.items() if "flash_fwd_vit_kernel" in n]
+    assert len(k) == 1, list(md)
+    assert k[0].get("private_segment_fixed_size") == 0 and k[0].get("vgpr_spill_count", 0) == 0, k[0]
+    inc = (build.CSRC / "attention_vit_tile.inc").read_text()
+    v0 = int(re.search(r"#define TV_FAV_V0 (\d+)", inc).group(1))
+    asm = tmp_path / "attention.s"
+    subprocess.run([build.HIPCC, *build.FLAGS, f"-I{build.CSRC}", "-x", "hip", "-S", "--cuda-device-only",
+                    str(build.CSRC / "attention.hip"), "-o", str(asm)], check=True, capture_output=True)
+    text = asm.read_text()
+    body = text[text.index("flash_fwd_vit_kernel"):]
+    body = body[body.index(": ; @"):body.index(".amdhsa_kernel")]
+    inside, in_block, cur, bad = False, False, [], []
+    for line in body.splitlines():
+        if "#ASMSTART" in line:
+            inside, cur = True, []
+        elif "#ASMEND" in line:
+            inside = False
+            big = len(cur) > 40
+            mfmas = sum("v_mfma" in c for c in cur)
+            if big and mfmas == 0 and any("v_accvgpr_write_b32 a0, 0" in c for c in cur):
+                in_block = True                       # TV_FAV_BEGIN_ASM
+            elif big and mfmas == 36 and not any("v_exp_f32" in c for c in cur):
+                in_block = False                      # TV_FAV_EPI_ASM
+        elif inside:
+            cur.append(line)
+        elif in_block:
+            t = line.strip()
+            if not t or t.startswith((";", ".")):
+                continue
+            regs = [int(a or c) for a, b, c in re.findall(r"\bv(\d+)\b|v\[(\d+):(\d+)\]", t)]
+            aregs = [int(a or c) for a, b, c in re.findall(r"\ba(\d+)\b|a\[(\d+):(\d+)\]", t)]
+            if "scratch_" in t or any(r >= v0 for r in regs) or any(r < 232 for r in aregs):
+                bad.append(t)
+    assert not bad, bad[:5]
+
+
+def test_vit_attention_tile_include_is_what_the_generator_writes():
+    """csrc/attention_vit_tile.inc is generated (devtools/gen_fa_vit.py)."""
+    import sys
+    out = subprocess.run([sys.executable, str(build.ROOT / "devtools" / "gen_fa_vit.py")], check=True, capture_output=True,
+                         text=True, env={k: v for k, v in os.environ.items() if k != "TV_FAV_ABLATE"}).stdout
+    assert out == (build.CSRC / "attention_vit_tile.inc").read_text()

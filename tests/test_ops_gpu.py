@@ -618,6 +618,42 @@ def test_flash_attention_streaming_row_sums_on_the_matrix_pipe(K, dtype, B, Lq, 
     assert e1 < 1.05 * e0 + 1e-5, (e1.item(), e0.item())           # and is no further from the fp32 oracle
 
 
+@pytest.mark.parametrize("B,Lq,Lk,Hq,Hkv,D,sharp", [
+    (24, 729, 729, 16, 16, 72, 1.0),     # SigLIP frames: 8 key tiles, the last one holds 57 keys
+    (24, 729, 729, 16, 16, 72, 6.0),     # sharp rows with late spikes: the lazy maximum has to move (rescale path)
+    (13, 300, 300, 16, 16, 72, 1.0),     # 4 key tiles, 12 keys in the last; query rows past the end in the second block
+    (12, 400, 290, 16, 8, 80, 2.0),      # head_dim 80 (no pad column inside the k-steps), grouped K / V heads, Lq != Lk
+    (30, 1000, 1000, 16, 16, 72, 1.0),   # 4 query blocks, 11 key tiles
+])
+def test_flash_attention_generated_tile_loop(K, B, Lq, Lk, Hq, Hkv, D, sharp):
+    """`flash_attn_set_variant(4)`: the ViT kernel whose key-tile loop is a generated instruction stream
+    (csrc/attention_vit.hpp <- devtools/gen_fa_vit.py: one wave per SIMD, 64 query rows a wave, software-pipelined across
+    tiles, lazy running maximum) against the fp32 oracle and the default kernel: as close to the oracle as the default
+    kernel is, log-sum-exp to 2e-3, same bits on a second call."""
+    g = torch.Generator().manual_seed(Lq * 7 + Lk + D)
+    qkv = torch.randn(B, max(Lq, Lk), Hq + 2 * Hkv, D, generator=g).bfloat16().to(DEV)
+    q, k, v = qkv[:, :Lq, :Hq], qkv[:, :Lk, Hq:Hq + Hkv], qkv[:, :Lk, Hq + Hkv:]
+    q = q * sharp
+    if sharp > 2:
+        k[:, Lk - 3] *= 3.0                                        # a late key that lifts many rows' maxima by more than 2^24
+        k[:, 200] *= 2.0
+    o0, lse0 = K.flash_attn_func(q, k, v, causal=False, return_lse=True)
+    K.flash_attn_set_variant(4)
+    try:
+        o1, lse1 = K.flash_attn_func(q, k, v, causal=False, return_lse=True)
+        o2 = K.flash_attn_func(q, k, v, causal=False)
+    finally:
+        K.flash_attn_set_variant(0)
+    assert torch.isfinite(o1.float()).all() and torch.equal(o1, o2)
+    assert not torch.equal(o1, o0) or sharp == 0                   # (another kernel ran: P is rounded relative to another maximum)
+    o_ref, lse_ref = R.attention_ref(q.float().cpu(), k.float().cpu(), v.float().cpu(), False)
+    close(o1, o_ref, 2e-2, 1e-2, "o")
+    close(lse1, lse_ref, 1e-3, 2e-3, "lse")
+    e1 = (o1.float().cpu() - o_ref).norm() / o_ref.norm()
+    e0 = (o0.float().cpu() - o_ref).norm() / o_ref.norm()
+    assert e1 < 1.15 * e0 + 1e-5, (e1.item(), e0.item())
+
+
 def test_flash_attention_spiked_max(K):
     """force large running-max jumps at chosen tiles (guide rule 26)."""
     g = torch.Generator().manual_seed(0)

@@ -471,7 +471,8 @@ def ssd_scan_last_impl() -> int:
 # ------------------------------------------------------------------ attention
 def flash_attn_set_variant(variant: int) -> None:
     """0 auto (ViT frames: the streaming kernel, P's row sums out of the P.V MFMAs), 3 the same kernel with the row sums on
-    the vector pipe (A/B, tests); include/timeviper_hip.h.  Process-global (dev tools and tests)."""
+    the vector pipe (A/B, tests), 4 the generated-instruction-stream kernel (csrc/attention_vit.hpp, opt-in);
+    include/timeviper_hip.h.  Process-global (dev tools and tests)."""
     _capi.lib().tv_flash_attn_set_variant(int(variant))
 
 
