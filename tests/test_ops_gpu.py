@@ -600,9 +600,10 @@ def test_flash_attention_streaming_row_sums_on_the_matrix_pipe(K, dtype, B, Lq, 
     q, k, v = qkv[:, :Lq, :Hq], qkv[:, :Lk, Hq:Hq + Hkv], qkv[:, :Lk, Hq + Hkv:]
     q = q * 2.0                                                    # sharper rows: few keys carry the weight
     k[:, Lk - 1] *= 4.0
-    o1, lse1 = K.flash_attn_func(q, k, v, causal=False, return_lse=True)
-    K.flash_attn_set_variant(3)
+    K.flash_attn_set_variant(5)               # (the compiled streaming kernel; 0 = auto takes the generated tile loop for bf16)
     try:
+        o1, lse1 = K.flash_attn_func(q, k, v, causal=False, return_lse=True)
+        K.flash_attn_set_variant(3)
         o0, lse0 = K.flash_attn_func(q, k, v, causal=False, return_lse=True)
     finally:
         K.flash_attn_set_variant(0)
@@ -626,7 +627,7 @@ def test_flash_attention_streaming_row_sums_on_the_matrix_pipe(K, dtype, B, Lq, 
     (30, 1000, 1000, 16, 16, 72, 1.0),   # 4 query blocks, 11 key tiles
 ])
 def test_flash_attention_generated_tile_loop(K, B, Lq, Lk, Hq, Hkv, D, sharp):
-    """`flash_attn_set_variant(4)`: the ViT kernel whose key-tile loop is a generated instruction stream
+    """`flash_attn_set_variant(4)` (and 0 = auto for bf16): the ViT kernel whose key-tile loop is a generated instruction stream
     (csrc/attention_vit.hpp <- devtools/gen_fa_vit.py: one wave per SIMD, 64 query rows a wave, software-pipelined across
     tiles, lazy running maximum) against the fp32 oracle and the default kernel: as close to the oracle as the default
     kernel is, log-sum-exp to 2e-3, same bits on a second call."""
@@ -637,9 +638,10 @@ def test_flash_attention_generated_tile_loop(K, B, Lq, Lk, Hq, Hkv, D, sharp):
     if sharp > 2:
         k[:, Lk - 3] *= 3.0                                        # a late key that lifts many rows' maxima by more than 2^24
         k[:, 200] *= 2.0
-    o0, lse0 = K.flash_attn_func(q, k, v, causal=False, return_lse=True)
-    K.flash_attn_set_variant(4)
+    K.flash_attn_set_variant(5)               # the compiled streaming kernel
     try:
+        o0, lse0 = K.flash_attn_func(q, k, v, causal=False, return_lse=True)
+        K.flash_attn_set_variant(4)
         o1, lse1 = K.flash_attn_func(q, k, v, causal=False, return_lse=True)
         o2 = K.flash_attn_func(q, k, v, causal=False)
     finally:

@@ -854,13 +854,14 @@ int launch_fa_d(const AttnArgs& a, int B, hipStream_t st) {
           static const int trim_ = [] { const char* v = getenv("TV_FA_TRIM"); return v ? atoi(v) : 1; }();
           ax.notrim = !trim_;
           const dim3 grid_s((unsigned)(8 * (tv_cu_count() / 8)), 1, 1);
-          if (g_fa_variant.load(std::memory_order_relaxed) == 4 && std::is_same<T, bf16_t>::value && KS == 5 && DT == 3 && KT == 3 &&
+          const int variant = g_fa_variant.load(std::memory_order_relaxed);
+          if ((variant == 0 || variant == 4) && std::is_same<T, bf16_t>::value && KS == 5 && DT == 3 && KT == 3 && ones_ && trim_ &&
               a.D % 8 == 0 && a.D < 32 * DT && a.Lk > 2 * 32 * KT) {
             // the generated tile loop (attention_vit.hpp): one wave per SIMD, 64 query rows a wave
             ax.notrim = 0;
             e = hipFuncSetAttribute((const void*)flash_fwd_vit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (e == hipSuccess) flash_fwd_vit_kernel<<<grid_s, 256, lds, st>>>(ax);
-          } else if (ones_ && g_fa_variant.load(std::memory_order_relaxed) != 3 && a.D % 8 == 0 && a.D < 32 * DT) {
+          } else if (ones_ && variant != 3 && a.D % 8 == 0 && a.D < 32 * DT) {
             e = hipFuncSetAttribute((const void*)flash_fwd_stream_kernel<T, KS, DT, KT, true>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (e == hipSuccess) flash_fwd_stream_kernel<T, KS, DT, KT, true><<<grid_s, 512, lds, st>>>(ax);

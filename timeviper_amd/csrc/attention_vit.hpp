@@ -123,14 +123,23 @@ __global__ __launch_bounds__(256) void flash_fwd_vit_kernel(AttnArgs a) {
 #define VSTAMP(ph) do {} while (0)
 #endif
   int g = 0;                       // ring stage of the current block's tile 0
+  // the walk over this XCD's slots without a division per block: slot -> (pair, qblk), pair -> (batch, head)
+  const int sd = step / a.nqb, sm = step % a.nqb;
+  int pb = pair / a.Hq, ph = pair % a.Hq;
+  auto kv_base = [&](const void* base, int64_t sb, int64_t sh, int b_, int h_) {
+    return (const T*)base + (int64_t)b_ * sb + (int64_t)(gq == 1 ? h_ : h_ / gq) * sh;
+  };
   for (;;) {
     const int slot_n = slot + step;
-    const int pair_n = xcd * a.ppx + slot_n / a.nqb, qblk_n = slot_n % a.nqb;
+    int qblk_n = qblk + sm, pair_n = pair + sd;
+    if (qblk_n >= a.nqb) { qblk_n -= a.nqb; ++pair_n; }
+    int pb_n = pb, ph_n = ph + (pair_n - pair);
+    while (ph_n >= a.Hq) { ph_n -= a.Hq; ++pb_n; }
     const bool has_next = slot_n < nslots && pair_n < npairs;
-    const T* kp_n = has_next ? k_of(pair_n) : kp;
-    const T* vp_n = has_next ? v_of(pair_n) : vp;
+    const T* kp_n = has_next ? kv_base(a.k, a.ksb, a.ksh, pb_n, ph_n) : kp;
+    const T* vp_n = has_next ? kv_base(a.v, a.vsb, a.vsh, pb_n, ph_n) : vp;
     const int qb_n = has_next ? qblk_n : qblk;
-    const void* qsrc = ssdk::uniform_ptr(q_of(has_next ? pair_n : pair));
+    const void* qsrc = ssdk::uniform_ptr((const T*)a.q + (int64_t)(has_next ? pb_n : pb) * a.qsb + (int64_t)(has_next ? ph_n : ph) * a.qsh);
     const unsigned qox = q_off(qb_n, 0, false), qox4 = q_off(qb_n, 0, true), qoy = q_off(qb_n, 1, false), qoy4 = q_off(qb_n, 1, true);
 
     asm volatile(TV_FAV_BEGIN_ASM ::: TV_FAV_CLOBBERS);
@@ -202,10 +211,22 @@ __global__ __launch_bounds__(256) void flash_fwd_vit_kernel(AttnArgs a) {
     }
 
     // ---- normalise and store O[q][d] of this block (both units); the stores complete under the next block's first tiles
-    {
+    if (a.o16 && !a.lse && (D == 72 || D == 80)) {
+      const void* obase = ssdk::uniform_ptr((const T*)a.o + (int64_t)pb * a.osb + (int64_t)ph * a.osh);
+      const int qx = qblk * QB + wave * 64 + r, qy = qx + 32;
+      const unsigned rbx = (unsigned)(min(qx, a.Lq - 1) * (int)a.osl * (int)sizeof(T)), rby = (unsigned)(min(qy, a.Lq - 1) * (int)a.osl * (int)sizeof(T));
+      const unsigned oax = rbx + 16 * hh, obx = rbx + 8 * hh, oay = rby + 16 * hh, oby = rby + 8 * hh;
+      const unsigned long long maskx = __builtin_amdgcn_ballot_w64(qx < a.Lq), masky = __builtin_amdgcn_ballot_w64(qy < a.Lq);
+      if (D == 72)
+        asm volatile(TV_FAV_STORE72_ASM :: [obase] "s"(obase), [oax] "v"(oax), [obx] "v"(obx), [oay] "v"(oay), [oby] "v"(oby),
+                     [maskx] "s"(maskx), [masky] "s"(masky) : TV_FAV_CLOBBERS);
+      else
+        asm volatile(TV_FAV_STORE80_ASM :: [obase] "s"(obase), [oax] "v"(oax), [obx] "v"(obx), [oay] "v"(oay), [oby] "v"(oby),
+                     [maskx] "s"(maskx), [masky] "s"(masky) : TV_FAV_CLOBBERS);
+    } else {
       float mu_x, mu_y;              // the maxima the exponentials used (first: the store phase may take these registers)
       asm volatile("v_mov_b32 %0, v[%c2]\n\tv_mov_b32 %1, v[%c3]" : "=v"(mu_x), "=v"(mu_y) : "n"(TV_FAV_MU_X), "n"(TV_FAV_MU_Y));
-      const int h = pair % a.Hq, b = pair / a.Hq;
+      const int h = ph, b = pb;
       typedef unsigned u32x2s __attribute__((ext_vector_type(2)));
       typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
 #define FAV_STORE_UNIT(U, MUREG)                                                                                       \
@@ -218,7 +239,7 @@ __global__ __launch_bounds__(256) void flash_fwd_vit_kernel(AttnArgs a) {
         _Pragma("unroll") for (int gg = 0; gg < 4; ++gg) lv = gg == rl8 ? oc[DT - 1][4 * gg] : lv;                     \
         const float lo = __shfl_xor(lv, 32, 64);                                                                       \
         const float l_tot = hh ? lo : lv;                                                                              \
-        const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;                                                             \
+        const float inv = __builtin_amdgcn_rcpf(l_tot);          /* (as the generated store block; l >= 1) */                \
         T* op = (T*)a.o + (int64_t)b * a.osb + (int64_t)min(qrow, a.Lq - 1) * a.osl + (int64_t)h * a.osh;              \
         const bool rowok = qrow < a.Lq;                                                                                \
         _Pragma("unroll") for (int dt = 0; dt < DT; ++dt)                                                              \
@@ -262,7 +283,7 @@ __global__ __launch_bounds__(256) void flash_fwd_vit_kernel(AttnArgs a) {
 #endif
     if (!has_next) break;
     g = sg;                        // (sg has advanced by ntiles stages)
-    slot = slot_n; pair = pair_n; qblk = qblk_n; kp = kp_n; vp = vp_n;
+    slot = slot_n; pair = pair_n; qblk = qblk_n; kp = kp_n; vp = vp_n; pb = pb_n; ph = ph_n;
   }
 #ifdef TV_FA_STAMP
   if (blockIdx.x == 0 && tid == 0)

@@ -372,6 +372,45 @@ def begin_block():
     return out
 
 
+def store_block(D):
+    """O[q][d] = O^T accumulators / l of both units as bf16, 16 bytes a lane: a lane (r, hh) holds 4 consecutive d per group of four
+    accumulator registers (d = 32 dt + 8 g + 4 hh + 0..3); v_permlane32_swap joins the halves of two groups of the lane pair
+    (r, r + 32) into 16 contiguous bytes each.  l = the ones column's row: d-tile 2, register 4 (D - 64) / 8 of the hh = 0 lanes."""
+    ng = D // 8
+    out = []
+    W = SW[0]                       # scratch: the score registers are dead here
+    for u in range(2):
+        ob = OACC[u]
+        L, T, INV = W + 40, W + 41, W + 42        # INV: pair (inv, inv)
+        out += [f"v_accvgpr_read_b32 v{L}, a{ob + 32 + 4 * ((D - 64) // 8)}", f"v_accvgpr_read_b32 v{T}, a{ob + 32 + 4 * ((D - 64) // 8)}", "s_nop 1",
+                f"v_permlane32_swap_b32 v{T}, v{L}", "s_nop 1", f"v_rcp_f32_e32 v{INV}, v{T}", "s_nop 0", f"v_mov_b32_e32 v{INV + 1}, v{INV}",
+                f"s_mov_b64 exec, %[mask{'xy'[u]}]"]
+        gi = 0
+        k = 0
+        while gi < ng:
+            pair = gi + 1 < ng
+            R = W + 8 * (k % 4)       # 8 fp32 temporaries; the packed words land in R .. R + 3
+            k += 1
+            n = 8 if pair else 4
+            for j in range(n):
+                g2 = gi + j // 4
+                out.append(f"v_accvgpr_read_b32 v{R + j}, a{ob + 16 * (g2 // 4) + 4 * (g2 % 4) + j % 4}")
+            for j in range(0, n, 2):
+                out.append(f"v_pk_mul_f32 v[{R + j}:{R + j + 1}], v[{R + j}:{R + j + 1}], v[{INV}:{INV + 1}]")
+            # words: group gi -> R, R + 1; group gi + 1 -> R + 2, R + 3
+            for j in range(0, n, 2):
+                out.append(f"v_cvt_pk_bf16_f32 v{R + j // 2}, v{R + j}, v{R + j + 1}")
+            if pair:
+                out += ["s_nop 1", f"v_permlane32_swap_b32 v{R}, v{R + 2}", f"v_permlane32_swap_b32 v{R + 1}, v{R + 3}", "s_nop 1",
+                        f"global_store_dwordx4 %[oa{'xy'[u]}], v[{R}:{R + 3}], %[obase] offset:{16 * gi}"]
+                gi += 2
+            else:
+                out += ["s_nop 1", f"global_store_dwordx2 %[ob{'xy'[u]}], v[{R}:{R + 1}], %[obase] offset:{16 * gi}"]
+                gi += 1
+        out.append("s_mov_b64 exec, -1")
+    return out
+
+
 def macro(name, lines):
     return f"#define {name} \\\n" + " \\\n".join('  "' + l + '\\n\\t"' for l in lines) + "\n"
 
@@ -399,6 +438,7 @@ def main():
     s += clobbers()
     s += macro("TV_FAV_TILE_ASM", parts["tile"]) + macro("TV_FAV_TILEC_ASM", parts["tilec"]) + macro("TV_FAV_TILE0_ASM", parts["tile0"])
     s += macro("TV_FAV_LAST_ASM", parts["last"]) + macro("TV_FAV_PRO_ASM", parts["pro"])
+    s += macro("TV_FAV_STORE72_ASM", store_block(72)) + macro("TV_FAV_STORE80_ASM", store_block(80))
     s += macro("TV_FAV_EPI_ASM", parts["epi"]) + macro("TV_FAV_RESCALE_ASM", rescale()) + macro("TV_FAV_BEGIN_ASM", begin_block())
     sys.stdout.write(s)
 
