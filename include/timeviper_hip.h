@@ -318,14 +318,15 @@ int tv_flash_attn_fwd(const void* q, const void* k, const void* v, void* o,
                       float softmax_scale, int causal, int dtype, void* stream);
 
 /* Kernel variant for many short non-causal sequences of head_dim 65..80 (the SigLIP ViT frames; testing /
- * benchmarking, process-global): 0 = auto (the streaming kernel: 8 waves x 32 query rows, two waves per SIMD, P's row
- * sums out of the P.V MFMAs through a ones column in the V ring), 3 = the same kernel with the row sums on the vector
- * pipe (`l` summed in fp32 before P is rounded) — for A/B runs and tests; 4 (round 6, bf16, >= 193 keys) = the kernel with
- * the key-tile loop as generated instruction streams (csrc/attention_vit.hpp: one wave per SIMD, 64 query rows a wave,
- * softmax of tile i beside P.V of tile i - 1 and Q.K^T of tile i + 1, a lazy running maximum): 3 % faster in the forward,
- * results equal to the default kernel's within the bf16 rounding of P (not bit for bit: P is rounded relative to another
- * maximum) — opt-in.  (1 / 2 named two measured-slower kernels removed in round 6: docs/history.md; the values are
- * accepted and mean 0.)  Initial value: env TV_FA_W64. */
+ * benchmarking, process-global): 0 = auto — bf16, >= 193 keys: the kernel with the key-tile loop as generated instruction
+ * streams (csrc/attention_vit.hpp: one wave per SIMD, 64 query rows a wave, the softmax of tile i beside P.V of tile i - 1
+ * and Q.K^T of tile i + 1, a lazy running maximum; round 6), otherwise the compiled streaming kernel (8 waves x 32 query
+ * rows, two waves per SIMD); 4 = the same choice as 0; 5 = always the compiled streaming kernel (P's row sums out of the
+ * P.V MFMAs through a ones column in the V ring); 3 = the compiled kernel with the row sums on the vector pipe (`l` summed
+ * in fp32 before P is rounded) — 3 and 5 for A/B runs and tests.  The generated kernel's results equal the compiled one's
+ * within the bf16 rounding of P (not bit for bit: P is rounded relative to another maximum).  (1 / 2 named two
+ * measured-slower kernels removed in round 6: docs/history.md; the values are accepted and mean 0.)  Initial value: env
+ * TV_FA_W64. */
 void tv_flash_attn_set_variant(int variant);
 
 /* The same operator with the QK^T and PV products on the FP8 matrix path of CDNA4

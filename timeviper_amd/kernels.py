@@ -470,9 +470,9 @@ def ssd_scan_last_impl() -> int:
 
 # ------------------------------------------------------------------ attention
 def flash_attn_set_variant(variant: int) -> None:
-    """0 auto (ViT frames: the streaming kernel, P's row sums out of the P.V MFMAs), 3 the same kernel with the row sums on
-    the vector pipe (A/B, tests), 4 the generated-instruction-stream kernel (csrc/attention_vit.hpp, opt-in);
-    include/timeviper_hip.h.  Process-global (dev tools and tests)."""
+    """0 auto (bf16 ViT frames: the kernel with the generated tile loop, csrc/attention_vit.hpp; else the compiled streaming
+    kernel), 5 always the compiled streaming kernel (P's row sums out of the P.V MFMAs), 3 the compiled kernel with the row
+    sums on the vector pipe (A/B, tests); include/timeviper_hip.h.  Process-global (dev tools and tests)."""
     _capi.lib().tv_flash_attn_set_variant(int(variant))
 
 
