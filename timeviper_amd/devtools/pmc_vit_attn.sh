@@ -1,6 +1,6 @@
-# Dev tool: rocprofv3 PMC passes on the ViT attention kernel (TV_FA_W64=0: row sums out of the P.V MFMAs; 3: on the vector pipe).
+# Dev tool: rocprofv3 PMC passes on the ViT attention kernel (TV_FA_W64=0: the generated tile loop, the default; 5: the compiled streaming kernel).
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-for v in 0 3; do
+for v in 0 5; do
   export TV_FA_W64=$v
   i=0
   for set in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
