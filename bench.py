@@ -313,7 +313,7 @@ class OpTimers:
 
     def all_rooflines(self, bytes_per_token, cfg=None):
         out = [self.scan_roofline(bytes_per_token),
-               self.mfma_roofline("attn_vit", "flash_fwd_stream_kernel, ViT frames (non-causal, head_dim 72; useful FLOPs)"),
+               self.mfma_roofline("attn_vit", "flash_fwd_vit_kernel (generated tile loop; other dtypes: flash_fwd_stream_kernel), ViT frames (non-causal, head_dim 72; useful FLOPs)"),
                self.mfma_roofline("attn_causal", "flash_fwd_kernel, causal GQA (LLM attention layers; useful FLOPs)")]
         out.append(self.mfma_roofline("gemm_fused", "gemm_persist_kernel<bias + erf-GELU> (tv_gemm_bf16_fwd: ViT fc1 with the activation in "
                                                     "the epilogue, persistent work-groups; useful GEMM FLOPs only: 4 304 of the "
